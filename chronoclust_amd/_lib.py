@@ -1,0 +1,221 @@
+"""Thin ctypes binding of include/chronoclust_hip.h.  Fails loudly when the HIP library or a GPU is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+PCORE, OUTLIER = 0, 1
+MAX_DIM = 64
+
+_ERRORS = {-1: "no HIP device / HIP runtime error", -2: "bad argument", -3: "non-finite input", -4: "out of memory",
+           -5: "internal error"}
+
+
+class ChronoclustHipError(RuntimeError):
+    pass
+
+
+class CcParams(C.Structure):
+    _fields_ = [("eps_sq", C.c_double), ("delta_sq", C.c_double), ("k", C.c_double), ("beta", C.c_double),
+                ("mu", C.c_double), ("omicron", C.c_double), ("ups_eps", C.c_double), ("ups_eps_sq", C.c_double),
+                ("delta", C.c_double), ("pi", C.c_int32), ("pad", C.c_int32)]
+
+
+class CcTuning(C.Structure):
+    _fields_ = [("window", C.c_int32), ("rounds", C.c_int32), ("segments", C.c_int32),
+                ("windows_per_sync", C.c_int32), ("time_kernels", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class CcStats(C.Structure):
+    _fields_ = [("points", C.c_int64), ("windows", C.c_int64), ("rounds", C.c_int64), ("truncated", C.c_int64),
+                ("scan_launches", C.c_int64), ("scan_ms", C.c_double), ("scan_pair_dims", C.c_double),
+                ("run_ms", C.c_double), ("rows", C.c_int64), ("reserved", C.c_int64 * 7)]
+
+
+_dp = C.POINTER(C.c_double)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_i8p = C.POINTER(C.c_int8)
+
+# name -> (restype, argtypes): every symbol include/chronoclust_hip.h declares
+SYMBOLS = {
+    "cc_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "cc_destroy": (None, [C.c_void_p]),
+    "cc_last_error": (C.c_char_p, [C.c_void_p]),
+    "cc_set_tuning": (C.c_int, [C.c_void_p, C.POINTER(CcTuning)]),
+    "cc_set_params": (C.c_int, [C.c_void_p, C.POINTER(CcParams)]),
+    "cc_decay_downgrade": (C.c_int, [C.c_void_p, C.c_double]),
+    "cc_points_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32]),
+    "cc_online_run": (C.c_int, [C.c_void_p]),
+    "cc_labels_download": (C.c_int, [C.c_void_p, _i64p, _i8p]),
+    "cc_online": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _i64p, _i8p]),
+    "cc_count": (C.c_int, [C.c_void_p, C.c_int]),
+    "cc_dim": (C.c_int, [C.c_void_p]),
+    "cc_counters": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "cc_export": (C.c_int, [C.c_void_p, C.c_int, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp]),
+    "cc_inject_mc": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, _dp, _dp, _dp, _dp, C.c_double, C.c_int64,
+                               C.c_int64]),
+    "cc_offline": (C.c_int, [C.c_void_p, _i32p, _i8p, _i32p, _i32p, _i32p]),
+    "cc_num_core": (C.c_int, [C.c_void_p]),
+    "cc_cluster_size": (C.c_int, [C.c_void_p, C.c_int32]),
+    "cc_cluster_export": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _dp, _dp, _dp, _dp, _dp]),
+    "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
+    "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libchronoclust_hip.so (built in-tree by chronoclust_amd.build).  Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise ChronoclustHipError(
+                "HIP library %s not built; run `python -m chronoclust_amd.build` (needs hipcc). "
+                "chronoclust_amd has no CPU fallback." % path)
+        lib = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _ptr(a, typ=_dp):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Handle(object):
+    """One HDDStream state on one GPU."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.cc_create(int(device), C.byref(h))
+        if rc != 0:
+            raise ChronoclustHipError("cc_create(device=%d) failed: %s. chronoclust_amd needs an MI355X-class HIP "
+                                      "device; there is no CPU fallback." % (device, _ERRORS.get(rc, rc)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.cc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            msg = self._lib.cc_last_error(self._h)
+            exc = ValueError if rc in (-2, -3) else ChronoclustHipError
+            raise exc("%s: %s" % (_ERRORS.get(rc, rc), msg.decode() if msg else ""))
+        return rc
+
+    def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0):
+        t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels)
+        self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
+
+    def set_params(self, eps_sq, delta_sq, k, beta, mu, omicron, ups_eps, ups_eps_sq, delta, pi):
+        p = CcParams(eps_sq, delta_sq, k, beta, mu, omicron, ups_eps, ups_eps_sq, delta, int(pi), 0)
+        self._check(self._lib.cc_set_params(self._h, C.byref(p)))
+
+    def decay_downgrade(self, factor):
+        self._check(self._lib.cc_decay_downgrade(self._h, float(factor)))
+
+    def points_upload(self, x):
+        x = _f64(x)
+        if x.ndim != 2:
+            raise ValueError("points must be a 2-d array")
+        self._check(self._lib.cc_points_upload(self._h, _ptr(x), x.shape[0], x.shape[1]))
+        self._n = x.shape[0]
+
+    def online_run(self):
+        self._check(self._lib.cc_online_run(self._h))
+
+    def labels_download(self, want_path=True):
+        uid = np.empty(self._n, dtype=np.int64)
+        path = np.empty(self._n, dtype=np.int8) if want_path else None
+        self._check(self._lib.cc_labels_download(self._h, _ptr(uid, _i64p), _ptr(path, _i8p)))
+        return uid, path
+
+    def online(self, x):
+        self.points_upload(x)
+        self.online_run()
+        return self.labels_download()
+
+    def count(self, kind):
+        return self._check(self._lib.cc_count(self._h, kind))
+
+    def dim(self):
+        return self._check(self._lib.cc_dim(self._h))
+
+    def counters(self):
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.cc_counters(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def export(self, kind):
+        n, d = self.count(kind), self.dim()
+        out = dict(id=np.empty(n, np.int64), uid=np.empty(n, np.int64), w=np.empty(n, np.float64),
+                   cf1=np.empty((n, d)), cf2=np.empty((n, d)), cen=np.empty((n, d)), pref=np.empty((n, d)))
+        self._check(self._lib.cc_export(self._h, kind, _ptr(out["id"], _i64p), _ptr(out["uid"], _i64p), _ptr(out["w"]),
+                                        _ptr(out["cf1"]), _ptr(out["cf2"]), _ptr(out["cen"]), _ptr(out["pref"])))
+        return out
+
+    def inject(self, kind, cf1, cf2, cen, pref, w, id, uid):
+        cf1, cf2, cen, pref = _f64(cf1), _f64(cf2), _f64(cen), _f64(pref)
+        self._check(self._lib.cc_inject_mc(self._h, kind, len(cf1), _ptr(cf1), _ptr(cf2), _ptr(cen), _ptr(pref),
+                                           float(w), int(id), int(uid)))
+
+    def offline(self, dumps=False):
+        n = C.c_int32()
+        m = self.count(PCORE) if dumps else 0
+        core = np.zeros(m, np.int8) if dumps else None
+        pdim, nn, nw = ((np.zeros(m, np.int32) for _ in range(3)) if dumps else (None, None, None))
+        self._check(self._lib.cc_offline(self._h, C.byref(n), _ptr(core, _i8p), _ptr(pdim, _i32p), _ptr(nn, _i32p),
+                                         _ptr(nw, _i32p)))
+        d = self.dim()
+        clusters = []
+        for c in range(n.value):
+            sz = self._check(self._lib.cc_cluster_size(self._h, c))
+            mem = np.empty(sz, np.int64)
+            w = C.c_double()
+            cf1, cf2, cen, pref = (np.empty(d) for _ in range(4))
+            self._check(self._lib.cc_cluster_export(self._h, c, _ptr(mem, _i64p), C.byref(w), _ptr(cf1), _ptr(cf2),
+                                                    _ptr(cen), _ptr(pref)))
+            clusters.append(dict(members=mem, w=w.value, cf1=cf1, cf2=cf2, cen=cen, pref=pref))
+        info = dict(core=core, pdim=pdim, nn=nn, nw=nw) if dumps else None
+        return clusters, info
+
+    def num_core(self):
+        return self._check(self._lib.cc_num_core(self._h))
+
+    def assoc_argmin(self, cur_cen, cur_pref, prev_cen):
+        cc, cp, pc = _f64(cur_cen), _f64(cur_pref), _f64(prev_cen)
+        mc, d = cc.shape
+        mp = pc.shape[0]
+        idx = np.empty(mc, np.int32)
+        dist = np.empty(mc, np.float64)
+        self._check(self._lib.cc_assoc_argmin(self._h, _ptr(cc), _ptr(cp), mc, _ptr(pc), mp, d, _ptr(idx, _i32p),
+                                              _ptr(dist)))
+        return idx, dist
+
+    def stats(self):
+        s = CcStats()
+        self._check(self._lib.cc_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in CcStats._fields_ if k != "reserved"}

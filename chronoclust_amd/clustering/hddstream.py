@@ -1,0 +1,177 @@
+"""HDDStream on MI355X: the interface of chronoclust/clustering/hddstream.py:29-549, the state in HBM.
+
+`online_microcluster_maintenance(X, daystamp)` performs, in this order and with the reference's semantics,
+  1. dataset-dependent parameters                       (hddstream.py:89-128)     host, Python
+  2. decay + downgrade + delete when the daystamp moved (hddstream.py:199-213)    cc_decay_downgrade
+  3. the per-point online loop, exact                   (hddstream.py:220-237)    cc_online
+  4. the offline PreDeCon phase                         (hddstream.py:464-510)    cc_offline
+through the C-ABI of include/chronoclust_hip.h.  Derived parameters use the reference's own Python
+expressions so thresholds are the same doubles.
+"""
+import logging
+import sys
+
+import numpy as np
+
+from .. import _lib
+from ..objects.microcluster import ClusterView, MicroclusterView
+
+
+class HDDStream(object):
+    def __init__(self, config, logger=None, device=0, tuning=None):
+        self.config = config
+        self.logger = logger if logger is not None else logging.getLogger("chronoclust_amd")
+        self.pi = None
+        self.mu = None
+        self.omicron = None
+        self.epsilon = float(config['epsilon'])
+        self.epsilon_squared = self.epsilon ** 2
+        self.upsilon = float(config['upsilon']) * self.epsilon
+        self.delta = self._checked_delta()
+        self.delta_squared = self.delta ** 2
+        self.beta = float(config['beta'])
+        self.k = float(config['k'])
+        self.lambbda = float(config['lambda'])
+        self.last_data_timestamp = 0
+        self.dataset_dimensionality = 0
+        self.dataset_size = 0
+
+        self._h = _lib.Handle(device)
+        if tuning:
+            self._h.set_tuning(**tuning)
+        self._X = None
+        self.labels_uid = None   # per row of the last call: creation number of the MC that holds it
+        self.labels_path = None
+        self._tables = {}
+        self._clusters = None
+        self._uid_rows = None
+
+    # ---- parameters -----------------------------------------------------------------------------
+
+    def _checked_delta(self):
+        delta = float(self.config['delta'])
+        if delta > 1 or delta < 0:  # hddstream.py:148-149
+            sys.exit("Given delta ({}) is out of range. Must be within 0-1.".format(delta))
+        return delta
+
+    def set_logger(self, logger):
+        self.logger = logger
+
+    def set_config(self, config):
+        self.config = config
+
+    def _set_dataset_dependent_parameters(self, input_dataset):
+        n, d = input_dataset.shape
+        self.dataset_dimensionality = d
+        config_pi = float(self.config['pi'])
+        self.pi = d if config_pi <= 0 else round(config_pi)
+        self.omicron = self.config['omicron'] * self.dataset_size  # previous timepoint's size
+        self.dataset_size = n
+        self.mu = float(self.config['mu']) * self.dataset_size
+
+    def _push_params(self):
+        self._h.set_params(self.epsilon_squared, self.delta_squared, self.k, self.beta, float(self.mu),
+                           float(self.omicron), self.upsilon, self.upsilon ** 2, self.delta, int(self.pi))
+
+    # ---- the timestep ---------------------------------------------------------------------------
+
+    def online_microcluster_maintenance(self, input_dataset, input_dataset_daystamp, reset_param=True):
+        X = np.ascontiguousarray(np.asarray(input_dataset, dtype=np.float64))
+        if X.ndim != 2:
+            raise ValueError("input_dataset must be 2-d [N, d]")
+        if reset_param:
+            self._set_dataset_dependent_parameters(X)
+        self._push_params()
+        log = self.logger
+        log.info(f"Setting up online phase for timepoint {input_dataset_daystamp} with following params:\n"
+                 f"Pcore density threshold factor(beta) = {self.beta}\n"
+                 f"Decay rate(lambda) = {self.lambbda}\n"
+                 f"Radius threshold(epsilon) = {self.epsilon}\n"
+                 f"Max projected dimensionality(pi) = {self.pi}\n"
+                 f"Density threshold(mu) = {self.mu} = {self.mu}\n"
+                 f"Variance threshold(delta) = {self.delta}\n"
+                 f"K = {self.k}\n"
+                 f"PreDeCon epsilon(upsilon) = {self.upsilon}\n"
+                 f"Outlier deletion point(omicron) = {self.omicron}\n")
+        self._invalidate()
+        if (self.last_data_timestamp - input_dataset_daystamp) != 0:
+            log.info("Decaying and downgrading microclusters")
+            interval = input_dataset_daystamp - self.last_data_timestamp
+            self._h.decay_downgrade(2 ** (-self.lambbda * interval))  # hddstream.py:283
+
+        log.info("Starting online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
+        self._X = X
+        if X.shape[0] > 0:
+            self.labels_uid, self.labels_path = self._h.online(X)
+        else:
+            self.labels_uid, self.labels_path = np.empty(0, np.int64), np.empty(0, np.int8)
+        log.info("Finish online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
+        log.info("Online maintenance yield {} pcores and {} outlier".format(
+            self._h.count(_lib.PCORE), self._h.count(_lib.OUTLIER)))
+        self.last_data_timestamp = input_dataset_daystamp
+        self.offline_clustering(input_dataset_daystamp)
+
+    def offline_clustering(self, dataset_daystamp):
+        self._push_params()
+        clusters, _ = self._h.offline()
+        num_core = self._h.num_core()
+        num_pcore = self._h.count(_lib.PCORE) - num_core
+        self.logger.info(f'Starting offline clustering with {num_core} core clusters and {num_pcore} pcore clusters.')
+        self._clusters = [ClusterView(c["members"], c["w"], c["cf1"], c["cf2"], c["cen"], c["pref"])
+                          for c in clusters]
+        self.logger.info('Finish offline clustering for dataset with timepoint: {}'.format(dataset_daystamp))
+        self.logger.info("Offline clustering yield {} clusters.".format(len(self._clusters)))
+
+    # ---- results ---------------------------------------------------------------------------------
+
+    def _invalidate(self):
+        self._tables = {}
+        self._clusters = None
+        self._uid_rows = None
+
+    def table(self, kind):
+        """dict of arrays (id, uid, w, cf1, cf2, cen, pref) for the pcore (0) or outlier (1) list, list order."""
+        if kind not in self._tables:
+            self._tables[kind] = self._h.export(kind)
+        return self._tables[kind]
+
+    def _views(self, kind):
+        t = self.table(kind)
+        return [MicroclusterView(t["id"][i], t["cf1"][i], t["cf2"][i], t["w"][i], t["cen"][i], t["pref"][i],
+                                 t["uid"][i], owner=self) for i in range(len(t["id"]))]
+
+    @property
+    def pcore_MC(self):
+        return self._views(_lib.PCORE)
+
+    @property
+    def outlier_MC(self):
+        return self._views(_lib.OUTLIER)
+
+    @property
+    def final_clusters(self):
+        return [] if self._clusters is None else self._clusters
+
+    @property
+    def pcore_MC_last_id(self):
+        return self._h.counters()[0]
+
+    @property
+    def outlier_MC_last_id(self):
+        return self._h.counters()[1]
+
+    def _points_of(self, uid):
+        if self.labels_uid is None or self._X is None:
+            return {}
+        if self._uid_rows is None:
+            order = np.argsort(self.labels_uid, kind="stable")
+            keys, starts = np.unique(self.labels_uid[order], return_index=True)
+            bounds = np.append(starts, len(order))
+            self._uid_rows = {int(k): order[bounds[i]:bounds[i + 1]] for i, k in enumerate(keys)}
+        rows = self._uid_rows.get(int(uid))
+        if rows is None:
+            return {}
+        return {int(r): self._X[r].tolist() for r in rows}
+
+    def stats(self):
+        return self._h.stats()

@@ -1,0 +1,874 @@
+// cc_api.hip — host side of the C-ABI declared in include/chronoclust_hip.h.
+// Owns the HBM-resident state (microcluster table, window buffers, points, labels) and enqueues the gfx950
+// kernels of cc_online.h / cc_offline.h on one HIP stream.  No CPU fallback exists for any kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/chronoclust_hip.h"
+#include "cc_common.h"
+#include "cc_online.h"
+#include "cc_offline.h"
+
+namespace {
+
+struct HipErr {
+    hipError_t e;
+    const char* what;
+};
+
+#define HIPCHK(call)                                  \
+    do {                                              \
+        hipError_t _e = (call);                       \
+        if (_e != hipSuccess) throw HipErr{_e, #call}; \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void ensure(size_t count)
+    {
+        if (count <= n && p) return;
+        release();
+        size_t want = std::max<size_t>(count, 1);
+        if (hipMalloc((void**)&p, want * sizeof(T)) != hipSuccess) {
+            p = nullptr;
+            throw HipErr{hipErrorOutOfMemory, "hipMalloc"};
+        }
+        n = want;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+};
+
+struct TableStore {
+    DevBuf<double> cf1, cf2, cen, pref, w;
+    DevBuf<int> kind, key;
+    DevBuf<long long> id, uid;
+    DevBuf<unsigned long long> touch;
+    size_t cap = 0;
+    int d = 0;
+    void alloc(size_t rows, int dim)
+    {
+        cf1.ensure(rows * dim); cf2.ensure(rows * dim); cen.ensure(rows * dim); pref.ensure(rows * dim);
+        w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(rows);
+        cap = rows;
+        d = dim;
+    }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, w.p, kind.p, key.p, id.p, uid.p, touch.p}; }
+    void swap(TableStore& o)
+    {
+        std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
+        std::swap(cen.p, o.cen.p); std::swap(cen.n, o.cen.n); std::swap(pref.p, o.pref.p); std::swap(pref.n, o.pref.n);
+        std::swap(w.p, o.w.p); std::swap(w.n, o.w.n); std::swap(kind.p, o.kind.p); std::swap(kind.n, o.kind.n);
+        std::swap(key.p, o.key.p); std::swap(key.n, o.key.n); std::swap(id.p, o.id.p); std::swap(id.n, o.id.n);
+        std::swap(uid.p, o.uid.p); std::swap(uid.n, o.uid.n); std::swap(touch.p, o.touch.p); std::swap(touch.n, o.touch.n);
+        std::swap(cap, o.cap); std::swap(d, o.d);
+    }
+};
+
+struct HostCluster {
+    std::vector<int> members;  // pcore list positions in merge order
+};
+
+}  // namespace
+
+struct cc_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    cc_params par{};
+    bool have_par = false;
+    cc_tuning tun{};
+    cc_stats stats{};
+
+    int d = 0;
+    TableStore tab, tab2;
+    Ctl hc{};  // host mirror of the device control block
+    DevBuf<Ctl> ctl;
+    bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
+
+    // points + labels of the current call
+    DevBuf<double> X;
+    long long n_points = 0;
+    DevBuf<long long> lab_uid;
+    DevBuf<int8_t> lab_path;
+    DevBuf<int> badflag;
+
+    // window buffers
+    int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
+    DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_w;
+    DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
+    DevBuf<Cand> part, clean, dpart;
+    DevBuf<int> T0, T1;
+    DevBuf<int8_t> dpath;
+
+    // offline results
+    DevBuf<double> pv_cf1, pv_cf2, pv_cen, pv_pref, pv_w, wvec;
+    DevBuf<long long> pv_id;
+    DevBuf<int> prow, nn, pdim, mem_dev, off_dev;
+    DevBuf<int8_t> core;
+    DevBuf<unsigned long long> adj, adjw;
+    DevBuf<double> c_cf1, c_cf2, c_cen, c_pref, c_w;
+    std::vector<HostCluster> clusters;
+    std::vector<long long> pcore_ids_host;
+    int n_core = 0;
+
+    // association scratch
+    DevBuf<double> a_cur_cen, a_cur_pref, a_prev_cen, a_dist;
+    DevBuf<int> a_idx;
+    DevBuf<int> flags;
+
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(cc_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+
+template <typename F>
+int guarded(cc_handle* h, F&& f)
+{
+    try {
+        if (h) HIPCHK(hipSetDevice(h->device));
+        return f();
+    } catch (const HipErr& e) {
+        char buf[512];
+        snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
+        return fail(h, e.e == hipErrorOutOfMemory ? CC_ERR_OOM : CC_ERR_NO_DEVICE, buf);
+    } catch (const std::bad_alloc&) {
+        return fail(h, CC_ERR_OOM, "host allocation failed");
+    }
+}
+
+bool is_pow2(double k)
+{
+    if (!(k > 0.0) || !std::isfinite(k)) return false;
+    int e;
+    double m = std::frexp(k, &e);
+    return m == 0.5 && e > -1000 && e < 1000;
+}
+
+void refresh_ctl_params(cc_handle* h)
+{
+    Ctl& c = h->hc;
+    const cc_params& p = h->par;
+    c.eps_sq = p.eps_sq;
+    c.delta_sq = p.delta_sq;
+    c.k = p.k;
+    c.pow2 = (is_pow2(p.k) && !h->tainted) ? 1 : 0;
+    c.inv_k = c.pow2 ? 1.0 / p.k : 0.0;
+    c.beta_mu = p.beta * p.mu;  // hddstream.py:416, 529
+    c.mu = p.mu;
+    c.omicron = p.omicron;
+    c.pi = p.pi;
+    c.filter = (h->d > 0 && p.pi < h->d) ? 1 : 0;
+    c.d = h->d;
+}
+
+void push_ctl(cc_handle* h) { HIPCHK(hipMemcpyAsync(h->ctl.p, &h->hc, sizeof(Ctl), hipMemcpyHostToDevice, h->stream)); }
+void pull_ctl(cc_handle* h)
+{
+    HIPCHK(hipMemcpyAsync(&h->hc, h->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+}
+
+// grow the table to at least `rows` rows, keeping the first m_rows rows
+void ensure_table(cc_handle* h, size_t rows)
+{
+    if (h->tab.cap >= rows && h->tab.d == h->d) return;
+    size_t want = std::max<size_t>(rows, std::max<size_t>(1024, h->tab.cap * 2));
+    TableStore nt;
+    nt.alloc(want, h->d);
+    const size_t m = (size_t)h->hc.m_rows, d = (size_t)h->d;
+    if (m > 0) {
+        const TableStore& o = h->tab;
+        HIPCHK(hipMemcpyAsync(nt.cf1.p, o.cf1.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.cf2.p, o.cf2.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.cen.p, o.cen.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.pref.p, o.pref.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.w.p, o.w.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.kind.p, o.kind.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.key.p, o.key.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.id.p, o.id.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.uid.p, o.uid.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
+    }
+    HIPCHK(hipMemsetAsync(nt.touch.p, 0, want * 8, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tab.swap(nt);
+}
+
+int set_dim(cc_handle* h, int d)
+{
+    if (d <= 0 || d > CC_MAX_DIM) return fail(h, CC_ERR_BAD_ARG, "d must be in 1.." + std::to_string(CC_MAX_DIM));
+    if (h->d == 0) h->d = d;
+    if (h->d != d) {
+        if (h->hc.m_rows == 0) h->d = d;
+        else return fail(h, CC_ERR_BAD_ARG, "dimensionality differs from the microclusters already held");
+    }
+    return CC_OK;
+}
+
+void ensure_window_buffers(cc_handle* h, int win, int seg)
+{
+    if (win <= h->win_alloc && seg <= h->seg_alloc && h->d <= h->d_alloc) return;
+    win = std::max(win, h->win_alloc);
+    seg = std::max(seg, h->seg_alloc);
+    const size_t w = (size_t)win, d = (size_t)std::max(h->d, h->d_alloc);
+    h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_w.ensure(w);
+    h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
+    h->v_tgt.ensure(w);
+    h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4);
+    h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w);
+    h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
+}
+
+Versions versions_view(cc_handle* h)
+{
+    return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_w.p, h->v_kind.p,
+                    h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p};
+}
+
+// ---- scan dispatch over the padded dimensionality ---------------------------------
+
+template <int DP, bool DIRTY>
+void launch_scan_dp(cc_handle* h, dim3 grid, Rows rows, const Cand* clean, Cand* part, int S, int round)
+{
+    if (h->hc.pow2)
+        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY>), grid, dim3(64), 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+                           part, S, round);
+    else
+        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY>), grid, dim3(64), 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+                           part, S, round);
+}
+
+template <bool DIRTY>
+void launch_scan(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part, int S, int round)
+{
+    dim3 grid((win + 63) / 64, S);
+    const int d = h->d;
+    if (d <= 4) launch_scan_dp<4, DIRTY>(h, grid, rows, clean, part, S, round);
+    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, grid, rows, clean, part, S, round);
+    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, grid, rows, clean, part, S, round);
+    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, grid, rows, clean, part, S, round);
+    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, grid, rows, clean, part, S, round);
+    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, grid, rows, clean, part, S, round);
+    else launch_scan_dp<64, DIRTY>(h, grid, rows, clean, part, S, round);
+}
+
+hipEvent_t get_event(cc_handle* h, size_t i)
+{
+    while (h->ev_pool.size() <= i) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->ev_pool.push_back(e);
+    }
+    return h->ev_pool[i];
+}
+
+struct RowList {
+    std::vector<int> pcore, outlier;  // table rows in Python list order
+};
+
+// list order = ascending key within a kind
+RowList list_order(cc_handle* h, std::vector<int>* kind_out = nullptr, std::vector<int>* key_out = nullptr)
+{
+    const int m = h->hc.m_rows;
+    std::vector<int> kind(m), key(m);
+    if (m) {
+        HIPCHK(hipMemcpyAsync(kind.data(), h->tab.kind.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(key.data(), h->tab.key.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    RowList rl;
+    for (int r = 0; r < m; ++r) {
+        if (kind[r] == CC_KIND_PCORE) rl.pcore.push_back(r);
+        else if (kind[r] == CC_KIND_OUTLIER) rl.outlier.push_back(r);
+    }
+    auto by_key = [&](int a, int b) { return key[a] < key[b]; };
+    std::sort(rl.pcore.begin(), rl.pcore.end(), by_key);
+    std::sort(rl.outlier.begin(), rl.outlier.end(), by_key);
+    if (kind_out) *kind_out = kind;
+    if (key_out) *key_out = key;
+    return rl;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+
+extern "C" {
+
+int cc_create(int device, cc_handle** out)
+{
+    if (!out) return CC_ERR_BAD_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return CC_ERR_NO_DEVICE;
+    cc_handle* h = new (std::nothrow) cc_handle();
+    if (!h) return CC_ERR_OOM;
+    h->device = device;
+    int rc = guarded(h, [&]() {
+        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->ctl.ensure(1);
+        h->badflag.ensure(1);
+        memset(&h->hc, 0, sizeof(Ctl));
+        h->tun.window = 1024;
+        h->tun.rounds = 3;
+        h->tun.segments = 64;
+        h->tun.windows_per_sync = 16;
+        h->tun.time_kernels = 0;
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return CC_OK;
+    });
+    if (rc != CC_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return CC_OK;
+}
+
+void cc_destroy(cc_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamDestroy(h->stream);
+    }
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    delete h;
+}
+
+const char* cc_last_error(const cc_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int cc_set_tuning(cc_handle* h, const cc_tuning* t)
+{
+    if (!h || !t) return CC_ERR_BAD_ARG;
+    if (t->window > 0) h->tun.window = std::min(t->window, 4096);
+    if (t->rounds > 0) h->tun.rounds = std::min(t->rounds, CC_MAX_ROUNDS);
+    if (t->segments > 0) h->tun.segments = std::min(t->segments, 1024);
+    if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
+    h->tun.time_kernels = t->time_kernels;
+    return CC_OK;
+}
+
+int cc_set_params(cc_handle* h, const cc_params* p)
+{
+    if (!h || !p) return CC_ERR_BAD_ARG;
+    if (h->have_par && h->hc.m_rows > 0 && p->k != h->par.k) h->tainted = true;  // old rows keep their old k
+    h->par = *p;
+    h->have_par = true;
+    refresh_ctl_params(h);
+    return CC_OK;
+}
+
+int cc_dim(cc_handle* h) { return h ? h->d : CC_ERR_BAD_ARG; }
+
+int cc_counters(cc_handle* h, int64_t* pcore_last_id, int64_t* outlier_last_id)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (pcore_last_id) *pcore_last_id = h->hc.pcore_last_id;
+    if (outlier_last_id) *outlier_last_id = h->hc.outlier_last_id;
+    return CC_OK;
+}
+
+int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d)
+{
+    if (!h || (!x && n > 0) || n < 0) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        int rc = set_dim(h, d);
+        if (rc != CC_OK) return rc;
+        h->X.ensure((size_t)n * d);
+        h->lab_uid.ensure((size_t)n);
+        h->lab_path.ensure((size_t)n);
+        h->n_points = n;
+        if (n == 0) return (int)CC_OK;
+        HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
+        const long long tot = (long long)n * d;
+        int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
+        int bad = 0;
+        HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (bad) {
+            h->n_points = 0;
+            return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
+        }
+        return (int)CC_OK;
+    });
+}
+
+int cc_online_run(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
+    return guarded(h, [&]() {
+        const long long N = h->n_points;
+        const int win = h->tun.window, R = h->tun.rounds, S = h->tun.segments;
+        memset(&h->stats, 0, sizeof(h->stats));
+        if (N == 0) return (int)CC_OK;
+        if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
+        refresh_ctl_params(h);
+        ensure_window_buffers(h, win, S);
+        ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * h->tun.windows_per_sync + 1);
+
+        Ctl& c = h->hc;
+        c.cursor = 0;
+        c.n_points = N;
+        c.win_cfg = win;
+        c.win_b = (int)std::min<long long>(win, N);
+        c.max_rounds = R;
+        c.last_round = 0;
+        c.fc[0] = 0;
+        for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) c.fc[i] = CC_IDX_INF;
+        c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
+        push_ctl(h);
+
+        hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
+        HIPCHK(hipEventRecord(ev0, h->stream));
+        size_t ev_used = 2;
+        std::vector<std::pair<size_t, double>> timed;  // (event index, pair-dims covered)
+        const bool timing = h->tun.time_kernels != 0;
+
+        const Versions ver = versions_view(h);
+        const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
+        const int dblocks = (win + 63) / 64;
+        const int cblocks = (win + 255) / 256;
+        const size_t commit_lds = ((size_t)2 * win + 1024) * sizeof(int);
+        long long done = 0;
+        int m_known = c.m_rows;
+        while (done < N) {
+            ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
+            const Table tab = h->tab.view();
+            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
+            for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
+                if (timing) {
+                    hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
+                    HIPCHK(hipEventRecord(a, h->stream));
+                    launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
+                    HIPCHK(hipEventRecord(b, h->stream));
+                    timed.push_back({ev_used, 0.0});
+                    ev_used += 2;
+                } else {
+                    launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
+                }
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                                   h->part.p, h->clean.p, h->dpart.p, (const int*)nullptr, h->T0.p, h->dpath.p, S, 0);
+                for (int r = 1; r <= R; ++r) {
+                    const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
+                    int* tnew = (r & 1) ? h->T1.p : h->T0.p;
+                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)win * sizeof(int), h->stream,
+                                       h->ctl.p, h->X.p, tab, ver, told, r);
+                    launch_scan<true>(h, win, vrows, h->clean.p, h->dpart.p, S, r);
+                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                                       h->part.p, h->clean.p, h->dpart.p, told, tnew, h->dpath.p, S, r);
+                }
+                hipLaunchKernelGGL(k_commit, dim3(1), dim3(1024), commit_lds, h->stream, h->ctl.p, tab, ver, h->T0.p,
+                                   h->T1.p, h->dpath.p, h->lab_uid.p, h->lab_path.p);
+            }
+            HIPCHK(hipGetLastError());
+            pull_ctl(h);
+            done = h->hc.cursor;
+            m_known = h->hc.m_rows;
+        }
+        HIPCHK(hipEventRecord(ev1, h->stream));
+        HIPCHK(hipEventSynchronize(ev1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
+        h->stats.run_ms = ms;
+        h->stats.points = N;
+        h->stats.windows = h->hc.stat_windows;
+        h->stats.rounds = h->hc.stat_rounds;
+        h->stats.truncated = h->hc.stat_truncated;
+        h->stats.rows = h->hc.m_rows;
+        if (timing) {
+            double tot = 0.0;
+            for (auto& t : timed) {
+                float e = 0.f;
+                HIPCHK(hipEventElapsedTime(&e, h->ev_pool[t.first], h->ev_pool[t.first + 1]));
+                tot += e;
+            }
+            h->stats.scan_launches = (int64_t)timed.size();
+            h->stats.scan_ms = tot;
+        }
+        return (int)CC_OK;
+    });
+}
+
+int cc_labels_download(cc_handle* h, int64_t* out_uid, int8_t* out_path)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        const size_t n = (size_t)h->n_points;
+        if (n == 0) return (int)CC_OK;
+        static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+        if (out_uid) HIPCHK(hipMemcpyAsync(out_uid, h->lab_uid.p, n * 8, hipMemcpyDeviceToHost, h->stream));
+        if (out_path) HIPCHK(hipMemcpyAsync(out_path, h->lab_path.p, n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
+int cc_online(cc_handle* h, const double* x, int64_t n, int32_t d, int64_t* out_uid, int8_t* out_path)
+{
+    int rc = cc_points_upload(h, x, n, d);
+    if (rc != CC_OK) return rc;
+    rc = cc_online_run(h);
+    if (rc != CC_OK) return rc;
+    return cc_labels_download(h, out_uid, out_path);
+}
+
+int cc_count(cc_handle* h, int kind)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    int n = 0;
+    int rc = guarded(h, [&]() {
+        RowList rl = list_order(h);
+        n = (int)(kind == CC_PCORE ? rl.pcore.size() : rl.outlier.size());
+        return (int)CC_OK;
+    });
+    return rc == CC_OK ? n : rc;
+}
+
+int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w, double* cf1, double* cf2, double* cen,
+              double* pref)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        RowList rl = list_order(h);
+        const std::vector<int>& rows = kind == CC_PCORE ? rl.pcore : rl.outlier;
+        const size_t m = (size_t)h->hc.m_rows, d = (size_t)h->d, n = rows.size();
+        if (n == 0) return (int)CC_OK;
+        auto fetch_vec = [&](const double* dev, double* out) {
+            if (!out) return;
+            std::vector<double> tmp(m * d);
+            HIPCHK(hipMemcpyAsync(tmp.data(), dev, m * d * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n; ++i) memcpy(out + i * d, tmp.data() + (size_t)rows[i] * d, d * 8);
+        };
+        fetch_vec(h->tab.cf1.p, cf1);
+        fetch_vec(h->tab.cf2.p, cf2);
+        fetch_vec(h->tab.cen.p, cen);
+        fetch_vec(h->tab.pref.p, pref);
+        if (w) {
+            std::vector<double> tmp(m);
+            HIPCHK(hipMemcpyAsync(tmp.data(), h->tab.w.p, m * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n; ++i) w[i] = tmp[rows[i]];
+        }
+        auto fetch_i64 = [&](const long long* dev, int64_t* out) {
+            if (!out) return;
+            std::vector<long long> tmp(m);
+            HIPCHK(hipMemcpyAsync(tmp.data(), dev, m * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n; ++i) out[i] = tmp[rows[i]];
+        };
+        fetch_i64(h->tab.id.p, id);
+        fetch_i64(h->tab.uid.p, uid);
+        return (int)CC_OK;
+    });
+}
+
+int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const double* cf2, const double* cen,
+                 const double* pref, double w, int64_t id, int64_t uid)
+{
+    if (!h || !cf1 || !cf2 || !cen || !pref) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        int rc = set_dim(h, d);
+        if (rc != CC_OK) return rc;
+        ensure_table(h, (size_t)h->hc.m_rows + 1);
+        const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d;
+        for (int i = 0; i < d; ++i)
+            if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) h->tainted = true;
+        HIPCHK(hipMemcpyAsync(h->tab.cf1.p + r * dd, cf1, dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.cf2.p + r * dd, cf2, dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.cen.p + r * dd, cen, dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.pref.p + r * dd, pref, dd * 8, hipMemcpyHostToDevice, h->stream));
+        const int knd = kind == CC_PCORE ? CC_KIND_PCORE : CC_KIND_OUTLIER;
+        const int key = kind == CC_PCORE ? h->hc.n_pkeys++ : h->hc.n_okeys++;
+        const long long lid = id, luid = uid;
+        HIPCHK(hipMemcpyAsync(h->tab.w.p + r, &w, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.kind.p + r, &knd, 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.key.p + r, &key, 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.id.p + r, &lid, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.uid.p + r, &luid, 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->hc.m_rows += 1;
+        if (kind == CC_PCORE && id >= h->hc.pcore_last_id) h->hc.pcore_last_id = id + 1;
+        if (uid >= h->hc.outlier_last_id) h->hc.outlier_last_id = uid + 1;
+        refresh_ctl_params(h);
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
+int cc_decay_downgrade(cc_handle* h, double factor)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
+    return guarded(h, [&]() {
+        const int m = h->hc.m_rows, d = h->d;
+        if (m == 0) return (int)CC_OK;
+        refresh_ctl_params(h);
+        const Table tab = h->tab.view();
+        hipLaunchKernelGGL(k_decay, dim3((m * d + 255) / 256), dim3(256), 0, h->stream, tab, m, d, factor);
+        h->flags.ensure((size_t)m);
+        hipLaunchKernelGGL(k_downgrade_flags, dim3((m + 255) / 256), dim3(256), 0, h->stream, tab, m, d,
+                           h->hc.beta_mu, h->hc.pi, h->hc.omicron, h->flags.p);
+        std::vector<int> flags(m);
+        std::vector<long long> id(m), uid(m);
+        HIPCHK(hipMemcpyAsync(flags.data(), h->flags.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(id.data(), tab.id, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(uid.data(), tab.uid, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+        RowList rl = list_order(h);  // synchronises the stream
+
+        // hddstream.py:528-537 and :545-549: Python removes from the list it iterates, so the element that
+        // slides into the freed position is skipped.  Integer work over the flags only.
+        std::vector<int> pl = rl.pcore, ol = rl.outlier;
+        std::vector<char> downgraded(m, 0);
+        for (size_t i = 0; i < pl.size(); ++i) {
+            const int r = pl[i];
+            if (flags[r] & 1) {
+                downgraded[r] = 1;
+                pl.erase(pl.begin() + (long)i);
+                ol.push_back(r);
+            }
+        }
+        for (size_t i = 0; i < ol.size(); ++i) {
+            if (flags[ol[i]] & 2) ol.erase(ol.begin() + (long)i);
+        }
+        const int np = (int)pl.size(), no = (int)ol.size(), n = np + no;
+        std::vector<int> perm(n), nkind(n), nkey(n);
+        std::vector<long long> nid(n);
+        for (int i = 0; i < np; ++i) { perm[i] = pl[i]; nkind[i] = CC_KIND_PCORE; nkey[i] = i; nid[i] = id[pl[i]]; }
+        for (int i = 0; i < no; ++i) {
+            const int r = ol[i];
+            perm[np + i] = r; nkind[np + i] = CC_KIND_OUTLIER; nkey[np + i] = i;
+            nid[np + i] = downgraded[r] ? uid[r] : id[r];  // hddstream.py:535
+        }
+        if (h->tab2.cap < h->tab.cap || h->tab2.d != d) h->tab2.alloc(h->tab.cap, d);
+        DevBuf<int> dperm, dkind, dkey;
+        DevBuf<long long> dnid;
+        dperm.ensure(n); dkind.ensure(n); dkey.ensure(n); dnid.ensure(n);
+        if (n) {
+            HIPCHK(hipMemcpyAsync(dperm.p, perm.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dkind.p, nkind.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dkey.p, nkey.data(), (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(dnid.p, nid.data(), (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_gather_rows, dim3((n * d + 255) / 256), dim3(256), 0, h->stream, tab, h->tab2.view(),
+                               dperm.p, dkind.p, dkey.p, dnid.p, n, d);
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->tab.swap(h->tab2);
+        h->hc.m_rows = n;
+        h->hc.n_pkeys = np;
+        h->hc.n_okeys = no;
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
+int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out_pdim, int32_t* out_nn,
+               int32_t* out_nw)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
+    return guarded(h, [&]() {
+        refresh_ctl_params(h);
+        h->clusters.clear();
+        h->pcore_ids_host.clear();
+        h->n_core = 0;
+        if (n_clusters) *n_clusters = 0;
+        RowList rl = list_order(h);
+        const int mp = (int)rl.pcore.size(), d = h->d;
+        if (mp == 0) return (int)CC_OK;
+        const size_t md = (size_t)mp * d;
+        const int words = (mp + 63) / 64;
+        h->pv_cf1.ensure(md); h->pv_cf2.ensure(md); h->pv_cen.ensure(md); h->pv_pref.ensure(md); h->pv_w.ensure(mp);
+        h->pv_id.ensure(mp); h->prow.ensure(mp); h->wvec.ensure(md); h->nn.ensure(mp); h->pdim.ensure(mp);
+        h->core.ensure(mp); h->adj.ensure((size_t)mp * words); h->adjw.ensure((size_t)mp * words);
+        HIPCHK(hipMemcpyAsync(h->prow.p, rl.pcore.data(), (size_t)mp * 4, hipMemcpyHostToDevice, h->stream));
+        PcoreView pv{h->pv_cf1.p, h->pv_cf2.p, h->pv_cen.p, h->pv_pref.p, h->pv_w.p, h->pv_id.p};
+        const Ctl& c = h->hc;
+        const cc_params& p = h->par;
+        hipLaunchKernelGGL(k_gather_pcores, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, h->stream, h->tab.view(),
+                           pv, h->prow.p, mp, d);
+        hipLaunchKernelGGL(k_core_flags, dim3((mp + 255) / 256), dim3(256), 0, h->stream, pv, mp, d, p.eps_sq, p.mu,
+                           p.pi, p.k, c.inv_k, c.pow2, h->core.p);
+        hipLaunchKernelGGL(k_eps_neighbours, dim3(words, mp), dim3(64), 0, h->stream, pv.cen, mp, d, p.ups_eps,
+                           h->adj.p, words);
+        hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, h->stream, pv.cen,
+                           h->adj.p, words, mp, d, p.delta, p.k, h->wvec.p, h->nn.p);
+        hipLaunchKernelGGL(k_pdim, dim3((mp + 255) / 256), dim3(256), 0, h->stream, h->wvec.p, mp, d, h->pdim.p);
+        hipLaunchKernelGGL(k_weighted_reach, dim3(words, mp), dim3(64), 0, h->stream, pv.cen, h->wvec.p, h->adj.p,
+                           h->adjw.p, words, mp, d, p.ups_eps_sq);
+        std::vector<int8_t> core(mp);
+        std::vector<int> pdim(mp), nn(mp);
+        std::vector<unsigned long long> adjw((size_t)mp * words);
+        h->pcore_ids_host.resize(mp);
+        HIPCHK(hipMemcpyAsync(core.data(), h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pdim.data(), h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(adjw.data(), h->adjw.p, (size_t)mp * words * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->pcore_ids_host.data(), h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+
+        // ---- ordered expansion on the host: predecon.py:62-120, 242-267 (integer / graph work only) ----
+        auto for_each_nw = [&](int q, auto&& fn) {
+            for (int wd = 0; wd < words; ++wd) {
+                unsigned long long m = adjw[(size_t)q * words + wd];
+                while (m) {
+                    const int b = __builtin_ctzll(m);
+                    m &= m - 1;
+                    fn(wd * 64 + b);
+                }
+            }
+        };
+        std::vector<int8_t> cls(mp, 0);  // 0 'u', 1 'c', 2 'n'
+        std::vector<int> queue;
+        const int lam = p.pi;
+        for (int seed = 0; seed < mp; ++seed) {
+            if (cls[seed] != 0) continue;
+            if (!core[seed]) { cls[seed] = 2; continue; }
+            HostCluster cl;
+            queue.clear();
+            for_each_nw(seed, [&](int x) { queue.push_back(x); });
+            size_t head = 0;
+            while (head < queue.size()) {
+                const int q = queue[head++];
+                if (!core[q]) continue;
+                for_each_nw(q, [&](int x) {
+                    if (pdim[x] > lam) return;
+                    if (cls[x] == 0) queue.push_back(x);
+                    if (cls[x] == 0 || cls[x] == 2) {
+                        cls[x] = 1;
+                        cl.members.push_back(x);
+                    }
+                });
+            }
+            if (!cl.members.empty()) h->clusters.push_back(std::move(cl));  // predecon.py:83 (W > 0)
+        }
+        for (int i = 0; i < mp; ++i) h->n_core += core[i];
+
+        // ---- cluster CF sums in merge order + preferred dimensions on the device ----
+        const int nc = (int)h->clusters.size();
+        if (nc) {
+            std::vector<int> mem, off(1, 0);
+            for (auto& cl : h->clusters) {
+                mem.insert(mem.end(), cl.members.begin(), cl.members.end());
+                off.push_back((int)mem.size());
+            }
+            const size_t cd = (size_t)nc * d;
+            h->mem_dev.ensure(mem.size()); h->off_dev.ensure(off.size());
+            h->c_cf1.ensure(cd); h->c_cf2.ensure(cd); h->c_cen.ensure(cd); h->c_pref.ensure(cd); h->c_w.ensure(nc);
+            HIPCHK(hipMemcpyAsync(h->mem_dev.p, mem.data(), mem.size() * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->off_dev.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_cluster_merge, dim3((unsigned)((cd + 255) / 256)), dim3(256), 0, h->stream, pv,
+                               h->mem_dev.p, h->off_dev.p, nc, d, p.delta_sq, p.k, h->c_cf1.p, h->c_cf2.p, h->c_cen.p,
+                               h->c_pref.p, h->c_w.p);
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        if (out_core) memcpy(out_core, core.data(), mp);
+        if (out_pdim) memcpy(out_pdim, pdim.data(), (size_t)mp * 4);
+        if (out_nn) memcpy(out_nn, nn.data(), (size_t)mp * 4);
+        if (out_nw) {
+            for (int i = 0; i < mp; ++i) {
+                int cnt = 0;
+                for (int wd = 0; wd < words; ++wd) cnt += __builtin_popcountll(adjw[(size_t)i * words + wd]);
+                out_nw[i] = cnt;
+            }
+        }
+        if (n_clusters) *n_clusters = nc;
+        return (int)CC_OK;
+    });
+}
+
+int cc_num_core(cc_handle* h) { return h ? h->n_core : CC_ERR_BAD_ARG; }
+
+int cc_cluster_size(cc_handle* h, int32_t c)
+{
+    if (!h || c < 0 || c >= (int)h->clusters.size()) return CC_ERR_BAD_ARG;
+    return (int)h->clusters[c].members.size();
+}
+
+int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, double* cf1, double* cf2, double* cen,
+                      double* pref)
+{
+    if (!h || c < 0 || c >= (int)h->clusters.size()) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        const HostCluster& cl = h->clusters[c];
+        const size_t d = (size_t)h->d;
+        if (members)
+            for (size_t i = 0; i < cl.members.size(); ++i) members[i] = h->pcore_ids_host[cl.members[i]];
+        if (w) HIPCHK(hipMemcpyAsync(w, h->c_w.p + c, 8, hipMemcpyDeviceToHost, h->stream));
+        if (cf1) HIPCHK(hipMemcpyAsync(cf1, h->c_cf1.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cen) HIPCHK(hipMemcpyAsync(cen, h->c_cen.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (pref) HIPCHK(hipMemcpyAsync(pref, h->c_pref.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
+int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref, int32_t mc, const double* prev_cen,
+                    int32_t mp, int32_t d, int32_t* out_idx, double* out_dist)
+{
+    if (!h || !cur_cen || !cur_pref || !out_idx || mc < 0 || mp < 0 || d <= 0) return CC_ERR_BAD_ARG;
+    if (mp > 0 && !prev_cen) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        if (mc == 0) return (int)CC_OK;
+        const size_t cd = (size_t)mc * d, pd = (size_t)mp * d;
+        h->a_cur_cen.ensure(cd); h->a_cur_pref.ensure(cd); h->a_prev_cen.ensure(pd); h->a_idx.ensure(mc);
+        h->a_dist.ensure(mc);
+        HIPCHK(hipMemcpyAsync(h->a_cur_cen.p, cur_cen, cd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->a_cur_pref.p, cur_pref, cd * 8, hipMemcpyHostToDevice, h->stream));
+        if (pd) HIPCHK(hipMemcpyAsync(h->a_prev_cen.p, prev_cen, pd * 8, hipMemcpyHostToDevice, h->stream));
+        const double k = h->have_par ? h->par.k : 1.0;
+        const int pow2 = is_pow2(k) ? 1 : 0;
+        hipLaunchKernelGGL(k_assoc_argmin, dim3(mc), dim3(64), 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,
+                           h->a_prev_cen.p, mc, mp, d, k, pow2 ? 1.0 / k : 0.0, pow2, h->a_idx.p, h->a_dist.p);
+        HIPCHK(hipMemcpyAsync(out_idx, h->a_idx.p, (size_t)mc * 4, hipMemcpyDeviceToHost, h->stream));
+        if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, h->a_dist.p, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipGetLastError());
+        return (int)CC_OK;
+    });
+}
+
+int cc_get_stats(cc_handle* h, cc_stats* out)
+{
+    if (!h || !out) return CC_ERR_BAD_ARG;
+    *out = h->stats;
+    return CC_OK;
+}
+
+}  // extern "C"

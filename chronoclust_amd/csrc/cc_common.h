@@ -1,0 +1,91 @@
+// cc_common.h — shared device/host declarations of the gfx950 ChronoClust hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CC_KIND_PCORE 0
+#define CC_KIND_OUTLIER 1
+#define CC_KIND_DEAD 2
+
+#define CC_MAX_ROUNDS 8
+#define CC_T_UNKNOWN (-2)
+#define CC_IDX_INF 0x7fffffff
+
+// One candidate of a per-point argmin: (distance, list-order key) ordered lexicographically
+// (strict `<` + "first in list order wins", hddstream.py:326/373), plus the row it refers to.
+struct __attribute__((aligned(16))) Cand {
+    double dist;
+    int key;
+    int slot;
+};
+
+// Microcluster table in HBM, structure of arrays, row r = one microcluster
+// (objects/microcluster.py:71-81: CF1, CF2, cumulative_weight, cluster_centroids, preferred_dimension_vector).
+struct Table {
+    double* cf1;   // [cap, d]
+    double* cf2;   // [cap, d]
+    double* cen;   // [cap, d]  stored centroid (NOT recomputed after decay, hddstream.py:283-286)
+    double* pref;  // [cap, d]  1.0 or k
+    double* w;     // [cap]
+    int* kind;     // [cap]  CC_KIND_*
+    int* key;      // [cap]  position in its Python list (pcore_MC or outlier_MC) as an order key
+    long long* id;   // [cap]  current id (pcore id or outlier id)
+    long long* uid;  // [cap]  prev_outlier_id = creation number
+    unsigned long long* touch;  // [cap]  (stamp << 20 | first toucher) of the current validation round
+};
+
+// Version rows of the current window: row j = state of point j's target microcluster right after point j
+// was processed (speculatively).  Same column meaning as Table.
+struct Versions {
+    double* cf1;
+    double* cf2;
+    double* cen;
+    double* pref;
+    double* w;
+    int* kind;
+    int* key;
+    int* next;  // next point of the window with the same target (CC_IDX_INF if none; == own index if row unused)
+    int* upg;   // index of the window point whose add promoted the microcluster, or -1
+    int* acc;   // 1 if point j was absorbed (radius test passed or new microcluster)
+    int* tgt;   // target id of the chain this row belongs to
+};
+
+// Read-only view the scan kernel walks (either the table or the version rows).
+struct Rows {
+    const double* cen;
+    const double* pref;
+    const double* cf1;
+    const double* cf2;
+    const double* w;
+    const int* kind;
+    const int* key;
+    const int* next;  // only for version rows
+};
+
+struct Ctl {
+    long long cursor;    // points of this call already committed
+    long long n_points;  // N of this call
+    int d;
+    int m_rows;          // table rows in use
+    int n_pkeys, n_okeys;
+    long long pcore_last_id, outlier_last_id;  // hddstream.py:63-64
+    unsigned long long window_seq;
+    int win_cfg;         // configured window size
+    int win_b;           // size of the current window (0: nothing left)
+    int max_rounds;
+    int last_round;      // last validation round that ran for the current window
+    int fc[CC_MAX_ROUNDS + 2];  // fc[r]: first point whose decision changed in round r (>= win_b: converged)
+    // parameters (cc_params, see include/chronoclust_hip.h)
+    double eps_sq, delta_sq, k, inv_k, beta_mu, mu, omicron;
+    int pi;
+    int filter;  // pi < d: the pdim filter of hddstream.py:317-321 is not vacuous
+    int pow2;    // k is a power of two: x / k == x * (1/k) bit for bit
+    int pad0;
+    // statistics
+    long long stat_windows, stat_rounds, stat_truncated;
+};
+
+__host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)
+{
+    return ad < bd || (ad == bd && ak < bk);
+}

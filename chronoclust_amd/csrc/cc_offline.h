@@ -1,0 +1,269 @@
+// cc_offline.h — gfx950 kernels of the timestep boundary (decay / downgrade), the offline PreDeCon phase
+// and the association tracker.  All of them are embarrassingly parallel given fixed inputs; the only ordered
+// parts (Python list mutation while iterating, the BFS expansion) run on the host over small integer arrays.
+#pragma once
+#include "cc_common.h"
+
+// ---------------------------------------------------------------------------------
+// K4: decay (hddstream.py:283-286) and the downgrade / delete predicates (:529-532, :547)
+// ---------------------------------------------------------------------------------
+
+__global__ void k_decay(Table tab, int m_rows, int d, double f)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < m_rows * d) {
+        tab.cf1[e] = tab.cf1[e] * f;
+        tab.cf2[e] = tab.cf2[e] * f;
+    }
+    if (e < m_rows) tab.w[e] = tab.w[e] * f;
+}
+
+// flags[r] bit 0: would be downgraded as a pcore (w < beta*mu or count(pref > 1) > pi)
+//          bit 1: would be deleted as an outlier (w <= omicron)
+__global__ void k_downgrade_flags(Table tab, int m_rows, int d, double beta_mu, int pi, double omicron, int* flags)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m_rows) return;
+    int cnt = 0;
+    for (int i = 0; i < d; ++i) cnt += (tab.pref[(size_t)r * d + i] > 1.0);
+    const double w = tab.w[r];
+    flags[r] = ((w < beta_mu || cnt > pi) ? 1 : 0) | ((w <= omicron) ? 2 : 0);
+}
+
+// dst row i <- src row perm[i]; kind / key / id are rewritten from the host-computed lists
+__global__ void k_gather_rows(Table src, Table dst, const int* perm, const int* nkind, const int* nkey,
+                              const long long* nid, int n, int d)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * d) {
+        const int i = e / d, c = e - i * d;
+        const size_t s = (size_t)perm[i] * d + c;
+        dst.cf1[e] = src.cf1[s];
+        dst.cf2[e] = src.cf2[s];
+        dst.cen[e] = src.cen[s];
+        dst.pref[e] = src.pref[s];
+    }
+    if (e < n) {
+        const int s = perm[e];
+        dst.w[e] = src.w[s];
+        dst.uid[e] = src.uid[s];
+        dst.kind[e] = nkind[e];
+        dst.key[e] = nkey[e];
+        dst.id[e] = nid[e];
+        dst.touch[e] = 0ull;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// offline phase on the pcore list (dense copies in list order)
+// ---------------------------------------------------------------------------------
+
+struct PcoreView {
+    double* cf1;
+    double* cf2;
+    double* cen;
+    double* pref;
+    double* w;
+    long long* id;
+};
+
+__global__ void k_gather_pcores(Table tab, PcoreView pv, const int* rows, int mp, int d)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < mp * d) {
+        const int i = e / d, c = e - i * d;
+        const size_t s = (size_t)rows[i] * d + c;
+        pv.cf1[e] = tab.cf1[s];
+        pv.cf2[e] = tab.cf2[s];
+        pv.cen[e] = tab.cen[s];
+        pv.pref[e] = tab.pref[s];
+    }
+    if (e < mp) {
+        pv.w[e] = tab.w[rows[e]];
+        pv.id[e] = tab.id[rows[e]];
+    }
+}
+
+// K5: mc_functions.py:64-77 with the thresholds of hddstream.py:489
+__global__ void k_core_flags(PcoreView pv, int mp, int d, double eps_sq, double mu, int pi, double k, double inv_k,
+                             int pow2, int8_t* core)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= mp) return;
+    const double w = pv.w[r];
+    double r2 = 0.0;
+    int cnt = 0;
+    for (int i = 0; i < d; ++i) {
+        const size_t g = (size_t)r * d + i;
+        double a = pv.cf2[g] / w;
+        double b = pv.cf1[g] / w;
+        b = b * b;
+        double v = a - b;
+        const double pr = pv.pref[g];
+        if (pr != 1.0) v = (pow2 && pr == k) ? v * inv_k : v / pr;
+        r2 = r2 + v;
+        cnt += (pr > 1.0);
+    }
+    core[r] = (r2 <= eps_sq && w >= mu && cnt <= pi) ? 1 : 0;
+}
+
+// K6: predecon.py:161-188.  One wave per (p, 64 consecutive q): ballot -> one word of the adjacency bitmask.
+// Euclidean distance = sqrt of the left-to-right sum of squares (the reference's np.linalg.norm is
+// platform-defined in the last ulp: nrm2 under numba, sqrt(dot) under numpy).
+__global__ __launch_bounds__(64) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
+                                                       unsigned long long* __restrict__ adj, int words)
+{
+    const int p = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    bool in = false;
+    if (q < mp) {
+        double acc = 0.0;
+        for (int i = 0; i < d; ++i) {
+            double t = cen[(size_t)q * d + i] - cen[(size_t)p * d + i];
+            t = t * t;
+            acc = acc + t;
+        }
+        in = sqrt(acc) <= eps;
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+    if (threadIdx.x == 0) adj[(size_t)p * words + blockIdx.x] = mask;
+}
+
+// K7: predecon.py:190-217 + predeconmc_functions.py:19-42.  One thread per (p, dim): mean squared deviation of
+// the neighbours' centroids, summed in dict (= list) order.  Note `<= delta`, not delta^2 (predecon.py:213).
+__global__ void k_subspace_pref(const double* __restrict__ cen, const unsigned long long* __restrict__ adj,
+                                int words, int mp, int d, double delta, double k, double* __restrict__ wvec,
+                                int* __restrict__ nn)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= mp * d) return;
+    const int p = e / d, c = e - p * d;
+    const double cp = cen[e];
+    double acc = 0.0;
+    int n = 0;
+    for (int wd = 0; wd < words; ++wd) {
+        unsigned long long m = adj[(size_t)p * words + wd];
+        while (m) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1;
+            const int q = wd * 64 + b;
+            double t = cp - cen[(size_t)q * d + c];
+            t = t * t;
+            acc = acc + t;
+            ++n;
+        }
+    }
+    const double var = acc / (double)n;
+    wvec[e] = (var <= delta) ? k : 1.0;
+    if (c == 0) nn[p] = n;
+}
+
+__global__ void k_pdim(const double* __restrict__ wvec, int mp, int d, int* __restrict__ pdim)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= mp) return;
+    int cnt = 0;
+    for (int i = 0; i < d; ++i) cnt += (wvec[(size_t)p * d + i] > 1.0);  // predecon_mc.py:81
+    pdim[p] = cnt;
+}
+
+// K8: predecon.py:155-159, 219-239 + predeconmc_functions.py:44-62 on the eps-neighbour pairs
+__global__ __launch_bounds__(64) void k_weighted_reach(const double* __restrict__ cen, const double* __restrict__ wvec,
+                                                       const unsigned long long* __restrict__ adj,
+                                                       unsigned long long* __restrict__ adjw, int words, int mp,
+                                                       int d, double eps_sq)
+{
+    const int p = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    const unsigned long long nb = adj[(size_t)p * words + blockIdx.x];
+    bool in = false;
+    if (q < mp && ((nb >> threadIdx.x) & 1ull)) {
+        double dpq = 0.0, dqp = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double a = cen[(size_t)p * d + i], b = cen[(size_t)q * d + i];
+            double t = a - b;
+            t = t * t;
+            t = wvec[(size_t)p * d + i] * t;
+            dpq = dpq + t;
+            double u = b - a;
+            u = u * u;
+            u = wvec[(size_t)q * d + i] * u;
+            dqp = dqp + u;
+        }
+        const double dist = dpq > dqp ? dpq : dqp;  // Python max(a, b): b only if b > a
+        in = dist <= eps_sq;
+    }
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+    if (threadIdx.x == 0) adjw[(size_t)p * words + blockIdx.x] = mask;
+}
+
+// predecon_mc.py:50-68 merge_mc in merge order + predecon.py:80 update_preferred_dimensions.
+// One thread per (cluster, dim); members[off[c] .. off[c+1]) are pcore list positions in merge order.
+__global__ void k_cluster_merge(PcoreView pv, const int* __restrict__ members, const int* __restrict__ off, int nc,
+                                int d, double delta_sq, double k, double* __restrict__ ccf1, double* __restrict__ ccf2,
+                                double* __restrict__ ccen, double* __restrict__ cpref, double* __restrict__ cw)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nc * d) return;
+    const int c = e / d, i = e - c * d;
+    double s1 = 0.0, s2 = 0.0, w = 0.0;
+    for (int t = off[c]; t < off[c + 1]; ++t) {
+        const int m = members[t];
+        s1 = s1 + pv.cf1[(size_t)m * d + i];
+        s2 = s2 + pv.cf2[(size_t)m * d + i];
+        w = w + pv.w[m];
+    }
+    ccf1[e] = s1;
+    ccf2[e] = s2;
+    ccen[e] = s1 / w;
+    double a = s2 / w;
+    double b = s1 / w;
+    b = b * b;
+    const double var = a - b;
+    cpref[e] = (var <= delta_sq) ? k : 1.0;
+    if (i == 0) cw[c] = w;
+}
+
+// ---------------------------------------------------------------------------------
+// K9: association tracker, cluster_tracker.py:127-141.  One wave per current pcore; lanes stride over the
+// previous pcores, then a wavefront shuffle reduction of (distance, index) keeps "first minimum wins".
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_assoc_argmin(const double* __restrict__ cur_cen,
+                                                     const double* __restrict__ cur_pref,
+                                                     const double* __restrict__ prev_cen, int mc, int mp, int d,
+                                                     double k, double inv_k, int pow2, int* __restrict__ out_idx,
+                                                     double* __restrict__ out_dist)
+{
+    const int c = blockIdx.x;
+    if (c >= mc) return;
+    const int lane = threadIdx.x;
+    double best = __builtin_huge_val();
+    int bidx = CC_IDX_INF;
+    for (int q = lane; q < mp; q += 64) {
+        double acc = 0.0;
+        for (int i = 0; i < d; ++i) {
+            double t = prev_cen[(size_t)q * d + i] - cur_cen[(size_t)c * d + i];
+            t = t * t;
+            const double pr = cur_pref[(size_t)c * d + i];
+            if (pr != 1.0) t = (pow2 && pr == k) ? t * inv_k : t / pr;
+            acc = acc + t;
+        }
+        if (bidx == CC_IDX_INF || acc < best) {  // ascending q inside a lane: strict < keeps the first
+            best = acc;
+            bidx = q;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bidx, off);
+        if (oi != CC_IDX_INF && (bidx == CC_IDX_INF || od < best || (od == best && oi < bidx))) {
+            best = od;
+            bidx = oi;
+        }
+    }
+    if (lane == 0) {
+        out_idx[c] = (bidx == CC_IDX_INF) ? -1 : bidx;
+        if (out_dist) out_dist[c] = best;
+    }
+}

@@ -1,0 +1,161 @@
+/*
+ * chronoclust_hip.h — C-ABI of the MI355X (gfx950) ChronoClust hot path.
+ *
+ * This is the drop-in boundary.  The upstream project is pure Python and has
+ * no FFI of its own; the seam a maintainer would bind
+ * is the HDDStream object (chronoclust/clustering/hddstream.py) and the
+ * association tracker (chronoclust/tracking/cluster_tracker.py).  Each entry
+ * point below names the reference code it replaces.  INTEGRATION.md shows the
+ * ctypes stub that goes into the reference.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types; every function returns 0
+ *    on success or a negative cc_status; cc_last_error() has the text;
+ *  - host pointers unless the name says "device"; row-major float64 [N, d];
+ *  - one handle = one HDDStream state on one GPU; a handle is not thread-safe;
+ *  - all floating-point work is IEEE double, no FMA contraction, sums over
+ *    dimensions strictly left to right, so results are bit-identical to the
+ *    reference's numba functions (utilities/mc_functions.py,
+ *    utilities/predeconmc_functions.py);
+ *  - there is NO CPU fallback: without a HIP device cc_create fails.
+ *
+ * Derived parameters are computed by the caller with the reference's own
+ * Python expressions and passed in finished (so libm's pow never enters a
+ * comparison on the device):
+ *    eps_sq      = epsilon ** 2                 hddstream.py:46
+ *    delta_sq    = delta ** 2                   hddstream.py:49
+ *    ups_eps     = upsilon * epsilon            hddstream.py:47
+ *    ups_eps_sq  = (upsilon * epsilon) ** 2     predecon.py:40
+ *    mu          = mu_cfg * N                   hddstream.py:126,164
+ *    omicron     = omicron_cfg * previous N     hddstream.py:119
+ *    pi          = d if pi_cfg <= 0 else round  hddstream.py:107-114
+ *    decay factor= 2 ** (-lambda * interval)    hddstream.py:283
+ */
+#ifndef CHRONOCLUST_HIP_H
+#define CHRONOCLUST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cc_handle cc_handle;
+
+enum cc_status {
+    CC_OK = 0,
+    CC_ERR_NO_DEVICE = -1,   /* no HIP device / HIP runtime error            */
+    CC_ERR_BAD_ARG = -2,     /* null pointer, d mismatch, d > CC_MAX_DIM ... */
+    CC_ERR_NONFINITE = -3,   /* NaN/Inf in the input points                  */
+    CC_ERR_OOM = -4,
+    CC_ERR_INTERNAL = -5
+};
+
+enum cc_kind { CC_PCORE = 0, CC_OUTLIER = 1 };
+
+#define CC_MAX_DIM 64
+
+typedef struct cc_params {
+    double eps_sq;
+    double delta_sq;
+    double k;
+    double beta;
+    double mu;
+    double omicron;
+    double ups_eps;
+    double ups_eps_sq;
+    double delta;
+    int32_t pi;
+    int32_t pad;
+} cc_params;
+
+/* Tuning knobs of the exact windowed online path (0 = library default). */
+typedef struct cc_tuning {
+    int32_t window;          /* points speculated per window                     */
+    int32_t rounds;          /* max validation rounds per window                 */
+    int32_t segments;        /* microcluster-range segments per point tile       */
+    int32_t windows_per_sync;/* windows enqueued between host read-backs         */
+    int32_t time_kernels;    /* 1: bracket every scan launch with HIP events     */
+    int32_t reserved[3];
+} cc_tuning;
+
+typedef struct cc_stats {
+    int64_t points;          /* points processed by the last cc_online_run       */
+    int64_t windows;         /* windows committed                                 */
+    int64_t rounds;          /* validation rounds executed                        */
+    int64_t truncated;       /* windows committed short of their full size       */
+    int64_t scan_launches;   /* k_scan launches timed (time_kernels = 1)         */
+    double  scan_ms;         /* sum of their HIP-event durations                  */
+    double  scan_pair_dims;  /* (point, microcluster, dim) triples they covered   */
+    double  run_ms;          /* HIP-event time of the whole cc_online_run         */
+    int64_t rows;            /* microcluster rows in the table after the run     */
+    int64_t reserved[7];
+} cc_stats;
+
+/* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
+int cc_create(int device, cc_handle** out);
+void cc_destroy(cc_handle* h);
+const char* cc_last_error(const cc_handle* h);
+int cc_set_tuning(cc_handle* h, const cc_tuning* t);
+
+/* hddstream.py:89-128 + 45-52: parameters in force for the following calls. */
+int cc_set_params(cc_handle* h, const cc_params* p);
+
+/* hddstream.py:199-213: _decay_clusters_weight(interval) (:247-286), then
+ * downgrade_microclusters() (:512-549, including the skip-next-element
+ * behaviour of removing from the list being iterated).  `factor` =
+ * 2 ** (-lambda * interval). */
+int cc_decay_downgrade(cc_handle* h, double factor);
+
+/* The per-point loop of online_microcluster_maintenance (hddstream.py:220-237:
+ * _add_to_pcore :288-343, _add_to_outlier :345-395 incl. upgrade :397-430,
+ * _create_new_outlier_cluster :434-462), exact sequential semantics.
+ *   cc_points_upload : copy X[N,d] to HBM (checks for NaN/Inf on the device)
+ *   cc_online_run    : cluster the resident points in row order
+ *   cc_labels_download: out_uid[r] = creation number (prev_outlier_id) of the
+ *                      microcluster holding row r (microcluster.py:149);
+ *                      out_path[r] (optional) = 0 pcore add, 1 outlier add,
+ *                      2 new microcluster, |4 if the add promoted it
+ *   cc_online        : the three of them in one call */
+int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d);
+int cc_online_run(cc_handle* h);
+int cc_labels_download(cc_handle* h, int64_t* out_uid, int8_t* out_path);
+int cc_online(cc_handle* h, const double* x, int64_t n, int32_t d, int64_t* out_uid, int8_t* out_path);
+
+/* HDDStream.pcore_MC / outlier_MC (hddstream.py:56-57) in list order.
+ * Any output pointer may be NULL.  cf1/cf2/cen/pref are [count, d]. */
+int cc_count(cc_handle* h, int kind);
+int cc_dim(cc_handle* h);
+int cc_counters(cc_handle* h, int64_t* pcore_last_id, int64_t* outlier_last_id);
+int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w,
+              double* cf1, double* cf2, double* cen, double* pref);
+/* Appends one microcluster to a list (tests, checkpoint restore). */
+int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const double* cf2, const double* cen,
+                 const double* pref, double w, int64_t id, int64_t uid);
+
+/* HDDStream.offline_clustering (hddstream.py:464-510) + PreDeCon.run
+ * (clustering/predecon.py:49-267): core flags, eps-neighbourhoods, subspace
+ * preference vectors and weighted reachability on the device; the ordered
+ * expansion (predecon.py:89-120) on the host.  Returns the number of clusters
+ * through *n_clusters.  Optional per-pcore dumps are indexed by list position. */
+int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out_pdim, int32_t* out_nn,
+               int32_t* out_nw);
+int cc_num_core(cc_handle* h);
+int cc_cluster_size(cc_handle* h, int32_t c);
+/* members = pcore ids in merge order (predecon_mc.py:50-68) */
+int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, double* cf1, double* cf2,
+                      double* cen, double* pref);
+
+/* TrackByHistoricalAssociation.track_cluster_history (cluster_tracker.py:127-141):
+ * for every current pcore (cur_cen/cur_pref [mc,d]) the index of the previous
+ * pcore (prev_cen [mp,d], given in iteration order) with the smallest
+ * sum_d (prev - cur)^2 / cur_pref; strict <, first minimum wins. */
+int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref, int32_t mc,
+                    const double* prev_cen, int32_t mp, int32_t d, int32_t* out_idx, double* out_dist);
+
+int cc_get_stats(cc_handle* h, cc_stats* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -30,13 +30,14 @@ def blob_params(n, beta=0.5, promote_after=10, **over):
 
 BLOB_SCENARIOS = {
     # d = 20, the BASELINE generator with drift; omicron > 0 so outlier deletion fires
-    "d20": dict(seed=42, n=8000, d=20, g=100, sigma=0.01, timepoints=3, drift=0.01, churn=0.05,
-                params=blob_params(8000, param_omicron=0.00015)),
+    # (lambda = 2: retired blobs decay below beta*mu at their 2nd timepoint -> downgrade, then <= omicron -> delete)
+    "d20": dict(seed=42, n=8000, d=20, g=100, sigma=0.01, timepoints=4, drift=0.01, churn=0.08,
+                params=blob_params(8000, param_omicron=0.0002, param_lambda=2)),
     # d = 14 (WNV-shaped), anisotropic blobs, pi < d (pdim filter active), k not a power of two
-    "d14_filter": dict(seed=7, n=5000, d=14, g=40, sigma=0.01, wide_dims=5, wide_sigma=0.08, timepoints=3,
+    "d14_filter": dict(seed=7, n=5000, d=14, g=40, sigma=0.01, wide_dims=(2, 7), wide_sigma=0.08, timepoints=3,
                        drift=0.01, churn=0.05,
-                       params=blob_params(5000, param_epsilon=0.25, param_pi=10, param_k=3, param_upsilon=2.0,
-                                          param_omicron=0.0002)),
+                       params=blob_params(5000, param_epsilon=0.25, param_pi=10, param_k=3, param_upsilon=5.6,
+                                          param_omicron=0.0002, param_lambda=1.5)),
     # d = 40 (stress shape)
     "d40": dict(seed=11, n=3000, d=40, g=30, sigma=0.01, timepoints=2, drift=0.01, churn=0.1,
                 params=blob_params(3000)),
@@ -67,8 +68,9 @@ def make_blob_timepoints(sc, raw=False):
     centres = rng.uniform(0.1, 0.9, (g, d))
     sig = np.full((g, d), sc["sigma"])
     if sc.get("wide_dims"):
+        lo, hi = sc["wide_dims"]
         for i in range(g):
-            sig[i, rng.choice(d, sc["wide_dims"], replace=False)] = sc["wide_sigma"]
+            sig[i, rng.choice(d, int(rng.integers(lo, hi + 1)), replace=False)] = sc["wide_sigma"]
     out = []
     for t in range(sc["timepoints"]):
         if t > 0:

@@ -1,0 +1,166 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the golden vectors of the upstream reference
+and against the CPU oracle on seeded inputs.  Integer outputs (labels, ids, list order, merge order) must be
+identical; float tables are compared bit for bit (the kernels keep the reference's operation order)."""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios
+from golden_util import GOLDEN, StateDump, assert_tables_equal, blob_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _hdd(config, **tuning):
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    return HDDStream(config, tuning=tuning or None)
+
+
+def _check_against_dump(h, dump, t):
+    par = dump.get(t, "params")
+    assert (h.pi, h.mu, h.omicron) == (par[0], par[1], par[2])
+    np.testing.assert_array_equal(h.labels_uid, dump.get(t, "labels_uid"), err_msg="labels t=%d" % t)
+    assert (h.pcore_MC_last_id, h.outlier_MC_last_id) == (int(par[3]), int(par[4]))
+    assert_tables_equal(h.table(0), dump, t, "pcore")
+    assert_tables_equal(h.table(1), dump, t, "outlier")
+    exp = dump.clusters(t)
+    got = h.final_clusters
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g.members_in_merge_order == [int(x) for x in e["members"]]
+        assert g.cumulative_weight == e["w"]
+        for a, b in ((g.CF1, e["cf1"]), (g.CF2, e["cf2"]), (g.cluster_centroids, e["cen"]),
+                     (g.preferred_dimension_vector, e["pref"])):
+            assert np.array_equal(a, b)
+
+
+def _replay_dump(dump, Xs, config, **tuning):
+    h = _hdd(config, **tuning)
+    for t in range(dump.n_timepoints):
+        h.online_microcluster_maintenance(Xs[t], int(dump.get(t, "daystamp")))
+        _check_against_dump(h, dump, t)
+    return h
+
+
+@pytest.mark.parametrize("window", [1024, 64, 1])
+def test_c1_golden(window):
+    dump = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
+    Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
+    if window == 1:
+        Xs = [x[:600] for x in Xs]  # one point per window: only the first timepoint prefix is comparable
+        h = _hdd(scenarios.params_to_config(scenarios.C1_PARAMS), window=1)
+        from oracle import oracle as O
+        o = O.OracleHDDStream(scenarios.params_to_config(scenarios.C1_PARAMS))
+        for t, x in enumerate(Xs):
+            h.online_microcluster_maintenance(x, t)
+            o.online_microcluster_maintenance(x, t)
+            _check_against_oracle(h, o)
+        return
+    _replay_dump(dump, Xs, scenarios.params_to_config(scenarios.C1_PARAMS), window=window)
+
+
+def test_nocluster_golden():
+    dump = StateDump(os.path.join(GOLDEN, "nocluster", "hdd_state.npz"))
+    Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
+    _replay_dump(dump, Xs, scenarios.params_to_config(scenarios.NOCLUSTER_PARAMS))
+
+
+@pytest.mark.parametrize("name", sorted(scenarios.BLOB_SCENARIOS))
+def test_blob_golden(name):
+    dump = StateDump(os.path.join(GOLDEN, "blob_%s.npz" % name))
+    Xs = blob_inputs(name, dump)
+    _replay_dump(dump, Xs, scenarios.params_to_config(scenarios.BLOB_SCENARIOS[name]["params"]))
+
+
+def _check_against_oracle(h, o):
+    from oracle import oracle as O
+    np.testing.assert_array_equal(h.labels_uid, o.labels_uid)
+    np.testing.assert_array_equal(h.labels_path, o.paths)
+    assert (h.pcore_MC_last_id, h.outlier_MC_last_id) == o.counters
+    for kind in (0, 1):
+        a, b = h.table(kind), o.table(kind)
+        for key in ("id", "uid"):
+            np.testing.assert_array_equal(a[key], b[key])
+        for key in ("w", "cf1", "cf2", "cen", "pref"):
+            assert np.array_equal(a[key], b[key]), (kind, key)
+    got, exp = h.final_clusters, o.clusters
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g.members_in_merge_order == [int(x) for x in e["members"]]
+        assert g.cumulative_weight == e["w"]
+        assert np.array_equal(g.CF1, e["cf1"]) and np.array_equal(g.CF2, e["cf2"])
+        assert np.array_equal(g.cluster_centroids, e["cen"])
+        assert np.array_equal(g.preferred_dimension_vector, e["pref"])
+
+
+SEEDED = [
+    # (seed, n, d, g, sigma, params-overrides, window)
+    (1, 6000, 20, 300, 0.01, {}, 1024),
+    (2, 6000, 20, 300, 0.01, {}, 256),
+    (3, 4000, 3, 6, 0.05, dict(param_epsilon=0.08, param_k=4, param_pi=3), 512),       # heavy overlap, tiny M
+    (4, 4000, 14, 50, 0.02, dict(param_k=3, param_pi=9, param_epsilon=0.12), 1024),     # division path + filter
+    (5, 3000, 40, 40, 0.01, {}, 1024),
+    (6, 3000, 64, 20, 0.01, {}, 512),                                                   # CC_MAX_DIM
+    (7, 5000, 8, 30, 0.03, dict(param_k=1), 1024),                                      # API default k = 1
+    (8, 2500, 5, 10, 0.2, dict(param_epsilon=0.05), 1024),                              # almost everything is noise
+]
+
+
+@pytest.mark.parametrize("seed,n,d,g,sigma,over,window", SEEDED)
+def test_seeded_against_oracle(seed, n, d, g, sigma, over, window):
+    from oracle import oracle as O
+    params = scenarios.blob_params(n, **over)
+    cfg = scenarios.params_to_config(params)
+    h = _hdd(cfg, window=window)
+    o = O.OracleHDDStream(cfg)
+    rng = np.random.default_rng(seed)
+    for t in range(3):
+        X = scenarios.make_blobs(seed * 100 + t, n, d, g, sigma)
+        if t == 2:
+            X = X[rng.permutation(n)[: n // 2]]  # ragged timepoint sizes
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+    s = h.stats()
+    assert s["points"] == len(X)
+
+
+def test_continue_same_daystamp_and_edge_sizes():
+    """hddstream.py:199: the same daystamp continues the timepoint (no decay); N = 1 and N = 0 inputs."""
+    from oracle import oracle as O
+    cfg = {"beta": 0.5, "delta": 0.3, "epsilon": 10, "lambda": 1, "k": 40, "mu": 1, "pi": 2, "omicron": 1,
+           "upsilon": 1}
+    h, o = _hdd(cfg), O.OracleHDDStream(cfg)
+    first = np.array([[0.966970507, 0.185628831, 0.861853663], [0.557335192, 0.324320201, 0.495929691],
+                      [0.698145385, 0.222617485, 0.83843284], [0.466592479, 0.557335192, 0.993609292]])
+    for X in (first, np.array([[0.91259336, 0.16408931, 0.06039347]])):  # unittest_hddstream.py:43-88
+        h.online_microcluster_maintenance(X, 0)
+        o.online_microcluster_maintenance(X, 0)
+        _check_against_oracle(h, o)
+    assert h.table(0)["pref"][0].tolist() == [40, 40, 1]
+
+
+def test_nonfinite_input_is_rejected():
+    h = _hdd(scenarios.params_to_config(scenarios.blob_params(10)))
+    X = np.random.rand(10, 4)
+    X[3, 2] = np.nan
+    with pytest.raises(ValueError):
+        h.online_microcluster_maintenance(X, 0)
+
+
+def test_assoc_argmin_against_oracle():
+    from chronoclust_amd import _lib
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    hd = _lib.Handle(0)
+    for mc, mp, d, k in ((1, 1, 3, 4.0), (37, 129, 20, 4.0), (500, 700, 14, 3.0), (64, 64, 40, 1.0)):
+        hd.set_params(0.01, 0.01, k, 0.5, 1.0, 0.0, 0.1, 0.01, 0.1, d)
+        cur = rng.random((mc, d))
+        pref = np.where(rng.random((mc, d)) < 0.5, k, 1.0)
+        prev = rng.random((mp, d))
+        prev[mp // 2] = prev[0]  # an exact tie: the first one must win
+        gi, gd = hd.assoc_argmin(cur, pref, prev)
+        oi, od = O.assoc_argmin(cur, pref, prev)
+        np.testing.assert_array_equal(gi, oi)
+        assert np.array_equal(gd, od)
