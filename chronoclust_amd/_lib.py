@@ -32,7 +32,8 @@ class CcTuning(C.Structure):
 class CcStats(C.Structure):
     _fields_ = [("points", C.c_int64), ("windows", C.c_int64), ("rounds", C.c_int64), ("truncated", C.c_int64),
                 ("scan_launches", C.c_int64), ("scan_ms", C.c_double), ("scan_pair_dims", C.c_double),
-                ("run_ms", C.c_double), ("rows", C.c_int64), ("reserved", C.c_int64 * 7)]
+                ("run_ms", C.c_double), ("rows", C.c_int64), ("table_rows_scanned", C.c_int64),
+                ("reserved", C.c_int64 * 6)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -46,6 +47,7 @@ SYMBOLS = {
     "cc_destroy": (None, [C.c_void_p]),
     "cc_last_error": (C.c_char_p, [C.c_void_p]),
     "cc_set_tuning": (C.c_int, [C.c_void_p, C.POINTER(CcTuning)]),
+    "cc_reset": (C.c_int, [C.c_void_p]),
     "cc_set_params": (C.c_int, [C.c_void_p, C.POINTER(CcParams)]),
     "cc_decay_downgrade": (C.c_int, [C.c_void_p, C.c_double]),
     "cc_points_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32]),
@@ -129,6 +131,9 @@ class Handle(object):
     def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0):
         t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels)
         self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
+
+    def reset(self):
+        self._check(self._lib.cc_reset(self._h))
 
     def set_params(self, eps_sq, delta_sq, k, beta, mu, omicron, ups_eps, ups_eps_sq, delta, pi):
         p = CcParams(eps_sq, delta_sq, k, beta, mu, omicron, ups_eps, ups_eps_sq, delta, int(pi), 0)

@@ -377,6 +377,25 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     return CC_OK;
 }
 
+int cc_reset(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        Ctl& c = h->hc;
+        c.m_rows = 0;
+        c.n_pkeys = c.n_okeys = 0;
+        c.pcore_last_id = c.outlier_last_id = 0;
+        c.cursor = 0;
+        h->tainted = false;
+        h->clusters.clear();
+        h->n_core = 0;
+        refresh_ctl_params(h);
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
 int cc_set_params(cc_handle* h, const cc_params* p)
 {
     if (!h || !p) return CC_ERR_BAD_ARG;
@@ -448,6 +467,8 @@ int cc_online_run(cc_handle* h)
         c.fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) c.fc[i] = CC_IDX_INF;
         c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
+        c.stat_table_rows = 0;
+        c.stat_pair_rows = 0.0;
         push_ctl(h);
 
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
@@ -507,6 +528,8 @@ int cc_online_run(cc_handle* h)
         h->stats.rounds = h->hc.stat_rounds;
         h->stats.truncated = h->hc.stat_truncated;
         h->stats.rows = h->hc.m_rows;
+        h->stats.scan_pair_dims = h->hc.stat_pair_rows * (double)h->d;
+        h->stats.table_rows_scanned = h->hc.stat_table_rows;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {

@@ -83,6 +83,8 @@ struct Ctl {
     int pad0;
     // statistics
     long long stat_windows, stat_rounds, stat_truncated;
+    long long stat_table_rows;  // sum over windows of the table rows scanned
+    double stat_pair_rows;      // sum over windows of (window points x table rows)
 };
 
 __host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)

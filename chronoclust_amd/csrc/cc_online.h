@@ -566,6 +566,8 @@ __global__ __launch_bounds__(1024) void k_commit(Ctl* __restrict__ ctl, Table ta
         ctl->stat_windows += 1;
         ctl->stat_rounds += r;
         ctl->stat_truncated += (n < B) ? 1 : 0;
+        ctl->stat_table_rows += M0;
+        ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
         ctl->window_seq += 1;
         long long left = ctl->n_points - (cursor + n);

@@ -89,7 +89,8 @@ typedef struct cc_stats {
     double  scan_pair_dims;  /* (point, microcluster, dim) triples they covered   */
     double  run_ms;          /* HIP-event time of the whole cc_online_run         */
     int64_t rows;            /* microcluster rows in the table after the run     */
-    int64_t reserved[7];
+    int64_t table_rows_scanned; /* sum over windows of the table rows a scan read  */
+    int64_t reserved[6];
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -97,6 +98,8 @@ int cc_create(int device, cc_handle** out);
 void cc_destroy(cc_handle* h);
 const char* cc_last_error(const cc_handle* h);
 int cc_set_tuning(cc_handle* h, const cc_tuning* t);
+/* Back to the state of a fresh HDDStream (no microclusters, id counters at 0); keeps buffers and parameters. */
+int cc_reset(cc_handle* h);
 
 /* hddstream.py:89-128 + 45-52: parameters in force for the following calls. */
 int cc_set_params(cc_handle* h, const cc_params* p);
