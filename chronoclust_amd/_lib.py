@@ -64,6 +64,8 @@ SYMBOLS = {
     "cc_num_core": (C.c_int, [C.c_void_p]),
     "cc_cluster_size": (C.c_int, [C.c_void_p, C.c_int32]),
     "cc_cluster_export": (C.c_int, [C.c_void_p, C.c_int32, _i64p, _dp, _dp, _dp, _dp, _dp]),
+    "cc_clusters_total_members": (C.c_int, [C.c_void_p]),
+    "cc_clusters_export": (C.c_int, [C.c_void_p, _i64p, _i32p, _dp, _dp, _dp, _dp, _dp]),
     "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
     "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
 }
@@ -194,16 +196,16 @@ class Handle(object):
         pdim, nn, nw = ((np.zeros(m, np.int32) for _ in range(3)) if dumps else (None, None, None))
         self._check(self._lib.cc_offline(self._h, C.byref(n), _ptr(core, _i8p), _ptr(pdim, _i32p), _ptr(nn, _i32p),
                                          _ptr(nw, _i32p)))
-        d = self.dim()
-        clusters = []
-        for c in range(n.value):
-            sz = self._check(self._lib.cc_cluster_size(self._h, c))
-            mem = np.empty(sz, np.int64)
-            w = C.c_double()
-            cf1, cf2, cen, pref = (np.empty(d) for _ in range(4))
-            self._check(self._lib.cc_cluster_export(self._h, c, _ptr(mem, _i64p), C.byref(w), _ptr(cf1), _ptr(cf2),
-                                                    _ptr(cen), _ptr(pref)))
-            clusters.append(dict(members=mem, w=w.value, cf1=cf1, cf2=cf2, cen=cen, pref=pref))
+        d, nc = self.dim(), n.value
+        tot = self._check(self._lib.cc_clusters_total_members(self._h))
+        mem = np.empty(tot, np.int64)
+        off = np.zeros(nc + 1, np.int32)
+        w = np.empty(nc, np.float64)
+        cf1, cf2, cen, pref = (np.empty((nc, d)) for _ in range(4))
+        self._check(self._lib.cc_clusters_export(self._h, _ptr(mem, _i64p), _ptr(off, _i32p), _ptr(w), _ptr(cf1),
+                                                 _ptr(cf2), _ptr(cen), _ptr(pref)))
+        clusters = [dict(members=mem[off[c]:off[c + 1]], w=float(w[c]), cf1=cf1[c], cf2=cf2[c], cen=cen[c],
+                         pref=pref[c]) for c in range(nc)]
         info = dict(core=core, pdim=pdim, nn=nn, nw=nw) if dumps else None
         return clusters, info
 

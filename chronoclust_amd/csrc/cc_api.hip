@@ -116,7 +116,8 @@ struct cc_handle {
     DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_w;
     DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
     DevBuf<Cand> part, clean, dpart;
-    DevBuf<int> T0, T1;
+    DevBuf<int> T0, T1, rk;
+    DevBuf<CommitRec> rec;
     DevBuf<int8_t> dpath;
 
     // offline results
@@ -239,7 +240,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_tgt.ensure(w);
     h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4);
-    h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w);
+    h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
 
@@ -479,9 +480,9 @@ int cc_online_run(cc_handle* h)
 
         const Versions ver = versions_view(h);
         const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
-        const int dblocks = (win + 63) / 64;
-        const int cblocks = (win + 255) / 256;
-        const size_t commit_lds = ((size_t)2 * win + 1024) * sizeof(int);
+        const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
+        const int cblocks = (win + 7) / 8;
+        const int rblocks = std::min((win * h->d + 255) / 256, 1024);
         long long done = 0;
         int m_known = c.m_rows;
         while (done < N) {
@@ -499,7 +500,7 @@ int cc_online_run(cc_handle* h)
                 } else {
                     launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
                 }
-                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
                                    h->part.p, h->clean.p, h->dpart.p, (const int*)nullptr, h->T0.p, h->dpath.p, S, 0);
                 for (int r = 1; r <= R; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
@@ -507,11 +508,13 @@ int cc_online_run(cc_handle* h)
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)win * sizeof(int), h->stream,
                                        h->ctl.p, h->X.p, tab, ver, told, r);
                     launch_scan<true>(h, win, vrows, h->clean.p, h->dpart.p, S, r);
-                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
                                        h->part.p, h->clean.p, h->dpart.p, told, tnew, h->dpath.p, S, r);
                 }
-                hipLaunchKernelGGL(k_commit, dim3(1), dim3(1024), commit_lds, h->stream, h->ctl.p, tab, ver, h->T0.p,
-                                   h->T1.p, h->dpath.p, h->lab_uid.p, h->lab_path.p);
+                hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, h->stream, h->ctl.p, tab, ver, h->T0.p, h->T1.p,
+                                   h->dpath.p, h->lab_uid.p, h->lab_path.p, h->rk.p, h->rec.p);
+                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, h->stream, h->rec.p, tab, ver, h->rk.p,
+                                   h->d);
             }
             HIPCHK(hipGetLastError());
             pull_ctl(h);
@@ -857,6 +860,40 @@ int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, doub
         if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
         if (cen) HIPCHK(hipMemcpyAsync(cen, h->c_cen.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
         if (pref) HIPCHK(hipMemcpyAsync(pref, h->c_pref.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
+int cc_clusters_total_members(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    size_t tot = 0;
+    for (auto& cl : h->clusters) tot += cl.members.size();
+    return (int)tot;
+}
+
+int cc_clusters_export(cc_handle* h, int64_t* members, int32_t* offsets, double* w, double* cf1, double* cf2,
+                       double* cen, double* pref)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        const size_t nc = h->clusters.size(), d = (size_t)h->d;
+        size_t pos = 0;
+        for (size_t c = 0; c < nc; ++c) {
+            if (offsets) offsets[c] = (int32_t)pos;
+            for (int m : h->clusters[c].members) {
+                if (members) members[pos] = h->pcore_ids_host[m];
+                ++pos;
+            }
+        }
+        if (offsets) offsets[nc] = (int32_t)pos;
+        if (nc == 0) return (int)CC_OK;
+        if (w) HIPCHK(hipMemcpyAsync(w, h->c_w.p, nc * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cf1) HIPCHK(hipMemcpyAsync(cf1, h->c_cf1.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cen) HIPCHK(hipMemcpyAsync(cen, h->c_cen.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
+        if (pref) HIPCHK(hipMemcpyAsync(pref, h->c_pref.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         return (int)CC_OK;
     });

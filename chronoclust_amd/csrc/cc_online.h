@@ -264,8 +264,59 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
 }
 
 // ---------------------------------------------------------------------------------
-// k_decide: one thread per window point
+// 32-lane groups: one group per window point in k_decide / k_chain.  Lane l owns dimensions l and l + 32
+// (d <= 64); sums over dimensions stay strictly left to right through an ordered shuffle loop.
 // ---------------------------------------------------------------------------------
+
+__device__ __forceinline__ unsigned cc_group_ballot(bool p)
+{
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(p);
+    return (unsigned)(b >> (threadIdx.x & 32));
+}
+
+struct GroupAdd {
+    double c1[2], c2[2], pr[2];  // this lane's two dimensions of (base + point): CF1, CF2, preferred-dimension entry
+    double r2;                   // projected radius^2 of the enlarged MC (all lanes)
+    int gt1, ne1;                // count(pref' > 1), count(pref' != 1)
+};
+
+// microcluster.py:213-233 + mc_functions.py:45-56, computed by the 32 lanes of a group together.
+// Every lane of the group must call it with the same arguments.  bcf1 == nullptr: empty base.
+__device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, double bw, const double* p, int d,
+                                        const Ctl* c)
+{
+    const int gl = threadIdx.x & 31;
+    GroupAdd g;
+    const double w1 = bw + 1.0;
+    double term[2];
+    bool gt[2], ne[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = gl + 32 * h;
+        g.c1[h] = 0.0; g.c2[h] = 0.0; g.pr[h] = 1.0;
+        term[h] = 0.0; gt[h] = false; ne[h] = false;
+        if (i < d) {
+            const double x = p[i];
+            g.c1[h] = (bcf1 ? bcf1[i] : 0.0) + x;
+            g.c2[h] = (bcf2 ? bcf2[i] : 0.0) + x * x;
+            const double var = cc_sqvar(g.c1[h], g.c2[h], w1);
+            const double pr = (var <= c->delta_sq) ? c->k : 1.0;
+            g.pr[h] = pr;
+            term[h] = cc_div_pref(var, pr, c);
+            gt[h] = pr > 1.0;
+            ne[h] = pr != 1.0;
+        }
+    }
+    g.gt1 = __builtin_popcount(cc_group_ballot(gt[0])) + __builtin_popcount(cc_group_ballot(gt[1]));
+    g.ne1 = __builtin_popcount(cc_group_ballot(ne[0])) + __builtin_popcount(cc_group_ballot(ne[1]));
+    double r2 = 0.0;
+    for (int i = 0; i < d; ++i) {
+        const double t = __shfl(i < 32 ? term[0] : term[1], i & 31, 32);
+        r2 = r2 + t;  // mc_functions.py:54, left to right
+    }
+    g.r2 = r2;
+    return g;
+}
 
 __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 {
@@ -278,15 +329,30 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
     }
 }
 
-__global__ __launch_bounds__(64) void k_decide(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                               Versions ver, const Cand* __restrict__ part, Cand* __restrict__ clean,
-                                               const Cand* __restrict__ dpart, const int* __restrict__ Told,
-                                               int* __restrict__ Tnew, int8_t* __restrict__ dpath, int S, int round)
+__device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
+{
+    Cand o;
+    o.dist = __shfl_xor(c.dist, off, 32);
+    o.key = __shfl_xor(c.key, off, 32);
+    o.slot = __shfl_xor(c.slot, off, 32);
+    return o;
+}
+
+// ---------------------------------------------------------------------------------
+// k_decide: one 32-lane group per window point.  Segment partials are merged with a shuffle butterfly
+// (per-point argmin over the MC range), then the reference's decision procedure runs group-uniformly.
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                                Versions ver, const Cand* __restrict__ part, Cand* __restrict__ clean,
+                                                const Cand* __restrict__ dpart, const int* __restrict__ Told,
+                                                int* __restrict__ Tnew, int8_t* __restrict__ dpath, int S, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
     if (round > 0 && ctl->fc[round - 1] >= B) return;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gl = threadIdx.x & 31;
+    const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
     const int d = ctl->d;
     const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
@@ -294,26 +360,39 @@ __global__ __launch_bounds__(64) void k_decide(Ctl* __restrict__ ctl, const doub
     Cand c[4];
     if (round == 0) {
         c[0] = c[1] = c[2] = c[3] = none;
-        for (int s = 0; s < S; ++s) {
+        for (int s = gl; s < S; s += 32) {
             const Cand* q = part + ((size_t)j * S + s) * 4;
             cc_top2_push(c[0], c[1], q[0]);
             cc_top2_push(c[0], c[1], q[1]);
             cc_top2_push(c[2], c[3], q[2]);
             cc_top2_push(c[2], c[3], q[3]);
         }
-        for (int i = 0; i < 4; ++i) clean[(size_t)j * 4 + i] = c[i];
+        for (int off = 16; off >= 1; off >>= 1) {
+            Cand o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = cc_shfl_xor_cand(c[i], off);
+            cc_top2_push(c[0], c[1], o[0]);
+            cc_top2_push(c[0], c[1], o[1]);
+            cc_top2_push(c[2], c[3], o[2]);
+            cc_top2_push(c[2], c[3], o[3]);
+        }
+        if (gl < 4) clean[(size_t)j * 4 + gl] = c[gl == 0 ? 0 : gl == 1 ? 1 : gl == 2 ? 2 : 3];
     } else {
+#pragma unroll
         for (int i = 0; i < 4; ++i) c[i] = clean[(size_t)j * 4 + i];
     }
     Cand dv[2] = {none, none};  // best live version per kind
     if (round > 0) {
         Cand dummy = none;
-        for (int s = 0; s < S; ++s) {
+        for (int s = gl; s < S; s += 32) {
             const Cand* q = dpart + ((size_t)j * S + s) * 2;
             cc_top2_push(dv[0], dummy, q[0]);
-            dummy = none;
             cc_top2_push(dv[1], dummy, q[1]);
-            dummy = none;
+        }
+        for (int off = 16; off >= 1; off >>= 1) {
+            const Cand o0 = cc_shfl_xor_cand(dv[0], off), o1 = cc_shfl_xor_cand(dv[1], off);
+            cc_top2_push(dv[0], dummy, o0);
+            cc_top2_push(dv[1], dummy, o1);
         }
     }
 
@@ -360,8 +439,8 @@ __global__ __launch_bounds__(64) void k_decide(Ctl* __restrict__ ctl, const doub
             bcf1 = ver.cf1 + (size_t)wrow * d; bcf2 = ver.cf2 + (size_t)wrow * d; bw = ver.w[wrow];
             target = ver.tgt[wrow];
         }
-        const double r2 = cc_tentative_radius(bcf1, bcf2, bw, p, d, ctl, nullptr, nullptr);  // hddstream.py:334-337
-        if (r2 <= ctl->eps_sq) {
+        const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, ctl);  // hddstream.py:334-337
+        if (g.r2 <= ctl->eps_sq) {
             T = target;
             path = stage;
         }
@@ -370,13 +449,16 @@ __global__ __launch_bounds__(64) void k_decide(Ctl* __restrict__ ctl, const doub
         T = M0 + j;
         path = 2;
     }
-    Tnew[j] = T;
-    dpath[j] = (int8_t)path;
-    if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
+    if (gl == 0) {
+        Tnew[j] = T;
+        dpath[j] = (int8_t)path;
+        if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
+    }
 }
 
 // ---------------------------------------------------------------------------------
-// k_chain: replay the claimed decisions per MC in arrival order
+// k_chain: replay the claimed decisions per MC in arrival order.  One 32-lane group per window point; the
+// group of the first point that targets a MC walks that MC's chain, every step dimension-parallel.
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
@@ -389,22 +471,27 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     extern __shared__ int sT[];
     for (int i = threadIdx.x; i < B; i += blockDim.x) sT[i] = T[i];
     __syncthreads();
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gl = threadIdx.x & 31;
+    const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
     const int t = sT[j];
     if (t == CC_T_UNKNOWN) {
-        ver.kind[j] = CC_KIND_DEAD; ver.next[j] = j; ver.tgt[j] = t; ver.acc[j] = 0; ver.upg[j] = -1;
+        if (gl == 0) {
+            ver.kind[j] = CC_KIND_DEAD; ver.next[j] = j; ver.tgt[j] = t; ver.acc[j] = 0; ver.upg[j] = -1;
+        }
         return;
     }
-    for (int i = j - 1; i >= 0; --i)
-        if (sT[i] == t) return;  // an earlier point heads this chain and walks over j
+    for (int base = 0; base < j; base += 32) {
+        const int i = base + gl;
+        if (cc_group_ballot(i < j && sT[i] == t)) return;  // an earlier point heads this chain and walks over j
+    }
 
     const int d = ctl->d;
     const int M0 = ctl->m_rows;
     const bool isnew = t >= M0;
     const bool valid_chain = !isnew || (t == M0 + j);  // a claim on a MC nobody creates any more is void
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
-    if (!isnew) tab.touch[t] = (stamp << 20) | (unsigned long long)j;
+    if (!isnew && gl == 0) tab.touch[t] = (stamp << 20) | (unsigned long long)j;
 
     const double *bcf1 = nullptr, *bcf2 = nullptr, *bcen = nullptr, *bpref = nullptr;
     double bw = 0.0;
@@ -417,48 +504,51 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     int cur = j;
     while (true) {
         int nx = CC_IDX_INF;
-        for (int i = cur + 1; i < B; ++i)
-            if (sT[i] == t) { nx = i; break; }
+        for (int base = cur + 1; base < B; base += 32) {
+            const int i = base + gl;
+            const unsigned m = cc_group_ballot(i < B && sT[i] == t);
+            if (m) { nx = base + __builtin_ctz(m); break; }
+        }
         double* vcf1 = ver.cf1 + (size_t)cur * d; double* vcf2 = ver.cf2 + (size_t)cur * d;
         double* vcen = ver.cen + (size_t)cur * d; double* vpref = ver.pref + (size_t)cur * d;
-        ver.tgt[cur] = t;
         if (!valid_chain) {
-            ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
+            if (gl == 0) {
+                ver.tgt[cur] = t; ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
+            }
         } else {
             const double* p = X + (ctl->cursor + cur) * d;
             const double w1 = bw + 1.0;  // microcluster.py:147
-            double r2 = 0.0;
-            int gt1 = 0;
-            for (int i = 0; i < d; ++i) {
-                const double x = p[i];
-                const double c1 = (bcf1 ? bcf1[i] : 0.0) + x;      // mc_functions.py:26
-                const double c2 = (bcf2 ? bcf2[i] : 0.0) + x * x;  // :27
-                const double var = cc_sqvar(c1, c2, w1);
-                const double pr = (var <= ctl->delta_sq) ? ctl->k : 1.0;
-                vcf1[i] = c1; vcf2[i] = c2;
-                vcen[i] = c1 / w1;  // mc_functions.py:31-33
-                vpref[i] = pr;
-                gt1 += (pr > 1.0);
-                r2 = r2 + cc_div_pref(var, pr, ctl);
-            }
+            const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, ctl);
             const bool creates = isnew && cur == j;
-            const bool ok = creates || (r2 <= ctl->eps_sq);
+            const bool ok = creates || (g.r2 <= ctl->eps_sq);
             if (ok) {
-                ver.w[cur] = w1;
                 // hddstream.py:416-430: promotion is only examined after an add to an existing outlier MC
-                if (bkind == CC_KIND_OUTLIER && !creates && w1 >= ctl->beta_mu && gt1 <= ctl->pi) {
+                if (bkind == CC_KIND_OUTLIER && !creates && w1 >= ctl->beta_mu && g.gt1 <= ctl->pi) {
                     bkind = CC_KIND_PCORE; bkey = ctl->n_pkeys + cur; bupg = cur;
                 }
-            } else {
-                for (int i = 0; i < d; ++i) {
-                    vcf1[i] = bcf1[i]; vcf2[i] = bcf2[i]; vcen[i] = bcen[i]; vpref[i] = bpref[i];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = gl + 32 * h;
+                    if (i < d) {
+                        vcf1[i] = g.c1[h]; vcf2[i] = g.c2[h];
+                        vcen[i] = g.c1[h] / w1;  // mc_functions.py:31-33
+                        vpref[i] = g.pr[h];
+                    }
                 }
-                ver.w[cur] = bw;
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = gl + 32 * h;
+                    if (i < d) { vcf1[i] = bcf1[i]; vcf2[i] = bcf2[i]; vcen[i] = bcen[i]; vpref[i] = bpref[i]; }
+                }
             }
-            ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg; ver.acc[cur] = ok ? 1 : 0;
-            ver.next[cur] = nx;
+            if (ok) bw = w1;
+            if (gl == 0) {
+                ver.w[cur] = bw;
+                ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
+                ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
+            }
             bcf1 = vcf1; bcf2 = vcf2; bcen = vcen; bpref = vpref;
-            bw = ver.w[cur];
         }
         if (nx == CC_IDX_INF) break;
         cur = nx;
@@ -466,97 +556,84 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 }
 
 // ---------------------------------------------------------------------------------
-// k_commit: write the validated prefix back and open the next window (one workgroup)
+// commit: k_commit_a (one workgroup) ranks the new MCs / promotions of the validated prefix in point order,
+// writes the labels, and opens the next window; k_commit_b (many workgroups) copies the last version of every
+// touched MC back into the table.
 // ---------------------------------------------------------------------------------
 
-__device__ inline void cc_block_exclusive_scan(int* a, int n, int* total, int* scratch)
-{
-    // a[0..n) -> exclusive prefix sums in place; blockDim.x threads, scratch[blockDim.x]
-    const int tid = threadIdx.x, nt = blockDim.x;
-    const int chunk = (n + nt - 1) / nt;
-    const int lo = min(n, tid * chunk), hi = min(n, lo + chunk);
-    int s = 0;
-    for (int i = lo; i < hi; ++i) s += a[i];
-    scratch[tid] = s;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < nt; ++i) { int v = scratch[i]; scratch[i] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    int run = scratch[tid];
-    for (int i = lo; i < hi; ++i) { int v = a[i]; a[i] = run; run += v; }
-    __syncthreads();
-}
+struct CommitRec {
+    int n;        // validated prefix length
+    int M0;       // table rows at window start
+    int pk0, ok0; // list-order key bases
+    long long pid0, oid0;
+    const int* T; // the claims the prefix was validated against
+};
 
-__global__ __launch_bounds__(1024) void k_commit(Ctl* __restrict__ ctl, Table tab, Versions ver,
-                                                 const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
-                                                 const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
-                                                 int8_t* __restrict__ lab_path)
+__global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver,
+                                                   const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
+                                                   const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
+                                                   int8_t* __restrict__ lab_path, int* __restrict__ rk,
+                                                   CommitRec* __restrict__ rec)
 {
     const int B = ctl->win_b;
-    if (B == 0) return;
-    extern __shared__ int sm[];
-    int* rnew = sm;          // [B]
-    int* rup = sm + B;       // [B]
-    int* scratch = sm + 2 * B;  // [blockDim.x]
-    __shared__ int tot_new, tot_up;
+    if (B == 0) {
+        if (threadIdx.x == 0) rec->n = 0;
+        return;
+    }
+    __shared__ int wsum[16];
+    __shared__ int tot;
     const int r = ctl->last_round;
     const int* T = ((r - 1) & 1) ? Tbuf1 : Tbuf0;
     const int fcv = ctl->fc[r];
     const int n = fcv < B ? fcv : B;
-    const int d = ctl->d;
     const int M0 = ctl->m_rows;
-    const int tid = threadIdx.x, nt = blockDim.x;
-
-    for (int j = tid; j < B; j += nt) {
-        rnew[j] = (j < n && T[j] == M0 + j) ? 1 : 0;
-        rup[j] = (j < n && ver.upg[j] == j) ? 1 : 0;
-    }
-    __syncthreads();
-    cc_block_exclusive_scan(rnew, B, &tot_new, scratch);
-    cc_block_exclusive_scan(rup, B, &tot_up, scratch);
-
+    const int tid = threadIdx.x;
     const long long cursor = ctl->cursor;
     const long long oid0 = ctl->outlier_last_id, pid0 = ctl->pcore_last_id;
     const int pk0 = ctl->n_pkeys, ok0 = ctl->n_okeys;
-    for (int j = tid; j < n; j += nt) {
-        const int t = T[j];
-        lab_uid[cursor + j] = (t < M0) ? tab.uid[t] : oid0 + rnew[t - M0];
-        lab_path[cursor + j] = (int8_t)(dpath[j] | ((ver.upg[j] == j) ? 4 : 0));
+    const long long n_points = ctl->n_points;
+    const int win_cfg = ctl->win_cfg;
+
+    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 4096
+    const int per = (B + 1023) >> 10;  // points per thread
+    int loc[4];
+    int mine = 0;
+    for (int q = 0; q < per; ++q) {
+        const int j = tid * per + q;
+        int f = 0;
+        if (j < n) f = ((T[j] == M0 + j) ? 1 : 0) | ((ver.upg[j] == j) ? 0x10000 : 0);
+        loc[q] = mine;
+        mine += f;
     }
-    __syncthreads();  // tab.uid reads above precede the row writes below
-    // scalar columns of the last version of every touched MC
-    for (int j = tid; j < n; j += nt) {
-        if (ver.next[j] < n) continue;
-        const int t = T[j];
-        const int row = (t < M0) ? t : M0 + rnew[t - M0];
-        tab.w[row] = ver.w[j];
-        tab.kind[row] = ver.kind[j];
-        const int u = ver.upg[j];
-        if (u >= 0) {
-            tab.key[row] = pk0 + rup[u];
-            tab.id[row] = pid0 + rup[u];
-        } else if (t >= M0) {
-            tab.key[row] = ok0 + rnew[t - M0];
-            tab.id[row] = oid0 + rnew[t - M0];
-        }
-        if (t >= M0) tab.uid[row] = oid0 + rnew[t - M0];
+    // inclusive wave scan of the per-thread sums
+    int v = mine;
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
     }
-    // vector columns
-    for (int e = tid; e < n * d; e += nt) {
-        const int j = e / d, i = e - j * d;
-        if (ver.next[j] < n) continue;
-        const int t = T[j];
-        const size_t row = (t < M0) ? (size_t)t : (size_t)(M0 + rnew[t - M0]);
-        tab.cf1[row * d + i] = ver.cf1[(size_t)j * d + i];
-        tab.cf2[row * d + i] = ver.cf2[(size_t)j * d + i];
-        tab.cen[row * d + i] = ver.cen[(size_t)j * d + i];
-        tab.pref[row * d + i] = ver.pref[(size_t)j * d + i];
-    }
+    if (lane == 63) wsum[wid] = v;
     __syncthreads();
     if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 16; ++i) { const int x = wsum[i]; wsum[i] = run; run += x; }
+        tot = run;
+    }
+    __syncthreads();
+    const int excl = v - mine + wsum[wid];
+    for (int q = 0; q < per; ++q) {
+        const int j = tid * per + q;
+        if (j < B) rk[j] = excl + loc[q];
+    }
+    __syncthreads();
+    const int tot_new = tot & 0xFFFF, tot_up = tot >> 16;
+    for (int j = tid; j < n; j += 1024) {
+        const int t = T[j];
+        lab_uid[cursor + j] = (t < M0) ? tab.uid[t] : oid0 + (rk[t - M0] & 0xFFFF);
+        lab_path[cursor + j] = (int8_t)(dpath[j] | ((ver.upg[j] == j) ? 4 : 0));
+    }
+    if (tid == 0) {
+        rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         ctl->m_rows = M0 + tot_new;
         ctl->n_okeys = ok0 + tot_new;
         ctl->outlier_last_id = oid0 + tot_new;
@@ -570,11 +647,45 @@ __global__ __launch_bounds__(1024) void k_commit(Ctl* __restrict__ ctl, Table ta
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
         ctl->window_seq += 1;
-        long long left = ctl->n_points - (cursor + n);
-        ctl->win_b = (int)(left < (long long)ctl->win_cfg ? left : (long long)ctl->win_cfg);
+        const long long left = n_points - (cursor + n);
+        ctl->win_b = (int)(left < (long long)win_cfg ? left : (long long)win_cfg);
         ctl->last_round = 0;
         ctl->fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) ctl->fc[i] = CC_IDX_INF;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ rec, Table tab, Versions ver,
+                                                  const int* __restrict__ rk, int d)
+{
+    const int n = rec->n;
+    if (n == 0) return;
+    const int M0 = rec->M0;
+    const int* T = rec->T;
+    const int stride = gridDim.x * blockDim.x;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * d; e += stride) {
+        const int j = e / d, i = e - j * d;
+        if (ver.next[j] < n) continue;  // a later point of the prefix holds the MC's last version
+        const int t = T[j];
+        const int c = t - M0;
+        const size_t row = (t < M0) ? (size_t)t : (size_t)(M0 + (rk[c] & 0xFFFF));
+        tab.cf1[row * d + i] = ver.cf1[(size_t)j * d + i];
+        tab.cf2[row * d + i] = ver.cf2[(size_t)j * d + i];
+        tab.cen[row * d + i] = ver.cen[(size_t)j * d + i];
+        tab.pref[row * d + i] = ver.pref[(size_t)j * d + i];
+        if (i == 0) {
+            tab.w[row] = ver.w[j];
+            tab.kind[row] = ver.kind[j];
+            const int u = ver.upg[j];
+            if (u >= 0) {
+                tab.key[row] = rec->pk0 + (rk[u] >> 16);
+                tab.id[row] = rec->pid0 + (rk[u] >> 16);
+            } else if (t >= M0) {
+                tab.key[row] = rec->ok0 + (rk[c] & 0xFFFF);
+                tab.id[row] = rec->oid0 + (rk[c] & 0xFFFF);
+            }
+            if (t >= M0) tab.uid[row] = rec->oid0 + (rk[c] & 0xFFFF);
+        }
     }
 }
 

@@ -149,6 +149,12 @@ int cc_cluster_size(cc_handle* h, int32_t c);
 int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, double* cf1, double* cf2,
                       double* cen, double* pref);
 
+/* All clusters in one call: offsets[n_clusters + 1] index members[] (pcore ids, merge order);
+ * w is [n_clusters]; cf1 / cf2 / cen / pref are [n_clusters, d].  Any output pointer may be NULL. */
+int cc_clusters_total_members(cc_handle* h);
+int cc_clusters_export(cc_handle* h, int64_t* members, int32_t* offsets, double* w, double* cf1, double* cf2,
+                       double* cen, double* pref);
+
 /* TrackByHistoricalAssociation.track_cluster_history (cluster_tracker.py:127-141):
  * for every current pcore (cur_cen/cur_pref [mc,d]) the index of the previous
  * pcore (prev_cen [mp,d], given in iteration order) with the smallest
