@@ -1,0 +1,185 @@
+"""chronoclust_amd.app — the reference's entry point (chronoclust/app.py:32-226) on top of the MI355X hot path.
+
+`run()` keeps the signature, the parameter surface (beta, delta, epsilon, lambda, k, mu, pi, omicron,
+upsilon) and the output files of the reference: result.csv, cluster_points_D{t}.csv, parameters.csv and
+logs/Chronoclust.log, byte for byte.  Per timepoint the clustering, the offline phase and the association
+argmin run on the GPU (clustering/hddstream.py, tracking/cluster_tracker.py); the writers are vectorised
+(per-point labels come back as one int64 array instead of per-microcluster Python dicts).
+"""
+import csv
+import logging
+import os
+from collections import defaultdict
+from decimal import ROUND_HALF_UP, Decimal
+
+import numpy as np
+import pandas as pd
+
+from .clustering.hddstream import HDDStream
+from .objects.cluster import Cluster
+from .scaling.scaler import Scaler
+from .tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
+
+HDDSTREAM_OBJ = 'hddstream'
+TRACKER_HISTORICAL_ASSOC = 'tracking_by_historical_association'
+TRACKER_LINEAGE = 'tracking_by_lineage'
+
+
+def run(data, output_directory, gating_centroid_file=None, normalise_data=True, restore_program=False,
+        param_beta=0.8, param_delta=0.0, param_epsilon=0.03, param_lambda=0, param_k=1,
+        param_mu=0.001, param_pi=0, param_omicron=0.0, param_upsilon=1):
+    """Runs ChronoClust over the timepoint files in `data` (in time order) and writes the results into
+    `output_directory`.  Same arguments and side effects as the reference's `chronoclust.app.run`.
+
+    restore_program: the reference's pickle-based resume loses its id counters and truncates result.csv
+    (SURVEY.md section 5); it is not offered here and raises NotImplementedError when requested.
+    """
+    if restore_program:
+        raise NotImplementedError("restore_program is not supported by chronoclust_amd (upstream resume is broken)")
+
+    logger = setup_logger('{}/logs'.format(output_directory))
+    logger.info("Chronoclust start")
+    config = {"beta": param_beta, "delta": param_delta, "epsilon": param_epsilon, "lambda": param_lambda,
+              "k": param_k, "mu": param_mu, "pi": param_pi, "omicron": param_omicron, "upsilon": param_upsilon}
+
+    logger.info("Setup new Chronoclust state")
+    hddstream = HDDStream(config, logger)
+    tracker_by_association = TrackByHistoricalAssociation(handle=hddstream._h)
+    tracker_by_lineage = TrackByLineage()
+
+    dataset_attributes = get_dataset_attributes(data[0])
+    result_filename = f'{output_directory}/result.csv'
+    result_file_header = ['timepoint', 'cumulative_size', 'pcore_ids', 'pref_dimensions'] + dataset_attributes + \
+                         ['tracking_by_lineage', 'tracking_by_association']
+
+    gating = defaultdict(dict)
+    if gating_centroid_file is not None:
+        gating_df = pd.read_csv(gating_centroid_file)
+        result_file_header.append('predicted_label')
+        for _, gate in gating_df.iterrows():
+            centroid = tuple(gate[dataset_attributes].values)
+            gating[int(gate['Day'])][centroid] = gate['PopName']
+    write_file_header(result_filename, result_file_header)
+
+    scaler = None
+    if normalise_data:
+        logger.info("Setting up scaler")
+        scaler = Scaler(data)
+
+    for timepoint, data_file in enumerate(data):
+        logger.info("Processing dataset {}".format(timepoint))
+        raw = pd.read_csv(data_file, header=0, sep=',').to_numpy()
+        dataset = raw
+        if normalise_data:
+            logger.info("Scaling dataset {}".format(timepoint))
+            dataset = scaler.scale_data(raw)
+
+        hddstream.online_microcluster_maintenance(dataset, timepoint)
+        pcore_by_id = {mc.id[0]: mc for mc in hddstream.pcore_MC}
+
+        for found in hddstream.final_clusters:
+            # one decimal place, half up, through the float's shortest repr (app.py:184)
+            rounded_weight = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)
+            cluster = Cluster(list(found.id), found.cluster_centroids, rounded_weight,
+                              found.preferred_dimension_vector)
+            cluster.add_pcore_objects(pcore_by_id)
+            tracker_by_lineage.add_new_child_cluster(cluster)
+
+        tracker_by_lineage.calculate_ids()
+        tracker_by_association.set_current_clusters(tracker_by_lineage.child_clusters)
+        tracker_by_association.track_cluster_history()
+
+        write_result_file(gating, result_filename, timepoint, tracker_by_association, scaler=scaler)
+        write_datapoints_details(dataset_attributes, tracker_by_lineage.child_clusters, hddstream,
+                                 raw, dataset, f'{output_directory}/cluster_points_D{timepoint}.csv', scaler)
+
+        tracker_by_lineage.transfer_child_to_parent()
+        tracker_by_association.transfer_current_to_previous()
+
+    with open(f'{output_directory}/parameters.csv', 'w') as f:
+        w = csv.DictWriter(f, config.keys())
+        w.writeheader()
+        w.writerow(config)
+    logger.info('Chronoclust finish')
+
+
+def write_result_file(gating, result_filename, timepoint, tracker_by_association, scaler):
+    """One row per cluster of this timepoint (app.py:229-260)."""
+    rows = []
+    gating_now = gating.get(timepoint)
+    for cluster in tracker_by_association.current_clusters:
+        row = [timepoint, cluster.cumulative_weight, cluster.get_pcore_ids_as_str(),
+               cluster.get_preferred_dimensions_as_str()]
+        if scaler:
+            centroid = scaler.reverse_scaling([cluster.centroid]).tolist()[0]
+            centroid = np.round(centroid, 5).tolist()
+        else:
+            centroid = np.round(cluster.centroid, 5).tolist()
+        row.extend(centroid)
+        row.append(cluster.id)
+        row.append(cluster.get_historical_associates_as_str())
+        if bool(gating_now):
+            row.append(find_closest_gating(gating_now, cluster, scaler))
+        rows.append(row)
+    append_to_file(result_filename, rows)
+
+
+def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, scaled, cluster_points_filename, scaler):
+    """id, cluster_id, <features> for every point of the timepoint, in input order (app.py:263-360).
+
+    The reference walks per-microcluster `points` dicts; here the per-point microcluster labels are one int64
+    array (creation number of the MC holding each row), joined to the lineage ids by lookup."""
+    write_file_header(cluster_points_filename, ['id', 'cluster_id'] + dataset_attributes)
+    n = scaled.shape[0]
+    pcore = hddstream.table(0)
+    uid_of_pcore = {int(i): int(u) for i, u in zip(pcore["id"], pcore["uid"])}
+    label_of_uid = {}
+    for cluster in clusters:
+        for p in cluster.pcore_objects:
+            label_of_uid[uid_of_pcore[p.id[0]]] = cluster.id
+    uids, inverse = np.unique(hddstream.labels_uid, return_inverse=True)
+    names = np.array([label_of_uid.get(int(u), "None") for u in uids], dtype=object)
+    cluster_ids = names[inverse] if n else np.empty(0, dtype=object)
+
+    if scaler:
+        values = scaler.reverse_scaling(scaled)
+    else:
+        values = raw
+    columns = {'id': np.arange(n, dtype=np.int64), 'cluster_id': cluster_ids}
+    for c, name in enumerate(dataset_attributes):
+        columns[name] = values[:, c] if n else []
+    pd.DataFrame(columns).to_csv(cluster_points_filename, index=False)
+
+
+def setup_logger(log_dir):
+    os.makedirs(log_dir, exist_ok=True)
+    logging.basicConfig(filename='{}/Chronoclust.log'.format(log_dir),
+                        format='%(asctime)s [%(levelname)-8s] %(message)s')
+    logger = logging.getLogger()
+    logger.setLevel(logging.INFO)
+    return logger
+
+
+def write_file_header(filename, header):
+    with open(filename, 'w') as f:
+        csv.writer(f).writerow(header)
+
+
+def append_to_file(filename, content):
+    with open(filename, 'a') as f:
+        csv.writer(f).writerows(content)
+
+
+def get_dataset_attributes(dataset_file):
+    return pd.read_csv(dataset_file, sep=',', header=None).iloc[0].values.tolist()
+
+
+def find_closest_gating(gating_dict, cluster, scaler):
+    """Label of the gating centroid with the smallest projected distance to the cluster (app.py:497-512)."""
+    best, best_label = None, None
+    for centroid, label in gating_dict.items():
+        point = scaler.scale_data([centroid])[0].tolist() if scaler else centroid
+        dist = cluster.get_projected_dist_to_point(np.array(point))
+        if best is None or dist < best:
+            best, best_label = dist, label
+    return best_label

@@ -1,0 +1,121 @@
+"""Cluster tracking: the interface of chronoclust/tracking/cluster_tracker.py.
+
+TrackByLineage is integer / string logic on pcore ids and stays on the host.
+TrackByHistoricalAssociation's distance argmin (cluster_tracker.py:127-141) is the K9 kernel behind
+cc_assoc_argmin: one launch for all current pcores against all previous pcores."""
+import string
+from collections import deque
+
+import numpy as np
+
+
+class TrackByLineage(object):
+    def __init__(self):
+        self.child_clusters = []
+        self.parent_clusters = []
+        self._letter_len = 1
+        self.letters = deque(string.ascii_uppercase)
+        self.split_per_id = {}
+
+    # letters: A..Z, AA..ZZ, AAA.. (cluster_tracker.py:14-24)
+    def get_new_letter(self):
+        letter = self.letters.popleft()
+        if not self.letters:
+            self._letter_len = len(letter) + 1
+            self.letters = deque(ch * self._letter_len for ch in string.ascii_uppercase)
+        return letter
+
+    def add_new_child_cluster(self, cluster):
+        self.child_clusters.append(cluster)
+
+    def get_parent_pcore_to_id(self):
+        mapping = {}
+        for parent in self.parent_clusters:
+            for pcore in parent.pcore_ids:
+                mapping[pcore] = parent.id
+        return mapping
+
+    def calculate_ids(self):
+        children = self.child_clusters
+        if all(c.cumulative_weight is not None for c in children):
+            children.sort(key=lambda c: c.cumulative_weight)  # stable; also the row order of result.csv
+
+        parent_of_pcore = self.get_parent_pcore_to_id()
+        offspring = {}
+        for cluster in children:
+            cluster.set_parents(parent_pcores_to_id=parent_of_pcore)
+            if not cluster.parents:
+                cluster.add_parent(id=self.get_new_letter())
+            for parent in cluster.get_parents():
+                offspring.setdefault(parent, []).append(cluster)
+
+        # per parent: the child holding most of its pcores keeps the label, the others become parent|n with a
+        # split counter that persists over timepoints (cluster_tracker.py:51-70)
+        for parent, kids in offspring.items():
+            ranked = sorted(kids, key=lambda c: len(c.pcore_ids), reverse=True)
+            splits = self.split_per_id.get(parent, 0)
+            for rank, child in enumerate(ranked):
+                if rank == 0:
+                    child.add_id(parent)
+                else:
+                    splits += 1
+                    child.add_id('{}|{}'.format(parent, splits))
+            self.split_per_id[parent] = splits
+        self.assign_child_id()
+
+    def assign_child_id(self):
+        # one label: itself; several (a merge): nested parentheses over the sorted labels (:88-109)
+        for child in self.child_clusters:
+            labels = sorted(child.id)
+            text = labels[0]
+            for extra in labels[1:]:
+                text = '(' + text + ',' + extra + ')'
+            child.id = text
+
+    def transfer_child_to_parent(self):
+        self.parent_clusters = self.child_clusters
+        self.child_clusters = []
+
+
+class TrackByHistoricalAssociation(object):
+    def __init__(self, handle=None):
+        self.current_clusters = []
+        self.previous_timepoint_clusters = []
+        self._handle = handle
+
+    def _hip(self):
+        if self._handle is None:
+            from .. import _lib
+            self._handle = _lib.Handle(0)
+        return self._handle
+
+    def set_current_clusters(self, clusters):
+        self.current_clusters = clusters
+
+    def track_cluster_history(self):
+        if len(self.previous_timepoint_clusters) == 0:
+            for cluster in self.current_clusters:
+                cluster.add_historical_associate(None)
+            return
+        prev_owner, prev_pcore, prev_cen = [], [], []
+        for pc in self.previous_timepoint_clusters:
+            for p in pc.pcore_objects:
+                prev_owner.append(pc.id)
+                prev_pcore.append(p.id)
+                prev_cen.append(np.asarray(p.cluster_centroids, dtype=np.float64))
+        cur = [(cl, p) for cl in self.current_clusters for p in cl.pcore_objects]
+        if not cur:
+            return
+        cur_cen = np.array([np.asarray(p.cluster_centroids, dtype=np.float64) for _, p in cur])
+        cur_pref = np.array([np.asarray(p.preferred_dimension_vector, dtype=np.float64) for _, p in cur])
+        if prev_cen:
+            idx, _ = self._hip().assoc_argmin(cur_cen, cur_pref, np.array(prev_cen))
+        else:
+            idx = np.full(len(cur), -1)
+        for (cluster, _), i in zip(cur, idx):
+            cluster.add_historical_associate(prev_owner[i] if i >= 0 else None)
+            cluster.add_historical_associate_pcore(prev_pcore[i] if i >= 0 else None)
+
+    def transfer_current_to_previous(self):
+        self.previous_timepoint_clusters = self.current_clusters
+        self.current_clusters = []

@@ -1,0 +1,138 @@
+"""GPU end-to-end tests of chronoclust_amd.app.run against the reference's committed / recorded outputs."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import scenarios
+from golden_util import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _reset_logging():
+    import logging
+    root = logging.getLogger()
+    for h in list(root.handlers):
+        root.removeHandler(h)
+        h.close()
+
+
+def _labels(csv_path):
+    df = pd.read_csv(csv_path, keep_default_na=False, dtype=str)
+    return df["id"].to_numpy().astype(np.int64), df["cluster_id"].to_numpy().astype(str)
+
+
+def test_c1_integration_golden(tmp_path):
+    """chronoclust/tests/integration_test/normal_test.py: result.csv byte for byte, every (id, cluster_id),
+    and the whole per-point files of the recorded reference run."""
+    from chronoclust_amd import app
+    c1 = os.path.join(GOLDEN, "c1")
+    data = [os.path.join(c1, "synthetic_d%d.csv.gz" % t) for t in range(5)]
+    try:
+        app.run(data=data, output_directory=str(tmp_path), gating_centroid_file=os.path.join(c1, "gating_centroids.csv"),
+                **scenarios.C1_PARAMS)
+    finally:
+        _reset_logging()
+    with open(os.path.join(c1, "expected_result.csv"), newline="") as f:
+        exp = f.read()
+    with open(os.path.join(str(tmp_path), "result.csv"), newline="") as f:
+        got = f.read()
+    assert got.replace("\r\n", "\n") == exp.replace("\r\n", "\n")
+    lab = np.load(os.path.join(c1, "expected_point_labels.npz"))
+    rec = np.load(os.path.join(c1, "hdd_state.npz"))
+    for t in range(5):
+        ids, cl = _labels(os.path.join(str(tmp_path), "cluster_points_D%d.csv" % t))
+        np.testing.assert_array_equal(ids, lab["t%d_id" % t])
+        assert (cl == lab["t%d_cluster_id" % t]).all()
+        exp_text = gzip.decompress(rec["t%d_points_csv" % t].tobytes())
+        assert open(os.path.join(str(tmp_path), "cluster_points_D%d.csv" % t), "rb").read() == exp_text
+    assert os.path.exists(os.path.join(str(tmp_path), "parameters.csv"))
+    # logs/Chronoclust.log: logging.basicConfig is a no-op under pytest (root handlers exist), as upstream
+
+
+def test_nocluster_integration_golden(tmp_path):
+    """chronoclust/tests/integration_test/no_cluster_test.py: no result rows, every point labelled None."""
+    from chronoclust_amd import app
+    nc = os.path.join(GOLDEN, "nocluster")
+    try:
+        app.run(data=[os.path.join(nc, "synthetic_d%d.csv.gz" % t) for t in range(5)], output_directory=str(tmp_path),
+                **scenarios.NOCLUSTER_PARAMS)
+    finally:
+        _reset_logging()
+    assert open(os.path.join(str(tmp_path), "result.csv"), "rb").read() == \
+        open(os.path.join(nc, "expected_result.csv"), "rb").read()
+    for t in range(5):
+        assert open(os.path.join(str(tmp_path), "cluster_points_D%d.csv" % t), "rb").read() == \
+            open(os.path.join(nc, "expected_cluster_points_D%d.csv" % t), "rb").read()
+        ids, cl = _labels(os.path.join(str(tmp_path), "cluster_points_D%d.csv" % t))
+        assert len(ids) == 10 and (cl == "None").all()
+
+
+@pytest.mark.parametrize("name", sorted(scenarios.BLOB_SCENARIOS))
+def test_blob_end_to_end(name, tmp_path):
+    """d = 20 / 14 / 40 / 5 scenarios through app.run: result.csv bytes (lineage + association strings, pcore id
+    set order, rounded weights and centroids) and per-point cluster ids of the recorded reference run."""
+    from chronoclust_amd import app
+    sc = scenarios.BLOB_SCENARIOS[name]
+    z = np.load(os.path.join(GOLDEN, "blob_%s.npz" % name))
+    Xs = scenarios.make_blob_timepoints(sc, raw=True)
+    files = []
+    for t, X in enumerate(Xs):
+        fn = os.path.join(str(tmp_path), "tp%d.csv" % t)
+        pd.DataFrame(X, columns=["m%d" % i for i in range(sc["d"])]).to_csv(fn, index=False)
+        files.append(fn)
+    out = os.path.join(str(tmp_path), "out")
+    os.makedirs(out)
+    try:
+        app.run(data=files, output_directory=out, normalise_data=sc.get("normalise", False), **sc["params"])
+    finally:
+        _reset_logging()
+    assert open(os.path.join(out, "result.csv"), "rb").read() == z["result_csv"].tobytes()
+    for t in range(len(Xs)):
+        ids, cl = _labels(os.path.join(out, "cluster_points_D%d.csv" % t))
+        assert (ids == np.arange(len(ids))).all()
+        assert (cl == z["t%d_cluster_id" % t]).all()
+
+
+def _assoc_scenarios():
+    with open(os.path.join(GOLDEN, "tracker_scenarios.json")) as f:
+        data = json.load(f)
+    return [s for s in data if any(e["op"] == "assoc" for e in s["events"])]
+
+
+@pytest.mark.parametrize("scenario", _assoc_scenarios(), ids=lambda s: s["test"])
+def test_association_scenarios_from_reference_unit_tests(scenario):
+    """chronoclust/tests/tracking_test/unittest_track_by_historical_assoc.py replayed through the K9 kernel."""
+    from chronoclust_amd.objects.cluster import Cluster, PcoreSnapshot
+    from chronoclust_amd.tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
+    lineage, assoc = TrackByLineage(), TrackByHistoricalAssociation()
+    for ev in scenario["events"]:
+        if ev["op"] == "lineage":
+            for c in ev["clusters_in_add_order"]:
+                cl = Cluster(list(c["pcore_ids"]))
+                for p in c.get("pcores", []):
+                    cl.pcore_objects.append(PcoreSnapshot(p["id"][0], np.array(p["centroid"]), np.array(p["pref"])))
+                lineage.add_new_child_cluster(cl)
+            lineage.calculate_ids()
+            assert [c.id for c in lineage.child_clusters] == ev["ids_after"]
+        elif ev["op"] == "lineage_next":
+            lineage.transfer_child_to_parent()
+        elif ev["op"] == "assoc":
+            if lineage.child_clusters:
+                assoc.set_current_clusters(lineage.child_clusters)
+            else:  # the first reference test drives the tracker without a lineage pass
+                cls = []
+                for c in ev["clusters"]:
+                    cl = Cluster(list(c["pcore_ids"]))
+                    for p in c.get("pcores", []):
+                        cl.pcore_objects.append(PcoreSnapshot(p["id"][0], np.array(p["centroid"]), np.array(p["pref"])))
+                    cls.append(cl)
+                assoc.set_current_clusters(cls)
+            assoc.track_cluster_history()
+            assert [c.get_historical_associates_as_str() for c in assoc.current_clusters] == ev["assoc_after"]
+        elif ev["op"] == "assoc_next":
+            assoc.transfer_current_to_previous()

@@ -1,0 +1,56 @@
+"""CPU tests of the host-side logic that mirrors the reference: scaler arithmetic, lineage strings."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from golden_util import GOLDEN
+from chronoclust_amd.objects.cluster import Cluster
+from chronoclust_amd.scaling.scaler import Scaler
+from chronoclust_amd.tracking.cluster_tracker import TrackByLineage
+
+
+def test_scaler_is_bit_identical_to_sklearn_minmax():
+    from sklearn.preprocessing import MinMaxScaler
+    rng = np.random.default_rng(0)
+    for shape, scale in (((500, 3), 40.0), ((2000, 20), 1.0), ((50, 7), 1e6)):
+        X = rng.normal(0, 1, shape) * scale + rng.uniform(-5, 5, shape[1])
+        X[:, 0] = 3.25  # constant column: range 0 -> scale 1
+        ref = MinMaxScaler().fit(X)
+        s = Scaler()
+        s.fit_scaler(X)
+        Y = rng.normal(0, 1, (100, shape[1])) * scale
+        assert np.array_equal(s.scale_data(Y), ref.transform(Y))
+        Z = ref.transform(Y)
+        assert np.array_equal(s.reverse_scaling(Z), ref.inverse_transform(Z))
+        assert np.array_equal(s.reverse_scaling([Z[0]]), ref.inverse_transform([Z[0]]))
+
+
+def _scenarios(op):
+    with open(os.path.join(GOLDEN, "tracker_scenarios.json")) as f:
+        data = json.load(f)
+    return [s for s in data if any(e["op"] == op for e in s["events"])]
+
+
+@pytest.mark.parametrize("scenario", _scenarios("lineage"), ids=lambda s: s["test"])
+def test_lineage_scenarios_from_reference_unit_tests(scenario):
+    """Every scenario of chronoclust/tests/tracking_test/*.py, replayed: same cluster ids in the same order."""
+    from decimal import Decimal
+    tracker = TrackByLineage()
+    for ev in scenario["events"]:
+        if ev["op"] == "lineage":
+            for c in ev["clusters_in_add_order"]:
+                w = None if c["weight"] is None else Decimal(c["weight"])
+                tracker.add_new_child_cluster(Cluster(list(c["pcore_ids"]), cumulative_weight=w))
+            tracker.calculate_ids()
+            assert [c.id for c in tracker.child_clusters] == ev["ids_after"]
+            assert [list(c.pcore_ids) for c in tracker.child_clusters] == ev["pcore_ids_after"]
+        elif ev["op"] == "lineage_next":
+            tracker.transfer_child_to_parent()
+
+
+def test_letters_run_past_z():
+    t = TrackByLineage()
+    got = [t.get_new_letter() for _ in range(26 * 2 + 2)]
+    assert got[25:28] == ["Z", "AA", "BB"] and got[51:54] == ["ZZ", "AAA", "BBB"]
