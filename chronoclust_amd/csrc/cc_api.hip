@@ -253,14 +253,15 @@ Versions versions_view(cc_handle* h)
 // ---- scan dispatch over the padded dimensionality ---------------------------------
 
 template <int DP, bool DIRTY>
-void launch_scan_dp(cc_handle* h, dim3 grid, Rows rows, const Cand* clean, Cand* part, int S, int round)
+void launch_scan_dp(cc_handle* h, dim3 grid, Rows rows, const Cand* clean, Cand* part, int round)
 {
+    const dim3 block(64 * CC_SCAN_WAVES);
     if (h->hc.pow2)
-        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY>), grid, dim3(64), 0, h->stream, h->ctl.p, h->X.p, rows, clean,
-                           part, S, round);
+        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+                           part, round);
     else
-        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY>), grid, dim3(64), 0, h->stream, h->ctl.p, h->X.p, rows, clean,
-                           part, S, round);
+        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+                           part, round);
 }
 
 template <bool DIRTY>
@@ -268,13 +269,13 @@ void launch_scan(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part
 {
     dim3 grid((win + 63) / 64, S);
     const int d = h->d;
-    if (d <= 4) launch_scan_dp<4, DIRTY>(h, grid, rows, clean, part, S, round);
-    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, grid, rows, clean, part, S, round);
-    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, grid, rows, clean, part, S, round);
-    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, grid, rows, clean, part, S, round);
-    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, grid, rows, clean, part, S, round);
-    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, grid, rows, clean, part, S, round);
-    else launch_scan_dp<64, DIRTY>(h, grid, rows, clean, part, S, round);
+    if (d <= 4) launch_scan_dp<4, DIRTY>(h, grid, rows, clean, part, round);
+    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, grid, rows, clean, part, round);
+    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, grid, rows, clean, part, round);
+    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, grid, rows, clean, part, round);
+    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, grid, rows, clean, part, round);
+    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, grid, rows, clean, part, round);
+    else launch_scan_dp<64, DIRTY>(h, grid, rows, clean, part, round);
 }
 
 hipEvent_t get_event(cc_handle* h, size_t i)
@@ -450,7 +451,9 @@ int cc_online_run(cc_handle* h)
     if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
     return guarded(h, [&]() {
         const long long N = h->n_points;
-        const int win = h->tun.window, R = h->tun.rounds, S = h->tun.segments;
+        const int win = h->tun.window, R = h->tun.rounds;
+        // `segments` MC sub-ranges per point tile = S workgroups of CC_SCAN_WAVES waves -> S partials per point
+        const int S = std::max(1, h->tun.segments / CC_SCAN_WAVES);
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
@@ -505,7 +508,7 @@ int cc_online_run(cc_handle* h)
                 for (int r = 1; r <= R; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
-                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)win * sizeof(int), h->stream,
+                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)((win + 127) & ~127) * sizeof(int), h->stream,
                                        h->ctl.p, h->X.p, tab, ver, told, r);
                     launch_scan<true>(h, win, vrows, h->clean.p, h->dpart.p, S, r);
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,

@@ -75,16 +75,33 @@ __device__ inline double cc_tentative_radius(const double* bcf1, const double* b
     return r2;
 }
 
+__device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
+{
+    if (x.slot < 0) return;
+    if (a.slot < 0 || cand_less(x.dist, x.key, a.dist, a.key)) {
+        b = a;
+        a = x;
+    } else if (b.slot < 0 || cand_less(x.dist, x.key, b.dist, b.key)) {
+        b = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // k_scan: points (one or PT per lane, in registers) x MC rows (wave-uniform, staged in LDS)
 // ---------------------------------------------------------------------------------
 
-#define CC_SCAN_TM 16  // MC rows per LDS tile
+#define CC_SCAN_TM 16     // MC rows per LDS tile
+#define CC_SCAN_WAVES 4   // waves per workgroup: same points, disjoint MC sub-ranges, merged through LDS
 
+// One workgroup = CC_SCAN_WAVES waves that hold the same 64*PT points in registers.  The MC rows of the launch
+// are split into gridDim.y * CC_SCAN_WAVES sub-ranges; each wave streams its sub-range through its own LDS tile
+// (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
+// the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
 template <int DP, int PT, bool POW2, bool DIRTY>
-__global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const double* __restrict__ X, Rows rows,
-                                             const Cand* __restrict__ clean, Cand* __restrict__ part, int S,
-                                             int round)
+__global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restrict__ ctl,
+                                                             const double* __restrict__ X, Rows rows,
+                                                             const Cand* __restrict__ clean,
+                                                             Cand* __restrict__ part, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
@@ -92,20 +109,25 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
     const int j0 = blockIdx.x * (64 * PT);
     if (j0 >= B) return;
     const int d = ctl->d;
-    const int lane = threadIdx.x;
-    const int seg = blockIdx.y;
-    const int nrows = DIRTY ? B : ctl->m_rows;
-    const int per = (nrows + S - 1) / S;
-    const int r0 = seg * per;
-    int r1 = min(nrows, r0 + per);
-    if (DIRTY) r1 = min(r1, j0 + 64 * PT - 1);  // a version row i only matters to points j > i
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int S = gridDim.y;  // partials per point
+    const int nsub = S * CC_SCAN_WAVES;
+    const int sub = blockIdx.y * CC_SCAN_WAVES + wv;
+    // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
+    const int nrows = DIRTY ? min(B, j0 + 64 * PT - 1) : ctl->m_rows;
+    const int per = (nrows + nsub - 1) / nsub;
+    const int r0 = sub * per;
+    const int r1 = min(nrows, r0 + per);
+    const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
     const long long cursor = ctl->cursor;
     const double inv_k = ctl->inv_k;
     const bool filter = ctl->filter != 0;
 
-    __shared__ double s_c[CC_SCAN_TM][DP];
-    __shared__ double s_s[CC_SCAN_TM][DP];
-    __shared__ int s_kind[CC_SCAN_TM], s_key[CC_SCAN_TM], s_next[CC_SCAN_TM];
+    __shared__ double s_c[CC_SCAN_WAVES][CC_SCAN_TM][DP];
+    __shared__ double s_s[CC_SCAN_WAVES][CC_SCAN_TM][DP];
+    __shared__ int s_kind[CC_SCAN_WAVES][CC_SCAN_TM], s_key[CC_SCAN_WAVES][CC_SCAN_TM],
+        s_next[CC_SCAN_WAVES][CC_SCAN_TM];
 
     double p[PT][DP];
     int jj[PT];
@@ -137,8 +159,9 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
             if (DIRTY && valid[t]) cap[kd][t] = clean[(size_t)jj[t] * 4 + kd * 2 + 1].dist;
         }
 
-    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
-        const int tm = min(CC_SCAN_TM, r1 - rt);
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int rt = r0 + tt * CC_SCAN_TM;
+        const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
         __syncthreads();
         for (int e = lane; e < tm * DP; e += 64) {
             const int m = e / DP, i = e - m * DP;
@@ -149,18 +172,18 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
                 const double pr = rows.pref[g];
                 s = POW2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
             }
-            s_c[m][i] = c;
-            s_s[m][i] = s;
+            s_c[wv][m][i] = c;
+            s_s[wv][m][i] = s;
         }
         if (lane < tm) {
-            s_kind[lane] = rows.kind[rt + lane];
-            s_key[lane] = rows.key[rt + lane];
-            s_next[lane] = DIRTY ? rows.next[rt + lane] : 0;
+            s_kind[wv][lane] = rows.kind[rt + lane];
+            s_key[wv][lane] = rows.key[rt + lane];
+            s_next[wv][lane] = DIRTY ? rows.next[rt + lane] : 0;
         }
         __syncthreads();
 
         for (int m = 0; m < tm; ++m) {
-            const int kind = __builtin_amdgcn_readfirstlane(s_kind[m]);
+            const int kind = __builtin_amdgcn_readfirstlane(s_kind[wv][m]);
             if (kind == CC_KIND_DEAD) continue;
             const int rowg = rt + m;
             bool act[PT];
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
             for (int t = 0; t < PT; ++t) {
                 act[t] = valid[t];
                 if (DIRTY) {
-                    const int nx = __builtin_amdgcn_readfirstlane(s_next[m]);
+                    const int nx = __builtin_amdgcn_readfirstlane(s_next[wv][m]);
                     act[t] = act[t] && rowg < jj[t] && jj[t] <= nx;
                     const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
                     const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
@@ -193,8 +216,8 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
                 for (int q = 0; q < 4; ++q) {
                     const int i = i0 + q;
                     if (i < DP) {
-                        const double c = s_c[m][i];
-                        const double s = s_s[m][i];
+                        const double c = s_c[wv][m][i];
+                        const double s = s_s[wv][m][i];
 #pragma unroll
                         for (int t = 0; t < PT; ++t) {
                             double x = p[t][i] - c;   // mc_functions.py:37
@@ -218,7 +241,7 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
             }
             if (!alive) continue;
 
-            const int key = s_key[m];
+            const int key = s_key[wv][m];
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
                 if (!(acc[t] <= bound[t])) continue;
@@ -246,19 +269,39 @@ __global__ __launch_bounds__(64) void k_scan(const Ctl* __restrict__ ctl, const 
         }
     }
 
+    // merge the waves' candidates through LDS; wave 0 writes the workgroup's partial
+    __shared__ Cand s_m[CC_SCAN_WAVES - 1][PT][4][64];
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            s_m[wv - 1][t][0][lane] = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
+            s_m[wv - 1][t][1][lane] = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
+            s_m[wv - 1][t][2][lane] = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
+            s_m[wv - 1][t][3][lane] = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
         if (!valid[t]) continue;
+        Cand c0{bd[0][t][0], bk[0][t][0], bs[0][t][0]}, c1{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
+        Cand c2{bd[1][t][0], bk[1][t][0], bs[1][t][0]}, c3{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+#pragma unroll
+        for (int w = 0; w < CC_SCAN_WAVES - 1; ++w) {
+            cc_top2_push(c0, c1, s_m[w][t][0][lane]);
+            cc_top2_push(c0, c1, s_m[w][t][1][lane]);
+            cc_top2_push(c2, c3, s_m[w][t][2][lane]);
+            cc_top2_push(c2, c3, s_m[w][t][3][lane]);
+        }
         if (DIRTY) {
-            Cand* o = part + ((size_t)jj[t] * S + seg) * 2;
-            o[0] = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
-            o[1] = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
+            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 2;
+            o[0] = c0;
+            o[1] = c2;
         } else {
-            Cand* o = part + ((size_t)jj[t] * S + seg) * 4;
-            o[0] = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
-            o[1] = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
-            o[2] = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
-            o[3] = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 4;
+            o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
         }
     }
 }
@@ -316,17 +359,6 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
     }
     g.r2 = r2;
     return g;
-}
-
-__device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
-{
-    if (x.slot < 0) return;
-    if (a.slot < 0 || cand_less(x.dist, x.key, a.dist, a.key)) {
-        b = a;
-        a = x;
-    } else if (b.slot < 0 || cand_less(x.dist, x.key, b.dist, b.key)) {
-        b = x;
-    }
 }
 
 __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
@@ -468,8 +500,9 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->last_round = round;
-    extern __shared__ int sT[];
-    for (int i = threadIdx.x; i < B; i += blockDim.x) sT[i] = T[i];
+    extern __shared__ __attribute__((aligned(16))) int sT[];
+    const int Bpad = (B + 127) & ~127;
+    for (int i = threadIdx.x; i < Bpad; i += blockDim.x) sT[i] = (i < B) ? T[i] : -1000000;
     __syncthreads();
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
@@ -481,9 +514,14 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         }
         return;
     }
-    for (int base = 0; base < j; base += 32) {
-        const int i = base + gl;
-        if (cc_group_ballot(i < j && sT[i] == t)) return;  // an earlier point heads this chain and walks over j
+    // sT is padded to a multiple of 128 entries with a sentinel, so the 16-byte reads below stay in range
+    const int4* sT4 = reinterpret_cast<const int4*>(sT);
+    for (int base = 0; base < j; base += 128) {
+        const int i = base + gl * 4;
+        const int4 v = sT4[(base >> 2) + gl];
+        const bool m = (i < j && v.x == t) || (i + 1 < j && v.y == t) || (i + 2 < j && v.z == t) ||
+                       (i + 3 < j && v.w == t);
+        if (cc_group_ballot(m)) return;  // an earlier point heads this chain and walks over j
     }
 
     const int d = ctl->d;
@@ -504,10 +542,18 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     int cur = j;
     while (true) {
         int nx = CC_IDX_INF;
-        for (int base = cur + 1; base < B; base += 32) {
-            const int i = base + gl;
-            const unsigned m = cc_group_ballot(i < B && sT[i] == t);
-            if (m) { nx = base + __builtin_ctz(m); break; }
+        for (int base = (cur + 1) & ~127; base < B; base += 128) {
+            const int i = base + gl * 4;
+            const int4 v = sT4[(base >> 2) + gl];
+            const unsigned mm = ((i > cur && v.x == t) ? 1u : 0u) | ((i + 1 > cur && v.y == t) ? 2u : 0u) |
+                                ((i + 2 > cur && v.z == t) ? 4u : 0u) | ((i + 3 > cur && v.w == t) ? 8u : 0u);
+            const unsigned b = cc_group_ballot(mm != 0u);
+            if (b) {
+                const int l = __builtin_ctz(b);
+                const unsigned ml = __shfl(mm, l, 32);
+                nx = base + l * 4 + __builtin_ctz(ml);
+                break;
+            }
         }
         double* vcf1 = ver.cf1 + (size_t)cur * d; double* vcf2 = ver.cf2 + (size_t)cur * d;
         double* vcen = ver.cen + (size_t)cur * d; double* vpref = ver.pref + (size_t)cur * d;
