@@ -115,7 +115,7 @@ struct cc_handle {
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
     DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_w;
     DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
-    DevBuf<Cand> part, clean, dpart;
+    DevBuf<Cand> part, clean, dpart, dseed;
     DevBuf<int> T0, T1, rk;
     DevBuf<CommitRec> rec;
     DevBuf<int8_t> dpath;
@@ -239,7 +239,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_tgt.ensure(w);
-    h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4);
+    h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
@@ -454,6 +454,7 @@ int cc_online_run(cc_handle* h)
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of CC_SCAN_WAVES waves -> S partials per point
         const int S = std::max(1, h->tun.segments / CC_SCAN_WAVES);
+        const int Sd = std::max(1, S / 4);  // the dirty scan has far fewer rows per point tile
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
@@ -473,6 +474,7 @@ int cc_online_run(cc_handle* h)
         c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
         c.stat_table_rows = 0;
         c.stat_pair_rows = 0.0;
+        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
         push_ctl(h);
 
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
@@ -482,16 +484,23 @@ int cc_online_run(cc_handle* h)
         const bool timing = h->tun.time_kernels != 0;
 
         const Versions ver = versions_view(h);
-        const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
+        
         const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
         const int cblocks = (win + 7) / 8;
         const int rblocks = std::min((win * h->d + 255) / 256, 1024);
         long long done = 0;
         int m_known = c.m_rows;
+        // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
+        // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
+        const int Rmax = R;
+        int Rcur = R;
+        long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
+        long long trunc_prev = 0;
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
             const Table tab = h->tab.view();
-            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
+            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, tab.touch};
+            const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next, tab.touch};
             for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
@@ -504,15 +513,17 @@ int cc_online_run(cc_handle* h)
                     launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
                 }
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
-                                   h->part.p, h->clean.p, h->dpart.p, (const int*)nullptr, h->T0.p, h->dpath.p, S, 0);
-                for (int r = 1; r <= R; ++r) {
+                                   h->part.p, h->clean.p, h->dpart.p, (const int*)nullptr, h->T0.p, h->dpath.p, S, Sd, 0);
+                for (int r = 1; r <= Rcur; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)((win + 127) & ~127) * sizeof(int), h->stream,
                                        h->ctl.p, h->X.p, tab, ver, told, r);
-                    launch_scan<true>(h, win, vrows, h->clean.p, h->dpart.p, S, r);
+                    hipLaunchKernelGGL(k_dseed, dim3((win + 63) / 64), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                                       h->clean.p, h->dseed.p, r);
+                    launch_scan<true>(h, win, vrows, h->dseed.p, h->dpart.p, Sd, r);
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
-                                       h->part.p, h->clean.p, h->dpart.p, told, tnew, h->dpath.p, S, r);
+                                       h->part.p, h->clean.p, h->dpart.p, told, tnew, h->dpath.p, S, Sd, r);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, h->stream, h->ctl.p, tab, ver, h->T0.p, h->T1.p,
                                    h->dpath.p, h->lab_uid.p, h->lab_path.p, h->rk.p, h->rec.p);
@@ -523,6 +534,17 @@ int cc_online_run(cc_handle* h)
             pull_ctl(h);
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
+            {
+                int used = 1;
+                for (int r = 1; r <= CC_MAX_ROUNDS; ++r) {
+                    if (h->hc.round_hist[r] - hist_prev[r] > 0) used = r;
+                    hist_prev[r] = h->hc.round_hist[r];
+                }
+                const long long trunc = h->hc.stat_truncated - trunc_prev;
+                trunc_prev = h->hc.stat_truncated;
+                if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
+                else Rcur = std::max(1, std::min(Rcur, used));
+            }
         }
         HIPCHK(hipEventRecord(ev1, h->stream));
         HIPCHK(hipEventSynchronize(ev1));

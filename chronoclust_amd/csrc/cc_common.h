@@ -60,6 +60,7 @@ struct Rows {
     const int* kind;
     const int* key;
     const int* next;  // only for version rows
+    const unsigned long long* touch;  // table stamps (dirty scan prologue)
 };
 
 struct Ctl {
@@ -85,6 +86,7 @@ struct Ctl {
     long long stat_windows, stat_rounds, stat_truncated;
     long long stat_table_rows;  // sum over windows of the table rows scanned
     double stat_pair_rows;      // sum over windows of (window points x table rows)
+    long long round_hist[CC_MAX_ROUNDS + 2];  // windows by the validation round they ended in
 };
 
 __host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)

@@ -93,6 +93,15 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 #define CC_SCAN_TM 16     // MC rows per LDS tile
 #define CC_SCAN_WAVES 4   // waves per workgroup: same points, disjoint MC sub-ranges, merged through LDS
 
+// Each wave stages its own LDS tile and is the only reader of it: DS operations of one wave execute in order,
+// so a wavefront-scope fence (no workgroup barrier) is enough between filling a tile and reading it.
+#define CC_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
 // One workgroup = CC_SCAN_WAVES waves that hold the same 64*PT points in registers.  The MC rows of the launch
 // are split into gridDim.y * CC_SCAN_WAVES sub-ranges; each wave streams its sub-range through its own LDS tile
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
@@ -156,13 +165,26 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
                 bs[kd][t][r] = -1;
             }
             cap[kd][t] = CC_INF;
-            if (DIRTY && valid[t]) cap[kd][t] = clean[(size_t)jj[t] * 4 + kd * 2 + 1].dist;
         }
+    if (DIRTY) {
+        // caps and first candidates prepared once per point by k_dseed (`clean` is the seed table here)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            if (!valid[t]) continue;
+#pragma unroll
+            for (int kd = 0; kd < 2; ++kd) {
+                const Cand sd = clean[(size_t)jj[t] * 4 + kd * 2];
+                cap[kd][t] = clean[(size_t)jj[t] * 4 + kd * 2 + 1].dist;
+                bd[kd][t][0] = sd.dist; bk[kd][t][0] = sd.key; bs[kd][t][0] = sd.slot;
+            }
+        }
+    }
 
     for (int tt = 0; tt < ntiles; ++tt) {
         const int rt = r0 + tt * CC_SCAN_TM;
         const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
-        __syncthreads();
+        if (tm == 0) break;
+        CC_WAVE_SYNC();
         for (int e = lane; e < tm * DP; e += 64) {
             const int m = e / DP, i = e - m * DP;
             double c = 0.0, s = 1.0;
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
             s_key[wv][lane] = rows.key[rt + lane];
             s_next[wv][lane] = DIRTY ? rows.next[rt + lane] : 0;
         }
-        __syncthreads();
+        CC_WAVE_SYNC();
 
         for (int m = 0; m < tm; ++m) {
             const int kind = __builtin_amdgcn_readfirstlane(s_kind[wv][m]);
@@ -371,6 +393,72 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 }
 
 // ---------------------------------------------------------------------------------
+// k_dseed: per window point and kind, the cap and the first candidate of the dirty scan (one thread per point).
+// A live version only matters to point j if it beats what j already has.  If j's best snapshot candidate c1 is
+// still untouched when j arrives, that is c1 itself (cap = d1).  If c1 was touched, the live version of c1's MC
+// is itself a candidate: find it (short walk along the chain), take its exact distance as the first candidate;
+// everything else has to beat that.  Loose fallback: the snapshot's second-best distance d2.
+// seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                              Versions ver, const Cand* __restrict__ clean, Cand* __restrict__ seed,
+                                              int round)
+{
+    const int B = ctl->win_b;
+    if (B == 0) return;
+    if (ctl->fc[round - 1] >= B) return;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    const int d = ctl->d;
+    const bool filter = ctl->filter != 0;
+    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    const double* p = X + (ctl->cursor + j) * d;
+    Cand first[2] = {Cand{CC_INF, CC_IDX_INF, -1}, Cand{CC_INF, CC_IDX_INF, -1}};
+    double cap[2] = {CC_INF, CC_INF};
+    for (int kd = 0; kd < 2; ++kd) {
+        const Cand c1 = clean[(size_t)j * 4 + kd * 2];
+        if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
+        const unsigned long long tc = tab.touch[c1.slot];
+        const int head = (int)(tc & 0xFFFFFull);
+        if ((tc >> 20) != stamp || head >= j) {
+            cap[kd] = c1.dist;  // c1 is clean at j
+            continue;
+        }
+        cap[kd] = clean[(size_t)j * 4 + kd * 2 + 1].dist;
+        int v = head;
+        for (int steps = 0; ver.next[v] < j; ++steps) {
+            v = ver.next[v];
+            if (steps >= 16) { v = -1; break; }
+        }
+        if (v < 0) continue;
+        const int kv = ver.kind[v];
+        if (kv == CC_KIND_DEAD) continue;
+        double acc = 0.0;
+        for (int i = 0; i < d; ++i) {
+            double x = p[i] - ver.cen[(size_t)v * d + i];
+            x = x * x;
+            acc = acc + cc_div_pref(x, ver.pref[(size_t)v * d + i], ctl);
+        }
+        if (kv == 0 && filter) {
+            int ne1 = 0;
+            cc_tentative_radius(ver.cf1 + (size_t)v * d, ver.cf2 + (size_t)v * d, ver.w[v], p, d, ctl, nullptr, &ne1);
+            if (ne1 > ctl->pi) continue;
+        }
+        const int key = ver.key[v];
+        if (kv == 0) {
+            if (cand_less(acc, key, first[0].dist, first[0].key)) first[0] = Cand{acc, key, v};
+        } else {
+            if (cand_less(acc, key, first[1].dist, first[1].key)) first[1] = Cand{acc, key, v};
+        }
+    }
+    for (int kd = 0; kd < 2; ++kd) {
+        seed[(size_t)j * 4 + kd * 2] = first[kd];
+        seed[(size_t)j * 4 + kd * 2 + 1] = Cand{cap[kd], 0, 0};
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // k_decide: one 32-lane group per window point.  Segment partials are merged with a shuffle butterfly
 // (per-point argmin over the MC range), then the reference's decision procedure runs group-uniformly.
 // ---------------------------------------------------------------------------------
@@ -378,7 +466,7 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                 Versions ver, const Cand* __restrict__ part, Cand* __restrict__ clean,
                                                 const Cand* __restrict__ dpart, const int* __restrict__ Told,
-                                                int* __restrict__ Tnew, int8_t* __restrict__ dpath, int S, int round)
+                                                int* __restrict__ Tnew, int8_t* __restrict__ dpath, int S, int Sd, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
@@ -416,8 +504,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     Cand dv[2] = {none, none};  // best live version per kind
     if (round > 0) {
         Cand dummy = none;
-        for (int s = gl; s < S; s += 32) {
-            const Cand* q = dpart + ((size_t)j * S + s) * 2;
+        for (int s = gl; s < Sd; s += 32) {
+            const Cand* q = dpart + ((size_t)j * Sd + s) * 2;
             cc_top2_push(dv[0], dummy, q[0]);
             cc_top2_push(dv[1], dummy, q[1]);
         }
@@ -688,6 +776,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->cursor = cursor + n;
         ctl->stat_windows += 1;
         ctl->stat_rounds += r;
+        ctl->round_hist[r] += 1;
         ctl->stat_truncated += (n < B) ? 1 : 0;
         ctl->stat_table_rows += M0;
         ctl->stat_pair_rows += (double)B * (double)M0;
