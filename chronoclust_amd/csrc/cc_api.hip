@@ -105,7 +105,7 @@ struct cc_handle {
     bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
 
     // points + labels of the current call
-    DevBuf<double> X;
+    DevBuf<double> X, Xt;
     long long n_points = 0;
     DevBuf<long long> lab_uid;
     DevBuf<int8_t> lab_path;
@@ -257,10 +257,10 @@ void launch_scan_dp(cc_handle* h, dim3 grid, Rows rows, const Cand* clean, Cand*
 {
     const dim3 block(64 * CC_SCAN_WAVES);
     if (h->hc.pow2)
-        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows, clean,
                            part, round);
     else
-        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, rows, clean,
+        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows, clean,
                            part, round);
 }
 
@@ -425,6 +425,7 @@ int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d)
         int rc = set_dim(h, d);
         if (rc != CC_OK) return rc;
         h->X.ensure((size_t)n * d);
+        h->Xt.ensure((size_t)n * d);
         h->lab_uid.ensure((size_t)n);
         h->lab_path.ensure((size_t)n);
         h->n_points = n;
@@ -434,6 +435,8 @@ int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d)
         const long long tot = (long long)n * d;
         int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
         hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
+        hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
+                           h->Xt.p, (long long)n, (int)d);
         int bad = 0;
         HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -454,7 +457,7 @@ int cc_online_run(cc_handle* h)
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of CC_SCAN_WAVES waves -> S partials per point
         const int S = std::max(1, h->tun.segments / CC_SCAN_WAVES);
-        const int Sd = std::max(1, S / 4);  // the dirty scan has far fewer rows per point tile
+        const int Sd = S;
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");

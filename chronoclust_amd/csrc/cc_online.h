@@ -108,7 +108,8 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
 template <int DP, int PT, bool POW2, bool DIRTY>
 __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restrict__ ctl,
-                                                             const double* __restrict__ X, Rows rows,
+                                                             const double* __restrict__ X,
+                                                             const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
                                                              Cand* __restrict__ part, int round)
 {
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
     const int r1 = min(nrows, r0 + per);
     const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
     const long long cursor = ctl->cursor;
+    const size_t n_pts = (size_t)ctl->n_points;
     const double inv_k = ctl->inv_k;
     const bool filter = ctl->filter != 0;
 
@@ -145,9 +147,10 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
     for (int t = 0; t < PT; ++t) {
         jj[t] = j0 + t * 64 + lane;
         valid[t] = jj[t] < B;
-        const double* xp = X + (cursor + (valid[t] ? jj[t] : 0)) * d;
+        // Xt is the dimension-major copy of the points: consecutive lanes read consecutive doubles
+        const double* xp = Xt + cursor + (valid[t] ? jj[t] : 0);
 #pragma unroll
-        for (int i = 0; i < DP; ++i) p[t][i] = (valid[t] && i < d) ? xp[i] : 0.0;
+        for (int i = 0; i < DP; ++i) p[t][i] = (valid[t] && i < d) ? xp[(size_t)i * n_pts] : 0.0;
     }
 
     // running best-two per kind and point: [kind][pt][rank]
@@ -204,57 +207,77 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
         }
         CC_WAVE_SYNC();
 
-        for (int m = 0; m < tm; ++m) {
-            const int kind = __builtin_amdgcn_readfirstlane(s_kind[wv][m]);
-            if (kind == CC_KIND_DEAD) continue;
-            const int rowg = rt + m;
-            bool act[PT];
-            double bound[PT];
-            bool anyact = false;
+        // The dirty scan (few waves, early exit after 4 dimensions) takes two MC rows per iteration: two
+        // independent accumulation chains hide each other's latency.  The clean scan mostly runs rows to the end,
+        // where pairing only adds work, and takes one.
+        constexpr bool RB2 = DIRTY;
+        for (int m = 0; m < tm; m += (RB2 ? 2 : 1)) {
+            const int kindA = __builtin_amdgcn_readfirstlane(s_kind[wv][m]);
+            const int kindB = (RB2 && m + 1 < tm) ? __builtin_amdgcn_readfirstlane(s_kind[wv][m + 1]) : CC_KIND_DEAD;
+            double boundA[PT], boundB[PT];
+            auto row_bounds = [&](int mm, int kind, double (&bound)[PT]) -> bool {
+                if (kind == CC_KIND_DEAD) {
 #pragma unroll
-            for (int t = 0; t < PT; ++t) {
-                act[t] = valid[t];
-                if (DIRTY) {
-                    const int nx = __builtin_amdgcn_readfirstlane(s_next[wv][m]);
-                    act[t] = act[t] && rowg < jj[t] && jj[t] <= nx;
-                    const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
-                    const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
-                    bound[t] = b1 < cp ? b1 : cp;
-                } else {
-                    bound[t] = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
+                    for (int t = 0; t < PT; ++t) bound[t] = -1.0;
+                    return false;
                 }
-                if (!act[t]) bound[t] = -1.0;
-                anyact = anyact || act[t];
-            }
-            if (__builtin_amdgcn_ballot_w64(anyact) == 0ull) continue;
-
-            double acc[PT];
+                const int rowg = rt + mm;
+                bool anyact = false;
 #pragma unroll
-            for (int t = 0; t < PT; ++t) acc[t] = 0.0;
+                for (int t = 0; t < PT; ++t) {
+                    bool a = valid[t];
+                    if (DIRTY) {
+                        const int nx = __builtin_amdgcn_readfirstlane(s_next[wv][mm]);
+                        a = a && rowg < jj[t] && jj[t] <= nx;
+                        const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
+                        const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
+                        bound[t] = b1 < cp ? b1 : cp;
+                    } else {
+                        bound[t] = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
+                    }
+                    if (!a) bound[t] = -1.0;
+                    anyact = anyact || a;
+                }
+                return __builtin_amdgcn_ballot_w64(anyact) != 0ull;
+            };
+            const bool liveA = row_bounds(m, kindA, boundA);
+            const bool liveB = RB2 ? row_bounds(m + 1, kindB, boundB) : false;
+            if (!liveA && !liveB) continue;
+
+            double accA[PT], accB[PT];
+#pragma unroll
+            for (int t = 0; t < PT; ++t) { accA[t] = 0.0; accB[t] = 0.0; }
             bool alive = true;
+            const int mB = (m + 1 < CC_SCAN_TM) ? m + 1 : m;
 #pragma unroll
             for (int i0 = 0; i0 < DP; i0 += 4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int i = i0 + q;
                     if (i < DP) {
-                        const double c = s_c[wv][m][i];
-                        const double s = s_s[wv][m][i];
+                        const double cA = s_c[wv][m][i], sA = s_s[wv][m][i];
+                        const double cB = s_c[wv][mB][i], sB = s_s[wv][mB][i];
 #pragma unroll
                         for (int t = 0; t < PT; ++t) {
-                            double x = p[t][i] - c;   // mc_functions.py:37
+                            double x = p[t][i] - cA;  // mc_functions.py:37
                             x = x * x;                // :38
-                            x = POW2 ? x * s : x / s; // :39
-                            acc[t] = acc[t] + x;      // :41, left to right
+                            x = POW2 ? x * sA : x / sA; // :39
+                            accA[t] = accA[t] + x;    // :41, left to right
+                            if (RB2) {
+                                double y = p[t][i] - cB;
+                                y = y * y;
+                                y = POW2 ? y * sB : y / sB;
+                                accB[t] = accB[t] + y;
+                            }
                         }
                     }
                 }
                 if (i0 + 4 < DP) {
-                    // terms are >= 0: once every point of the wave is past its bound this MC cannot
-                    // enter any candidate list, whatever the remaining dimensions add
+                    // terms are >= 0: once every point of the wave is past its bound for both rows, neither MC
+                    // can enter any candidate list, whatever the remaining dimensions add
                     bool q = false;
 #pragma unroll
-                    for (int t = 0; t < PT; ++t) q = q || (acc[t] <= bound[t]);
+                    for (int t = 0; t < PT; ++t) q = q || (accA[t] <= boundA[t]) || (RB2 && accB[t] <= boundB[t]);
                     if (__builtin_amdgcn_ballot_w64(q) == 0ull) {
                         alive = false;
                         break;
@@ -263,31 +286,36 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
             }
             if (!alive) continue;
 
-            const int key = s_key[wv][m];
+            auto insert_row = [&](int mm, int kind, const double (&acc)[PT], const double (&bound)[PT]) {
+                const int rowg = rt + mm;
+                const int key = s_key[wv][mm];
 #pragma unroll
-            for (int t = 0; t < PT; ++t) {
-                if (!(acc[t] <= bound[t])) continue;
-                auto consider = [&](auto KC) {
-                    constexpr int K = decltype(KC)::value;
-                    constexpr int R = DIRTY ? 0 : 1;  // rank that a newcomer has to beat
-                    if (!cand_less(acc[t], key, bd[K][t][R], bk[K][t][R])) return;
-                    if (K == 0 && filter) {
-                        // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
-                        int ne1 = 0;
-                        cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d, rows.w[rowg],
-                                            X + (cursor + jj[t]) * d, d, ctl, nullptr, &ne1);
-                        if (ne1 > ctl->pi) return;
-                    }
-                    if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
-                        bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
-                        bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowg;
-                    } else {
-                        bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowg;
-                    }
-                };
-                if (kind == 0) consider(std::integral_constant<int, 0>{});
-                else consider(std::integral_constant<int, 1>{});
-            }
+                for (int t = 0; t < PT; ++t) {
+                    if (!(acc[t] <= bound[t])) continue;
+                    auto consider = [&](auto KC) {
+                        constexpr int K = decltype(KC)::value;
+                        constexpr int R = DIRTY ? 0 : 1;  // rank that a newcomer has to beat
+                        if (!cand_less(acc[t], key, bd[K][t][R], bk[K][t][R])) return;
+                        if (K == 0 && filter) {
+                            // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                            int ne1 = 0;
+                            cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
+                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, ctl, nullptr, &ne1);
+                            if (ne1 > ctl->pi) return;
+                        }
+                        if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
+                            bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
+                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowg;
+                        } else {
+                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowg;
+                        }
+                    };
+                    if (kind == 0) consider(std::integral_constant<int, 0>{});
+                    else consider(std::integral_constant<int, 1>{});
+                }
+            };
+            if (liveA) insert_row(m, kindA, accA, boundA);
+            if (RB2 && liveB) insert_row(m + 1, kindB, accB, boundB);
         }
     }
 
@@ -822,6 +850,16 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
             if (t >= M0) tab.uid[row] = rec->oid0 + (rk[c] & 0xFFFF);
         }
     }
+}
+
+// dimension-major copy of the points for the scan's coalesced loads: xt[i * n + r] = x[r * d + i]
+__global__ void k_transpose_points(const double* __restrict__ x, double* __restrict__ xt, long long n, int d)
+{
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * d) return;
+    const long long r = e / d;
+    const int i = (int)(e - r * d);
+    xt[(size_t)i * n + r] = x[e];
 }
 
 // NaN / Inf check of the uploaded points (cc_points_upload)
