@@ -66,9 +66,8 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from chronoclust_amd import multi
+    rank, world, local_rank = multi.rank_info()
     import torch
     dist = None
     if world > 1:
@@ -78,7 +77,7 @@ def main():
 
     from chronoclust_amd import _lib
     n, d, g = args.points, args.dim, args.blobs
-    X = make_blobs(42 + rank, n, d, g)
+    X = make_blobs(multi.stream_seed(42, rank), n, d, g)
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
     h.set_tuning(window=args.window, rounds=args.rounds, segments=args.segments,
@@ -115,10 +114,7 @@ def main():
         online_ms += s["run_ms"]
     sync()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda")
     uid, _ = h.labels_download()
 
     if rank != 0:
@@ -128,7 +124,7 @@ def main():
 
     out = {
         "metric": "points clustered/sec (20-dim)" if d == 20 else "points clustered/sec (%d-dim)" % d,
-        "value": world * n * args.steps / elapsed,
+        "value": multi.whole_job_rate(n, args.steps, world, elapsed),
         "unit": "points/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -162,6 +158,17 @@ def main():
                                          "frac": 4.0 * pair_dims / secs / 1e12 / FP64_VALU_PEAK_TOPS,
                                          "note": "4 non-FMA fp64 ops per (point, microcluster, dim); brute-force "
                                                  "count, the kernel's exact early exit skips part of it"}}
+    if "roofline" in out:
+        # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
+        # separate runs, profiles/r01_pmc_traffic.json); only quoted when it was measured on this workload shape
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            if (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
+                out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = pmc["note"]
+        except (OSError, KeyError, ValueError):
+            pass
     if world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
         m = min(args.cpu_sample, n)

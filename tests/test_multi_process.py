@@ -1,0 +1,58 @@
+"""world_size-2 gloo tests (CPU) of the N > 1 path of bench.py: replicas only, one stream per rank, whole-job
+rate = units of all ranks / max-over-ranks time (chronoclust_amd/multi.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from chronoclust_amd import multi
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        r, w, lr = multi.rank_info()
+        assert (r, w, lr) == (rank, world, rank)
+        import bench
+        # each rank has its own stream: different seeds give different data of the same shape
+        X = bench.make_blobs(multi.stream_seed(42, rank), 2000, 5, 10)
+        t = torch.tensor([float(X.sum())], dtype=torch.float64)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        assert len({float(g.item()) for g in gathered}) == world
+        dist.barrier()
+        elapsed = 1.0 + rank  # rank 1 is the slow one
+        worst = multi.max_over_ranks(elapsed, dist)
+        assert worst == float(world)
+        out[rank] = multi.whole_job_rate(1000, 3, world, worst)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_replicas_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        assert out[0] == out[1] == pytest.approx(2 * 1000 * 3 / 2.0)
+
+
+def test_single_process_defaults():
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    assert multi.rank_info() == (0, 1, 0)
+    assert multi.max_over_ranks(1.5, None) == 1.5
