@@ -91,7 +91,7 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 // ---------------------------------------------------------------------------------
 
 #define CC_SCAN_TM 16     // MC rows per LDS tile
-#define CC_SCAN_WAVES 4   // waves per workgroup: same points, disjoint MC sub-ranges, merged through LDS
+// waves per workgroup (template parameter NW): same points, disjoint MC sub-ranges, merged through LDS
 
 // Each wave stages its own LDS tile and is the only reader of it: DS operations of one wave execute in order,
 // so a wavefront-scope fence (no workgroup barrier) is enough between filling a tile and reading it.
@@ -102,12 +102,12 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
     } while (0)
 
-// One workgroup = CC_SCAN_WAVES waves that hold the same 64*PT points in registers.  The MC rows of the launch
-// are split into gridDim.y * CC_SCAN_WAVES sub-ranges; each wave streams its sub-range through its own LDS tile
+// One workgroup = NW waves that hold the same 64*PT points in registers.  The MC rows of the launch
+// are split into gridDim.y * NW sub-ranges; each wave streams its sub-range through its own LDS tile
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
-template <int DP, int PT, bool POW2, bool DIRTY>
-__global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restrict__ ctl,
+template <int DP, int PT, bool POW2, bool DIRTY, int NW>
+__global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int S = gridDim.y;  // partials per point
-    const int nsub = S * CC_SCAN_WAVES;
-    const int sub = blockIdx.y * CC_SCAN_WAVES + wv;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
     // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
     const int nrows = DIRTY ? min(B, j0 + 64 * PT - 1) : ctl->m_rows;
     const int per = (nrows + nsub - 1) / nsub;
@@ -135,10 +135,17 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
     const double inv_k = ctl->inv_k;
     const bool filter = ctl->filter != 0;
 
-    __shared__ double s_c[CC_SCAN_WAVES][CC_SCAN_TM][DP];
-    __shared__ double s_s[CC_SCAN_WAVES][CC_SCAN_TM][DP];
-    __shared__ int s_kind[CC_SCAN_WAVES][CC_SCAN_TM], s_key[CC_SCAN_WAVES][CC_SCAN_TM],
-        s_next[CC_SCAN_WAVES][CC_SCAN_TM];
+    // LDS: per-wave tiles while scanning, then (same bytes) the candidate exchange of the final merge
+    constexpr int TILE_DOUBLES = NW * CC_SCAN_TM * DP;
+    constexpr int TILE_BYTES = TILE_DOUBLES * 16 + NW * CC_SCAN_TM * 12;
+    constexpr int MERGE_BYTES = (NW - 1) * PT * 4 * 64 * (int)sizeof(Cand);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
+    double* const s_c_base = reinterpret_cast<double*>(smem) + (size_t)wv * CC_SCAN_TM * DP;
+    double* const s_s_base = reinterpret_cast<double*>(smem) + TILE_DOUBLES + (size_t)wv * CC_SCAN_TM * DP;
+    int* const s_int = reinterpret_cast<int*>(smem + (size_t)TILE_DOUBLES * 16) + wv * CC_SCAN_TM * 3;
+    int* const s_kind_w = s_int;
+    int* const s_key_w = s_int + CC_SCAN_TM;
+    int* const s_next_w = s_int + 2 * CC_SCAN_TM;
 
     double p[PT][DP];
     int jj[PT];
@@ -197,13 +204,13 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
                 const double pr = rows.pref[g];
                 s = POW2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
             }
-            s_c[wv][m][i] = c;
-            s_s[wv][m][i] = s;
+            s_c_base[m * DP + i] = c;
+            s_s_base[m * DP + i] = s;
         }
         if (lane < tm) {
-            s_kind[wv][lane] = rows.kind[rt + lane];
-            s_key[wv][lane] = rows.key[rt + lane];
-            s_next[wv][lane] = DIRTY ? rows.next[rt + lane] : 0;
+            s_kind_w[lane] = rows.kind[rt + lane];
+            s_key_w[lane] = rows.key[rt + lane];
+            s_next_w[lane] = DIRTY ? rows.next[rt + lane] : 0;
         }
         CC_WAVE_SYNC();
 
@@ -212,8 +219,8 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
         // where pairing only adds work, and takes one.
         constexpr bool RB2 = DIRTY;
         for (int m = 0; m < tm; m += (RB2 ? 2 : 1)) {
-            const int kindA = __builtin_amdgcn_readfirstlane(s_kind[wv][m]);
-            const int kindB = (RB2 && m + 1 < tm) ? __builtin_amdgcn_readfirstlane(s_kind[wv][m + 1]) : CC_KIND_DEAD;
+            const int kindA = __builtin_amdgcn_readfirstlane(s_kind_w[m]);
+            const int kindB = (RB2 && m + 1 < tm) ? __builtin_amdgcn_readfirstlane(s_kind_w[m + 1]) : CC_KIND_DEAD;
             double boundA[PT], boundB[PT];
             auto row_bounds = [&](int mm, int kind, double (&bound)[PT]) -> bool {
                 if (kind == CC_KIND_DEAD) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
                 for (int t = 0; t < PT; ++t) {
                     bool a = valid[t];
                     if (DIRTY) {
-                        const int nx = __builtin_amdgcn_readfirstlane(s_next[wv][mm]);
+                        const int nx = __builtin_amdgcn_readfirstlane(s_next_w[mm]);
                         a = a && rowg < jj[t] && jj[t] <= nx;
                         const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
                         const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
@@ -255,8 +262,8 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
                 for (int q = 0; q < 4; ++q) {
                     const int i = i0 + q;
                     if (i < DP) {
-                        const double cA = s_c[wv][m][i], sA = s_s[wv][m][i];
-                        const double cB = s_c[wv][mB][i], sB = s_s[wv][mB][i];
+                        const double cA = s_c_base[m * DP + i], sA = s_s_base[m * DP + i];
+                        const double cB = s_c_base[mB * DP + i], sB = s_s_base[mB * DP + i];
 #pragma unroll
                         for (int t = 0; t < PT; ++t) {
                             double x = p[t][i] - cA;  // mc_functions.py:37
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
 
             auto insert_row = [&](int mm, int kind, const double (&acc)[PT], const double (&bound)[PT]) {
                 const int rowg = rt + mm;
-                const int key = s_key[wv][mm];
+                const int key = s_key_w[mm];
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
                     if (!(acc[t] <= bound[t])) continue;
@@ -320,15 +327,16 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
     }
 
     // merge the waves' candidates through LDS; wave 0 writes the workgroup's partial
-    __shared__ Cand s_m[CC_SCAN_WAVES - 1][PT][4][64];
-    __syncthreads();
+    Cand* const s_m = reinterpret_cast<Cand*>(smem);  // [NW - 1][PT][4][64], reuses the tile bytes
+    auto s_m_at = [&](int w, int t, int c) -> Cand& { return s_m[((w * PT + t) * 4 + c) * 64 + lane]; };
+    __syncthreads();  // every wave is done with its tile
     if (wv > 0) {
 #pragma unroll
         for (int t = 0; t < PT; ++t) {
-            s_m[wv - 1][t][0][lane] = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
-            s_m[wv - 1][t][1][lane] = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
-            s_m[wv - 1][t][2][lane] = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
-            s_m[wv - 1][t][3][lane] = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+            s_m_at(wv - 1, t, 0) = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
+            s_m_at(wv - 1, t, 1) = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
+            s_m_at(wv - 1, t, 2) = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
+            s_m_at(wv - 1, t, 3) = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
         }
     }
     __syncthreads();
@@ -339,11 +347,11 @@ __global__ __launch_bounds__(64 * CC_SCAN_WAVES) void k_scan(const Ctl* __restri
         Cand c0{bd[0][t][0], bk[0][t][0], bs[0][t][0]}, c1{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
         Cand c2{bd[1][t][0], bk[1][t][0], bs[1][t][0]}, c3{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
 #pragma unroll
-        for (int w = 0; w < CC_SCAN_WAVES - 1; ++w) {
-            cc_top2_push(c0, c1, s_m[w][t][0][lane]);
-            cc_top2_push(c0, c1, s_m[w][t][1][lane]);
-            cc_top2_push(c2, c3, s_m[w][t][2][lane]);
-            cc_top2_push(c2, c3, s_m[w][t][3][lane]);
+        for (int w = 0; w < NW - 1; ++w) {
+            cc_top2_push(c0, c1, s_m_at(w, t, 0));
+            cc_top2_push(c0, c1, s_m_at(w, t, 1));
+            cc_top2_push(c2, c3, s_m_at(w, t, 2));
+            cc_top2_push(c2, c3, s_m_at(w, t, 3));
         }
         if (DIRTY) {
             Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 2;
