@@ -30,6 +30,16 @@
 #include "cc_common.h"
 
 #define CC_INF (__builtin_huge_val())
+#define CC_GROUP_THREADS 256  // workgroup size of the one-32-lane-group-per-point kernels (k_decide, k_chain)
+
+// Each wave stages its own LDS tile and is the only reader of it: DS operations of one wave execute in order,
+// so a wavefront-scope fence (no workgroup barrier) is enough between filling a tile and reading it.
+#define CC_WAVE_SYNC()                                          \
+    do {                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 
 // ---------------------------------------------------------------------------------
 // per-MC arithmetic (utilities/mc_functions.py)
@@ -75,15 +85,18 @@ __device__ inline double cc_tentative_radius(const double* bcf1, const double* b
     return r2;
 }
 
-__device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
+// insert x into the ordered pair (a, b); field-wise selects keep the structs in registers
+__device__ __forceinline__ void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 {
-    if (x.slot < 0) return;
-    if (a.slot < 0 || cand_less(x.dist, x.key, a.dist, a.key)) {
-        b = a;
-        a = x;
-    } else if (b.slot < 0 || cand_less(x.dist, x.key, b.dist, b.key)) {
-        b = x;
-    }
+    const bool ok = x.slot >= 0;
+    const bool beats_a = ok && (a.slot < 0 || cand_less(x.dist, x.key, a.dist, a.key));
+    const bool beats_b = ok && !beats_a && (b.slot < 0 || cand_less(x.dist, x.key, b.dist, b.key));
+    b.dist = beats_a ? a.dist : (beats_b ? x.dist : b.dist);
+    b.key = beats_a ? a.key : (beats_b ? x.key : b.key);
+    b.slot = beats_a ? a.slot : (beats_b ? x.slot : b.slot);
+    a.dist = beats_a ? x.dist : a.dist;
+    a.key = beats_a ? x.key : a.key;
+    a.slot = beats_a ? x.slot : a.slot;
 }
 
 // ---------------------------------------------------------------------------------
@@ -93,14 +106,6 @@ __device__ inline void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 #define CC_SCAN_TM 16     // MC rows per LDS tile
 // waves per workgroup (template parameter NW): same points, disjoint MC sub-ranges, merged through LDS
 
-// Each wave stages its own LDS tile and is the only reader of it: DS operations of one wave execute in order,
-// so a wavefront-scope fence (no workgroup barrier) is enough between filling a tile and reading it.
-#define CC_WAVE_SYNC()                                          \
-    do {                                                        \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
-        __builtin_amdgcn_wave_barrier();                        \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
-    } while (0)
 
 // One workgroup = NW waves that hold the same 64*PT points in registers.  The MC rows of the launch
 // are split into gridDim.y * NW sub-ranges; each wave streams its sub-range through its own LDS tile
@@ -410,11 +415,16 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
     }
     g.gt1 = __builtin_popcount(cc_group_ballot(gt[0])) + __builtin_popcount(cc_group_ballot(gt[1]));
     g.ne1 = __builtin_popcount(cc_group_ballot(ne[0])) + __builtin_popcount(cc_group_ballot(ne[1]));
+    // ordered sum over dimensions: the terms go through LDS (one 64-double row per group) and every lane adds
+    // them left to right from broadcast reads; the wave owns its rows, so a wavefront fence is enough
+    __shared__ double s_term[(CC_GROUP_THREADS / 32)][64];
+    double* const row = s_term[(threadIdx.x >> 5) % (CC_GROUP_THREADS / 32)];
+    CC_WAVE_SYNC();
+    row[gl] = term[0];
+    row[gl + 32] = term[1];
+    CC_WAVE_SYNC();
     double r2 = 0.0;
-    for (int i = 0; i < d; ++i) {
-        const double t = __shfl(i < 32 ? term[0] : term[1], i & 31, 32);
-        r2 = r2 + t;  // mc_functions.py:54, left to right
-    }
+    for (int i = 0; i < d; ++i) r2 = r2 + row[i];  // mc_functions.py:54, left to right
     g.r2 = r2;
     return g;
 }
@@ -513,42 +523,44 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const int d = ctl->d;
     const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
 
-    Cand c[4];
+    // candidates are kept in named scalars (no runtime-indexed arrays: those would live in scratch memory)
+    Cand p1 = none, p2 = none, o1 = none, o2 = none;  // best two pcore / outlier snapshot candidates
     if (round == 0) {
-        c[0] = c[1] = c[2] = c[3] = none;
         for (int s = gl; s < S; s += 32) {
             const Cand* q = part + ((size_t)j * S + s) * 4;
-            cc_top2_push(c[0], c[1], q[0]);
-            cc_top2_push(c[0], c[1], q[1]);
-            cc_top2_push(c[2], c[3], q[2]);
-            cc_top2_push(c[2], c[3], q[3]);
+            cc_top2_push(p1, p2, q[0]);
+            cc_top2_push(p1, p2, q[1]);
+            cc_top2_push(o1, o2, q[2]);
+            cc_top2_push(o1, o2, q[3]);
         }
         for (int off = 16; off >= 1; off >>= 1) {
-            Cand o[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = cc_shfl_xor_cand(c[i], off);
-            cc_top2_push(c[0], c[1], o[0]);
-            cc_top2_push(c[0], c[1], o[1]);
-            cc_top2_push(c[2], c[3], o[2]);
-            cc_top2_push(c[2], c[3], o[3]);
+            const Cand a0 = cc_shfl_xor_cand(p1, off), a1 = cc_shfl_xor_cand(p2, off);
+            const Cand a2 = cc_shfl_xor_cand(o1, off), a3 = cc_shfl_xor_cand(o2, off);
+            cc_top2_push(p1, p2, a0);
+            cc_top2_push(p1, p2, a1);
+            cc_top2_push(o1, o2, a2);
+            cc_top2_push(o1, o2, a3);
         }
-        if (gl < 4) clean[(size_t)j * 4 + gl] = c[gl == 0 ? 0 : gl == 1 ? 1 : gl == 2 ? 2 : 3];
+        if (gl == 0) {
+            Cand* out = clean + (size_t)j * 4;
+            out[0] = p1; out[1] = p2; out[2] = o1; out[3] = o2;
+        }
     } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) c[i] = clean[(size_t)j * 4 + i];
+        const Cand* in = clean + (size_t)j * 4;
+        p1 = in[0]; p2 = in[1]; o1 = in[2]; o2 = in[3];
     }
-    Cand dv[2] = {none, none};  // best live version per kind
+    Cand dvp = none, dvo = none;  // best live version per kind
     if (round > 0) {
         Cand dummy = none;
         for (int s = gl; s < Sd; s += 32) {
             const Cand* q = dpart + ((size_t)j * Sd + s) * 2;
-            cc_top2_push(dv[0], dummy, q[0]);
-            cc_top2_push(dv[1], dummy, q[1]);
+            cc_top2_push(dvp, dummy, q[0]);
+            cc_top2_push(dvo, dummy, q[1]);
         }
         for (int off = 16; off >= 1; off >>= 1) {
-            const Cand o0 = cc_shfl_xor_cand(dv[0], off), o1 = cc_shfl_xor_cand(dv[1], off);
-            cc_top2_push(dv[0], dummy, o0);
-            cc_top2_push(dv[1], dummy, o1);
+            const Cand b0 = cc_shfl_xor_cand(dvp, off), b1 = cc_shfl_xor_cand(dvo, off);
+            cc_top2_push(dvp, dummy, b0);
+            cc_top2_push(dvo, dummy, b1);
         }
     }
 
@@ -563,8 +575,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const double* p = X + (ctl->cursor + j) * d;
     int T = -1;
     int path = 2;
-    for (int stage = 0; stage < 2 && T == -1; ++stage) {
-        const Cand c1 = c[stage * 2], c2 = c[stage * 2 + 1], dd = dv[stage];
+    // one stage of the reference's procedure: stage 0 = _add_to_pcore (hddstream.py:288-343), 1 = _add_to_outlier
+    auto run_stage = [&](const Cand& c1, const Cand& c2, const Cand& dd, int stage) {
         int state;  // 0: no clean candidate, 1: cb is the exact clean best, 2: cb only bounds the clean best from below
         Cand cb = none;
         if (c1.slot < 0) state = 0;
@@ -582,9 +594,9 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             else { wkind = 1; wrow = cb.slot; }
         } else {
             if (dd.slot >= 0 && cand_less(dd.dist, dd.key, cb.dist, cb.key)) { wkind = 2; wrow = dd.slot; }
-            else { T = CC_T_UNKNOWN; break; }
+            else { T = CC_T_UNKNOWN; return; }
         }
-        if (wkind == 0) continue;
+        if (wkind == 0) return;
         const double *bcf1, *bcf2;
         double bw;
         int target;
@@ -600,7 +612,9 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             T = target;
             path = stage;
         }
-    }
+    };
+    run_stage(p1, p2, dvp, 0);
+    if (T == -1) run_stage(o1, o2, dvo, 1);
     if (T == -1) {  // hddstream.py:434-462: new outlier MC, provisional id = rows-at-window-start + j
         T = M0 + j;
         path = 2;
@@ -640,11 +654,18 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     }
     // sT is padded to a multiple of 128 entries with a sentinel, so the 16-byte reads below stay in range
     const int4* sT4 = reinterpret_cast<const int4*>(sT);
-    for (int base = 0; base < j; base += 128) {
-        const int i = base + gl * 4;
-        const int4 v = sT4[(base >> 2) + gl];
-        const bool m = (i < j && v.x == t) || (i + 1 < j && v.y == t) || (i + 2 < j && v.z == t) ||
-                       (i + 3 < j && v.w == t);
+    for (int base = 0; base < j; base += 512) {  // 4 x 128 entries per ballot (reads past j are masked by i < j)
+        bool m = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int b2 = base + u * 128;
+            if (b2 < Bpad) {
+                const int i = b2 + gl * 4;
+                const int4 v = sT4[(b2 >> 2) + gl];
+                m = m || (i < j && v.x == t) || (i + 1 < j && v.y == t) || (i + 2 < j && v.z == t) ||
+                    (i + 3 < j && v.w == t);
+            }
+        }
         if (cc_group_ballot(m)) return;  // an earlier point heads this chain and walks over j
     }
 
