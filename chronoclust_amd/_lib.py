@@ -26,7 +26,8 @@ class CcParams(C.Structure):
 
 class CcTuning(C.Structure):
     _fields_ = [("window", C.c_int32), ("rounds", C.c_int32), ("segments", C.c_int32),
-                ("windows_per_sync", C.c_int32), ("time_kernels", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("windows_per_sync", C.c_int32), ("time_kernels", C.c_int32), ("dirty_segments", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class CcStats(C.Structure):
@@ -130,8 +131,8 @@ class Handle(object):
             raise exc("%s: %s" % (_ERRORS.get(rc, rc), msg.decode() if msg else ""))
         return rc
 
-    def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0):
-        t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels)
+    def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0, dirty_segments=0):
+        t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels, dirty_segments)
         self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
 
     def reset(self):

@@ -385,6 +385,7 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     if (t->segments > 0) h->tun.segments = std::min(t->segments, 1024);
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
     h->tun.time_kernels = t->time_kernels;
+    if (t->dirty_segments > 0) h->tun.dirty_segments = std::min(t->dirty_segments, 1024);
     return CC_OK;
 }
 
@@ -466,12 +467,12 @@ int cc_online_run(cc_handle* h)
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
         const int S = std::max(1, h->tun.segments / scan_waves_for_dim(h->d));
-        const int Sd = S;
+        const int Sd = h->tun.dirty_segments > 0 ? std::max(1, h->tun.dirty_segments / scan_waves_for_dim(h->d)) : S;
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
         refresh_ctl_params(h);
-        ensure_window_buffers(h, win, S);
+        ensure_window_buffers(h, win, std::max(S, Sd));
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * h->tun.windows_per_sync + 1);
 
         Ctl& c = h->hc;

@@ -640,7 +640,33 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->last_round = round;
     extern __shared__ __attribute__((aligned(16))) int sT[];
     const int Bpad = (B + 127) & ~127;
-    for (int i = threadIdx.x; i < Bpad; i += blockDim.x) sT[i] = (i < B) ? T[i] : -1000000;
+    {
+        // 16-byte loads, four in flight per thread before the first LDS store (T is 16-byte aligned, Bpad % 4 == 0)
+        const int4* T4 = reinterpret_cast<const int4*>(T);
+        int4* s4 = reinterpret_cast<int4*>(sT);
+        const int n4 = Bpad >> 2;
+        for (int base = 0; base < n4; base += 4 * (int)blockDim.x) {
+            int4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + u * (int)blockDim.x + (int)threadIdx.x;
+                v[u] = make_int4(-1000000, -1000000, -1000000, -1000000);
+                if (q < n4) {
+                    if (q * 4 + 3 < B) v[u] = T4[q];
+                    else {
+                        if (q * 4 + 0 < B) v[u].x = T[q * 4 + 0];
+                        if (q * 4 + 1 < B) v[u].y = T[q * 4 + 1];
+                        if (q * 4 + 2 < B) v[u].z = T[q * 4 + 2];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = base + u * (int)blockDim.x + (int)threadIdx.x;
+                if (q < n4) s4[q] = v[u];
+            }
+        }
+    }
     __syncthreads();
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);

@@ -76,7 +76,8 @@ typedef struct cc_tuning {
     int32_t segments;        /* microcluster-range segments per point tile       */
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */
     int32_t time_kernels;    /* 1: bracket every scan launch with HIP events     */
-    int32_t reserved[3];
+    int32_t dirty_segments;  /* sub-ranges of the version-row scan (0: = segments)*/
+    int32_t reserved[2];
 } cc_tuning;
 
 typedef struct cc_stats {

@@ -24,8 +24,9 @@ if __name__ == "__main__":
     wins = [int(x) for x in os.environ.get("WINS", "512,1024,2048,4096").split(",")]
     segs = [int(x) for x in os.environ.get("SEGS", "32,64,128").split(",")]
     rnds = [int(x) for x in os.environ.get("RNDS", "2,3").split(",")]
-    for win, seg, rd in itertools.product(wins, segs, rnds):
-        h.set_tuning(window=win, segments=seg, rounds=rd, time_kernels=int(os.environ.get("TK", "0")))
+    dsegs = [int(x) for x in os.environ.get("DSEGS", "0").split(",")]
+    for win, seg, rd, dseg in itertools.product(wins, segs, rnds, dsegs):
+        h.set_tuning(window=win, segments=seg, rounds=rd, time_kernels=int(os.environ.get("TK", "0")), dirty_segments=dseg)
         best = None
         for rep in range(2):
             h.reset()
@@ -38,5 +39,5 @@ if __name__ == "__main__":
         if ref is None:
             ref = uid
         same = bool(np.array_equal(ref, uid))
-        print("win %5d seg %4d rounds %d : %7.1f ms  %6.2f Mpts/s  windows %5d rounds %5d trunc %4d scan_ms %.1f same_labels %s" % (
-            win, seg, rd, best * 1e3, n / best / 1e6, s["windows"], s["rounds"], s["truncated"], s["scan_ms"], same), flush=True)
+        print("win %5d seg %4d dseg %4d rounds %d : %7.1f ms  %6.2f Mpts/s  windows %5d rounds %5d trunc %4d scan_ms %.1f same_labels %s" % (
+            win, seg, dseg, rd, best * 1e3, n / best / 1e6, s["windows"], s["rounds"], s["truncated"], s["scan_ms"], same), flush=True)
