@@ -131,8 +131,10 @@ class Handle(object):
             raise exc("%s: %s" % (_ERRORS.get(rc, rc), msg.decode() if msg else ""))
         return rc
 
-    def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0, dirty_segments=0):
+    def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0, dirty_segments=0,
+                   points_per_lane=0):
         t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels, dirty_segments)
+        t.reserved[0] = int(points_per_lane)
         self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
 
     def reset(self):

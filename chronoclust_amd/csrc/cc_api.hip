@@ -262,7 +262,21 @@ template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part, int S, int round)
 {
     constexpr int NW = ScanWaves<DP>::value;
-    const dim3 grid((win + 63) / 64, S), block(64 * NW);
+    // points per lane: 2 for the clean scan at small d (more independent work per staged MC row), else 1
+    constexpr int PT = (!DIRTY && DP <= 20) ? 2 : 1;
+    const bool pt2 = PT == 2 && h->tun.reserved[0] == 2;  // measured 10 % slower on C2: off unless asked for
+    const dim3 block(64 * NW);
+    if (pt2) {
+        const dim3 grid((win + 64 * PT - 1) / (64 * PT), S);
+        if (h->hc.pow2)
+            hipLaunchKernelGGL((k_scan<DP, PT, true, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p,
+                               rows, clean, part, round);
+        else
+            hipLaunchKernelGGL((k_scan<DP, PT, false, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p,
+                               h->Xt.p, rows, clean, part, round);
+        return;
+    }
+    const dim3 grid((win + 63) / 64, S);
     if (h->hc.pow2)
         hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows,
                            clean, part, round);
@@ -386,6 +400,7 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
     h->tun.time_kernels = t->time_kernels;
     if (t->dirty_segments > 0) h->tun.dirty_segments = std::min(t->dirty_segments, 1024);
+    h->tun.reserved[0] = t->reserved[0];  // 2: two points per lane in the clean scan (A/B switch)
     return CC_OK;
 }
 
