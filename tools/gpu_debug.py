@@ -92,6 +92,19 @@ if __name__ == "__main__":
         if "blob" in which:
             cfg = scenarios.params_to_config(scenarios.blob_params(20000))
             run("blob-d20", cfg, [scenarios.make_blobs(10 + t, 20000, 20, 500, 0.01) for t in range(2)], window=1024)
+        if "seed3" in which:
+            n = 4000
+            params = scenarios.blob_params(n, param_epsilon=0.08, param_k=4, param_pi=3)
+            cfg = scenarios.params_to_config(params)
+            rng = np.random.default_rng(3)
+            Xs = []
+            for t in range(3):
+                X = scenarios.make_blobs(3 * 100 + t, n, 3, 6, 0.05)
+                if t == 2:
+                    X = X[rng.permutation(n)[: n // 2]]
+                Xs.append(X)
+            for w in (512, 64, 8):
+                run("seed3-w%d" % w, cfg, Xs, window=w)
         if "c1" in which:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from golden_util import GOLDEN, StateDump
