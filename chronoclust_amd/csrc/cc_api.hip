@@ -102,7 +102,6 @@ struct cc_handle {
     TableStore tab, tab2;
     Ctl hc{};  // host mirror of the device control block
     DevBuf<Ctl> ctl;
-    double gamma = 4.0;
     bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
 
     // points + labels of the current call
@@ -185,7 +184,6 @@ void refresh_ctl_params(cc_handle* h)
     c.omicron = p.omicron;
     c.pi = p.pi;
     c.filter = (h->d > 0 && p.pi < h->d) ? 1 : 0;
-    c.gamma = h->gamma;
     c.d = h->d;
 }
 
@@ -241,7 +239,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_tgt.ensure(w);
-    h->part.ensure(w * seg * 6); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 6); h->dseed.ensure(w * 4);
+    h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }

@@ -82,7 +82,6 @@ struct Ctl {
     int filter;  // pi < d: the pdim filter of hddstream.py:317-321 is not vacuous
     int pow2;    // k is a power of two: x / k == x * (1/k) bit for bit
     int pad0;
-    double gamma;  // clean scan: a MC row is dropped once every point's partial sum exceeds gamma x its best
     // statistics
     long long stat_windows, stat_rounds, stat_truncated;
     long long stat_table_rows;  // sum over windows of the table rows scanned

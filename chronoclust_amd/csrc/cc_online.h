@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     // LDS: per-wave tiles while scanning, then (same bytes) the candidate exchange of the final merge
     constexpr int TILE_DOUBLES = NW * CC_SCAN_TM * DP;
     constexpr int TILE_BYTES = TILE_DOUBLES * 16 + NW * CC_SCAN_TM * 12;
-    constexpr int MERGE_BYTES = (NW - 1) * PT * 6 * 64 * (int)sizeof(Cand);
+    constexpr int MERGE_BYTES = (NW - 1) * PT * 4 * 64 * (int)sizeof(Cand);
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
     double* const s_c_base = reinterpret_cast<double*>(smem) + (size_t)wv * CC_SCAN_TM * DP;
     double* const s_s_base = reinterpret_cast<double*>(smem) + TILE_DOUBLES + (size_t)wv * CC_SCAN_TM * DP;
@@ -169,12 +169,6 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     double bd[2][PT][2];
     int bk[2][PT][2], bs[2][PT][2];
     double cap[2][PT];
-    // clean scan: ub = upper bound on the best distance known before the scan (seed, may be +inf);
-    // lb = lower bound on the distance of every MC row that was dropped before its last dimension or finished
-    // outside the candidate lists.  The candidate lists are exact; "everything else >= min(c2, lb)".
-    double ub[2][PT], lb[2][PT];
-    const double gamma = ctl->gamma;
-    const double* seedu = DIRTY ? nullptr : reinterpret_cast<const double*>(clean);
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd)
 #pragma unroll
@@ -186,8 +180,6 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                 bs[kd][t][r] = -1;
             }
             cap[kd][t] = CC_INF;
-            lb[kd][t] = CC_INF;
-            ub[kd][t] = (seedu && valid[t]) ? seedu[(size_t)jj[t] * 2 + kd] : CC_INF;
         }
     if (DIRTY) {
         // caps and first candidates prepared once per point by k_dseed (`clean` is the seed table here)
@@ -253,11 +245,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                         const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
                         bound[t] = b1 < cp ? b1 : cp;
                     } else {
-                        const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
-                        const double b2 = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
-                        const double u = (kind == 0) ? ub[0][t] : ub[1][t];
-                        const double g = gamma * (b1 < u ? b1 : u);
-                        bound[t] = b2 < g ? b2 : g;
+                        bound[t] = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
                     }
                     if (!a) bound[t] = -1.0;
                     anyact = anyact || a;
@@ -308,30 +296,14 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                     }
                 }
             }
-            if (!alive) {
-                if (!DIRTY && liveA) {  // dropped early: its partial sum bounds its distance from below
-#pragma unroll
-                    for (int t = 0; t < PT; ++t) {
-                        if (!valid[t]) continue;
-                        if (kindA == 0) lb[0][t] = accA[t] < lb[0][t] ? accA[t] : lb[0][t];
-                        else lb[1][t] = accA[t] < lb[1][t] ? accA[t] : lb[1][t];
-                    }
-                }
-                continue;
-            }
+            if (!alive) continue;
 
             auto insert_row = [&](int mm, int kind, const double (&acc)[PT], const double (&bound)[PT]) {
                 const int rowg = rt + mm;
                 const int key = s_key_w[mm];
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
-                    if (!(acc[t] <= bound[t])) {
-                        if (!DIRTY && valid[t]) {  // finished outside the lists: still "everything else"
-                            if (kind == 0) lb[0][t] = acc[t] < lb[0][t] ? acc[t] : lb[0][t];
-                            else lb[1][t] = acc[t] < lb[1][t] ? acc[t] : lb[1][t];
-                        }
-                        continue;
-                    }
+                    if (!(acc[t] <= bound[t])) continue;
                     auto consider = [&](auto KC) {
                         constexpr int K = decltype(KC)::value;
                         constexpr int R = DIRTY ? 0 : 1;  // rank that a newcomer has to beat
@@ -360,8 +332,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     }
 
     // merge the waves' candidates through LDS; wave 0 writes the workgroup's partial
-    Cand* const s_m = reinterpret_cast<Cand*>(smem);  // [NW - 1][PT][6][64], reuses the tile bytes
-    auto s_m_at = [&](int w, int t, int c) -> Cand& { return s_m[((w * PT + t) * 6 + c) * 64 + lane]; };
+    Cand* const s_m = reinterpret_cast<Cand*>(smem);  // [NW - 1][PT][4][64], reuses the tile bytes
+    auto s_m_at = [&](int w, int t, int c) -> Cand& { return s_m[((w * PT + t) * 4 + c) * 64 + lane]; };
     __syncthreads();  // every wave is done with its tile
     if (wv > 0) {
 #pragma unroll
@@ -370,8 +342,6 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             s_m_at(wv - 1, t, 1) = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
             s_m_at(wv - 1, t, 2) = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
             s_m_at(wv - 1, t, 3) = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
-            s_m_at(wv - 1, t, 4) = Cand{lb[0][t], 0, 0};
-            s_m_at(wv - 1, t, 5) = Cand{lb[1][t], 0, 0};
         }
     }
     __syncthreads();
@@ -387,19 +357,14 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             cc_top2_push(c0, c1, s_m_at(w, t, 1));
             cc_top2_push(c2, c3, s_m_at(w, t, 2));
             cc_top2_push(c2, c3, s_m_at(w, t, 3));
-            const double l0 = s_m_at(w, t, 4).dist, l1 = s_m_at(w, t, 5).dist;
-            lb[0][t] = l0 < lb[0][t] ? l0 : lb[0][t];
-            lb[1][t] = l1 < lb[1][t] ? l1 : lb[1][t];
         }
         if (DIRTY) {
             Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 2;
             o[0] = c0;
             o[1] = c2;
         } else {
-            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 6;
+            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 4;
             o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-            o[4] = Cand{lb[0][t], 0, 0};
-            o[5] = Cand{lb[1][t], 0, 0};
         }
     }
 }
@@ -478,7 +443,7 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 // A live version only matters to point j if it beats what j already has.  If j's best snapshot candidate c1 is
 // still untouched when j arrives, that is c1 itself (cap = d1).  If c1 was touched, the live version of c1's MC
 // is itself a candidate: find it (short walk along the chain), take its exact distance as the first candidate;
-// everything else has to beat that.  Loose fallback: the bound on every other snapshot MC, min(d2, lb).
+// everything else has to beat that.  Loose fallback: the snapshot's second-best distance d2.
 // seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
 // ---------------------------------------------------------------------------------
 
@@ -498,19 +463,15 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     Cand first[2] = {Cand{CC_INF, CC_IDX_INF, -1}, Cand{CC_INF, CC_IDX_INF, -1}};
     double cap[2] = {CC_INF, CC_INF};
     for (int kd = 0; kd < 2; ++kd) {
-        const Cand c1 = clean[(size_t)j * 6 + kd * 2];
-        const Cand c2 = clean[(size_t)j * 6 + kd * 2 + 1];
-        const double lbk = clean[(size_t)j * 6 + 4 + kd].dist;
-        const double others = (c2.slot >= 0 && c2.dist < lbk) ? c2.dist : lbk;  // every other snapshot MC is >= this
-        if (c1.slot < 0) { cap[kd] = others; continue; }
+        const Cand c1 = clean[(size_t)j * 4 + kd * 2];
+        if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
         const unsigned long long tc = tab.touch[c1.slot];
         const int head = (int)(tc & 0xFFFFFull);
         if ((tc >> 20) != stamp || head >= j) {
             cap[kd] = c1.dist;  // c1 is clean at j
             continue;
         }
-        // c1 is touched: a live version has to get below every other snapshot MC to matter / to be provable
-        cap[kd] = others;
+        cap[kd] = clean[(size_t)j * 4 + kd * 2 + 1].dist;
         int v = head;
         for (int steps = 0; ver.next[v] < j; ++steps) {
             v = ver.next[v];
@@ -564,38 +525,29 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
 
     // candidates are kept in named scalars (no runtime-indexed arrays: those would live in scratch memory)
     Cand p1 = none, p2 = none, o1 = none, o2 = none;  // best two pcore / outlier snapshot candidates
-    double lbp = CC_INF, lbo = CC_INF;                // lower bound on every other pcore / outlier snapshot MC
     if (round == 0) {
         for (int s = gl; s < S; s += 32) {
-            const Cand* q = part + ((size_t)j * S + s) * 6;
+            const Cand* q = part + ((size_t)j * S + s) * 4;
             cc_top2_push(p1, p2, q[0]);
             cc_top2_push(p1, p2, q[1]);
             cc_top2_push(o1, o2, q[2]);
             cc_top2_push(o1, o2, q[3]);
-            const double l0 = q[4].dist, l1 = q[5].dist;
-            lbp = l0 < lbp ? l0 : lbp;
-            lbo = l1 < lbo ? l1 : lbo;
         }
         for (int off = 16; off >= 1; off >>= 1) {
             const Cand a0 = cc_shfl_xor_cand(p1, off), a1 = cc_shfl_xor_cand(p2, off);
             const Cand a2 = cc_shfl_xor_cand(o1, off), a3 = cc_shfl_xor_cand(o2, off);
-            const double l0 = __shfl_xor(lbp, off, 32), l1 = __shfl_xor(lbo, off, 32);
             cc_top2_push(p1, p2, a0);
             cc_top2_push(p1, p2, a1);
             cc_top2_push(o1, o2, a2);
             cc_top2_push(o1, o2, a3);
-            lbp = l0 < lbp ? l0 : lbp;
-            lbo = l1 < lbo ? l1 : lbo;
         }
         if (gl == 0) {
-            Cand* out = clean + (size_t)j * 6;
+            Cand* out = clean + (size_t)j * 4;
             out[0] = p1; out[1] = p2; out[2] = o1; out[3] = o2;
-            out[4] = Cand{lbp, 0, 0}; out[5] = Cand{lbo, 0, 0};
         }
     } else {
-        const Cand* in = clean + (size_t)j * 6;
+        const Cand* in = clean + (size_t)j * 4;
         p1 = in[0]; p2 = in[1]; o1 = in[2]; o2 = in[3];
-        lbp = in[4].dist; lbo = in[5].dist;
     }
     Cand dvp = none, dvo = none;  // best live version per kind
     if (round > 0) {
@@ -624,27 +576,14 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     int T = -1;
     int path = 2;
     // one stage of the reference's procedure: stage 0 = _add_to_pcore (hddstream.py:288-343), 1 = _add_to_outlier
-    auto run_stage = [&](const Cand& c1, const Cand& c2, double lbk, const Cand& dd, int stage) {
-        // The snapshot lists are exact: c1 is the best MC of this kind; c2 is exactly the second best iff its
-        // distance is below lbk, the lower bound on every MC that is in neither list; `others` bounds all
-        // snapshot MCs except c1 (and except c2 when c2 is exact) from below.
-        const bool c2x = c2.slot >= 0 && c2.dist < lbk;
-        // MCs that were pushed out of the lists (by better ones, or in a merge) are only known to be >= c2
-        const double others = c2x ? c2.dist : lbk;
-        int state;  // 0: no clean candidate, 1: cb is the exact clean best, 2: the clean best is only known to be >= bnd
+    auto run_stage = [&](const Cand& c1, const Cand& c2, const Cand& dd, int stage) {
+        int state;  // 0: no clean candidate, 1: cb is the exact clean best, 2: cb only bounds the clean best from below
         Cand cb = none;
-        double bnd = CC_INF;
-        if (c1.slot >= 0 && !dirty(c1.slot)) { state = 1; cb = c1; }
-        else if (c1.slot >= 0 && c2x && !dirty(c2.slot)) { state = 1; cb = c2; }
-        else if (c1.slot >= 0) {
-            // c1 (and c2 if it is exact) are touched: their live versions are among the dirty candidates;
-            // every untouched snapshot MC is >= others
-            bnd = others;
-            state = (bnd == CC_INF) ? 0 : 2;
-        } else {
-            bnd = lbk;  // no list entry at all: nothing finished inside the lists
-            state = (bnd == CC_INF) ? 0 : 2;
-        }
+        if (c1.slot < 0) state = 0;
+        else if (!dirty(c1.slot)) { state = 1; cb = c1; }
+        else if (c2.slot < 0) state = 0;
+        else if (!dirty(c2.slot)) { state = 1; cb = c2; }
+        else { state = 2; cb = c2; }
 
         int wkind = 0;  // 0 none, 1 table row, 2 version row
         int wrow = -1;
@@ -654,7 +593,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             if (dd.slot >= 0 && cand_less(dd.dist, dd.key, cb.dist, cb.key)) { wkind = 2; wrow = dd.slot; }
             else { wkind = 1; wrow = cb.slot; }
         } else {
-            if (dd.slot >= 0 && dd.dist < bnd) { wkind = 2; wrow = dd.slot; }  // strictly closer than anything clean
+            if (dd.slot >= 0 && cand_less(dd.dist, dd.key, cb.dist, cb.key)) { wkind = 2; wrow = dd.slot; }
             else { T = CC_T_UNKNOWN; return; }
         }
         if (wkind == 0) return;
@@ -674,8 +613,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             path = stage;
         }
     };
-    run_stage(p1, p2, lbp, dvp, 0);
-    if (T == -1) run_stage(o1, o2, lbo, dvo, 1);
+    run_stage(p1, p2, dvp, 0);
+    if (T == -1) run_stage(o1, o2, dvo, 1);
     if (T == -1) {  // hddstream.py:434-462: new outlier MC, provisional id = rows-at-window-start + j
         T = M0 + j;
         path = 2;
