@@ -802,8 +802,8 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                            pv, h->prow.p, mp, d);
         hipLaunchKernelGGL(k_core_flags, dim3((mp + 255) / 256), dim3(256), 0, h->stream, pv, mp, d, p.eps_sq, p.mu,
                            p.pi, p.k, c.inv_k, c.pow2, h->core.p);
-        hipLaunchKernelGGL(k_eps_neighbours, dim3(words, mp), dim3(64), 0, h->stream, pv.cen, mp, d, p.ups_eps,
-                           h->adj.p, words);
+        hipLaunchKernelGGL(k_eps_neighbours, dim3(words, words), dim3(256), (size_t)2 * 64 * (d + 1) * sizeof(double),
+                           h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words);
         hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, h->stream, pv.cen,
                            h->adj.p, words, mp, d, p.delta, p.k, h->wvec.p, h->nn.p);
         hipLaunchKernelGGL(k_pdim, dim3((mp + 255) / 256), dim3(256), 0, h->stream, h->wvec.p, mp, d, h->pdim.p);

@@ -107,26 +107,43 @@ __global__ void k_core_flags(PcoreView pv, int mp, int d, double eps_sq, double 
     core[r] = (r2 <= eps_sq && w >= mu && cnt <= pi) ? 1 : 0;
 }
 
-// K6: predecon.py:161-188.  One wave per (p, 64 consecutive q): ballot -> one word of the adjacency bitmask.
+// K6: predecon.py:161-188.  A workgroup takes a 64 x 64 block of the (p, q) pair matrix: both centroid tiles are
+// staged through LDS (row stride d + 1 doubles, conflict-free for the per-lane q rows), lane = q, each of the four
+// waves walks 16 values of p; ballot -> one word of the adjacency bitmask per (p, 64 q).
 // Euclidean distance = sqrt of the left-to-right sum of squares (the reference's np.linalg.norm is
 // platform-defined in the last ulp: nrm2 under numba, sqrt(dot) under numpy).
-__global__ __launch_bounds__(64) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
-                                                       unsigned long long* __restrict__ adj, int words)
+__global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
+                                                        unsigned long long* __restrict__ adj, int words)
 {
-    const int p = blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    bool in = false;
-    if (q < mp) {
-        double acc = 0.0;
-        for (int i = 0; i < d; ++i) {
-            double t = cen[(size_t)q * d + i] - cen[(size_t)p * d + i];
-            t = t * t;
-            acc = acc + t;
-        }
-        in = sqrt(acc) <= eps;
+    extern __shared__ double s_tiles[];  // [64][d + 1] q rows, then [64][d + 1] p rows
+    const int ld = d + 1;
+    double* sq = s_tiles;
+    double* sp = s_tiles + 64 * ld;
+    const int q0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+    for (int e = threadIdx.x; e < 64 * d; e += 256) {
+        const int r = e / d, i = e - r * d;
+        sq[r * ld + i] = (q0 + r < mp) ? cen[(size_t)(q0 + r) * d + i] : 0.0;
+        sp[r * ld + i] = (p0 + r < mp) ? cen[(size_t)(p0 + r) * d + i] : 0.0;
     }
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
-    if (threadIdx.x == 0) adj[(size_t)p * words + blockIdx.x] = mask;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int q = q0 + lane;
+    for (int pp = wv * 16; pp < wv * 16 + 16; ++pp) {
+        const int p = p0 + pp;
+        if (p >= mp) break;
+        bool in = false;
+        if (q < mp) {
+            double acc = 0.0;
+            for (int i = 0; i < d; ++i) {
+                double t = sq[lane * ld + i] - sp[pp * ld + i];
+                t = t * t;
+                acc = acc + t;
+            }
+            in = sqrt(acc) <= eps;
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+        if (lane == 0) adj[(size_t)p * words + blockIdx.x] = mask;
+    }
 }
 
 // K7: predecon.py:190-217 + predeconmc_functions.py:19-42.  One thread per (p, dim): mean squared deviation of

@@ -164,3 +164,20 @@ def test_assoc_argmin_against_oracle():
         oi, od = O.assoc_argmin(cur, pref, prev)
         np.testing.assert_array_equal(gi, oi)
         assert np.array_equal(gd, od)
+
+
+def test_offline_intermediates_against_oracle():
+    """Core flags, |N_eps|, PreDeCon pdim and |N_w| per pcore (predecon.py:136-217) on a scenario where
+    neighbourhoods are non-trivial (upsilon large, anisotropic blobs, pi < d, k = 3)."""
+    from oracle import oracle as O
+    sc = scenarios.BLOB_SCENARIOS["d14_filter"]
+    cfg = scenarios.params_to_config(sc["params"])
+    Xs = scenarios.make_blob_timepoints(sc, raw=True)
+    h, o = _hdd(cfg), O.OracleHDDStream(cfg)
+    for t, X in enumerate(Xs):
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _, info = h._h.offline(dumps=True)
+        for key in ("core", "pdim", "nn", "nw"):
+            np.testing.assert_array_equal(info[key], o.offline_dump[key], err_msg="%s t=%d" % (key, t))
+        assert info["nn"].max() > 1  # the eps-neighbourhoods are not all singletons
