@@ -58,6 +58,7 @@ SYMBOLS = {
     "cc_count": (C.c_int, [C.c_void_p, C.c_int]),
     "cc_dim": (C.c_int, [C.c_void_p]),
     "cc_counters": (C.c_int, [C.c_void_p, _i64p, _i64p]),
+    "cc_set_counters": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "cc_export": (C.c_int, [C.c_void_p, C.c_int, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp]),
     "cc_inject_mc": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, _dp, _dp, _dp, _dp, C.c_double, C.c_int64,
                                C.c_int64]),
@@ -178,6 +179,9 @@ class Handle(object):
         a, b = C.c_int64(), C.c_int64()
         self._check(self._lib.cc_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_counters(self, pcore_last_id, outlier_last_id):
+        self._check(self._lib.cc_set_counters(self._h, int(pcore_last_id), int(outlier_last_id)))
 
     def export(self, kind):
         n, d = self.count(kind), self.dim()

@@ -31,21 +31,29 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
     """Runs ChronoClust over the timepoint files in `data` (in time order) and writes the results into
     `output_directory`.  Same arguments and side effects as the reference's `chronoclust.app.run`.
 
-    restore_program: the reference's pickle-based resume loses its id counters and truncates result.csv
-    (SURVEY.md section 5); it is not offered here and raises NotImplementedError when requested.
+    restore_program: continue from the state saved under `<output_directory>/program_images` after the last
+    completed timepoint (app.py:107-114, 165-166).  Unlike the reference's pickles (which lose the id counters
+    and whose restart truncates result.csv) the images here hold the microcluster tables
+    and counters, and result.csv is appended to.
     """
-    if restore_program:
-        raise NotImplementedError("restore_program is not supported by chronoclust_amd (upstream resume is broken)")
-
+    program_state_dir = '{}/program_images'.format(output_directory)
     logger = setup_logger('{}/logs'.format(output_directory))
     logger.info("Chronoclust start")
     config = {"beta": param_beta, "delta": param_delta, "epsilon": param_epsilon, "lambda": param_lambda,
               "k": param_k, "mu": param_mu, "pi": param_pi, "omicron": param_omicron, "upsilon": param_upsilon}
 
-    logger.info("Setup new Chronoclust state")
+    restoring = bool(restore_program) and os.path.exists(os.path.join(program_state_dir, HDDSTREAM_OBJ + '.npz'))
     hddstream = HDDStream(config, logger)
-    tracker_by_association = TrackByHistoricalAssociation(handle=hddstream._h)
-    tracker_by_lineage = TrackByLineage()
+    if restoring:
+        logger.info("Restoring Chronoclust state saved in {}".format(program_state_dir))
+        tracker_by_association, tracker_by_lineage = restore_program_state(program_state_dir, hddstream)
+    else:
+        if restore_program:
+            logger.warning("Restoring previous Chronoclust state not possible as program_images is not in {}".format(
+                output_directory))
+        logger.info("Setup new Chronoclust state")
+        tracker_by_association = TrackByHistoricalAssociation(handle=hddstream._h)
+        tracker_by_lineage = TrackByLineage()
 
     dataset_attributes = get_dataset_attributes(data[0])
     result_filename = f'{output_directory}/result.csv'
@@ -59,7 +67,8 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
         for _, gate in gating_df.iterrows():
             centroid = tuple(gate[dataset_attributes].values)
             gating[int(gate['Day'])][centroid] = gate['PopName']
-    write_file_header(result_filename, result_file_header)
+    if not (restoring and os.path.exists(result_filename)):
+        write_file_header(result_filename, result_file_header)
 
     scaler = None
     if normalise_data:
@@ -67,6 +76,8 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
         scaler = Scaler(data)
 
     for timepoint, data_file in enumerate(data):
+        if restoring and hddstream.last_data_timestamp >= timepoint:
+            continue  # already processed before the checkpoint (app.py:165-166)
         logger.info("Processing dataset {}".format(timepoint))
         raw = pd.read_csv(data_file, header=0, sep=',').to_numpy()
         dataset = raw
@@ -95,6 +106,9 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
 
         tracker_by_lineage.transfer_child_to_parent()
         tracker_by_association.transfer_current_to_previous()
+
+        logger.info("Saving Chronoclust state for timepoint {}".format(timepoint))
+        save_program_state(hddstream, output_directory, tracker_by_association, tracker_by_lineage)
 
     with open(f'{output_directory}/parameters.csv', 'w') as f:
         w = csv.DictWriter(f, config.keys())
@@ -149,6 +163,32 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, scale
     for c, name in enumerate(dataset_attributes):
         columns[name] = values[:, c] if n else []
     pd.DataFrame(columns).to_csv(cluster_points_filename, index=False)
+
+
+def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by_lineage):
+    """State after a completed timepoint (app.py:402-433): microcluster tables + counters as arrays, the two
+    trackers pickled (they only hold small Cluster records here)."""
+    import pickle
+    d = "{}/program_images".format(output_dir)
+    os.makedirs(d, exist_ok=True)
+    np.savez(os.path.join(d, HDDSTREAM_OBJ + '.npz'), **hddstream.get_state())
+    with open(os.path.join(d, TRACKER_HISTORICAL_ASSOC), 'wb') as f:
+        pickle.dump(tracker_by_association, f)
+    with open(os.path.join(d, TRACKER_LINEAGE), 'wb') as f:
+        pickle.dump(tracker_by_lineage, f)
+
+
+def restore_program_state(program_state_dir, hddstream):
+    """Loads what save_program_state wrote into `hddstream`; returns the two trackers (app.py:436-465)."""
+    import pickle
+    with np.load(os.path.join(program_state_dir, HDDSTREAM_OBJ + '.npz')) as z:
+        hddstream.set_state({k: z[k] for k in z.files})
+    with open(os.path.join(program_state_dir, TRACKER_HISTORICAL_ASSOC), 'rb') as f:
+        tracker_by_association = pickle.load(f)
+    with open(os.path.join(program_state_dir, TRACKER_LINEAGE), 'rb') as f:
+        tracker_by_lineage = pickle.load(f)
+    tracker_by_association._handle = hddstream._h
+    return tracker_by_association, tracker_by_lineage
 
 
 def setup_logger(log_dir):

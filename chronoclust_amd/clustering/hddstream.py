@@ -175,3 +175,32 @@ class HDDStream(object):
 
     def stats(self):
         return self._h.stats()
+
+    # ---- checkpoint (what chronoclust/app.py:402-465 pickles; here plain arrays + the id counters the
+    # reference's __getstate__ forgets, hddstream.py:69-81) -------------------------------------------------
+
+    def get_state(self):
+        state = {"last_data_timestamp": self.last_data_timestamp, "dataset_size": self.dataset_size,
+                 "dataset_dimensionality": self.dataset_dimensionality,
+                 "pcore_MC_last_id": self.pcore_MC_last_id, "outlier_MC_last_id": self.outlier_MC_last_id}
+        for kind, name in ((_lib.PCORE, "pcore"), (_lib.OUTLIER, "outlier")):
+            for key, val in self.table(kind).items():
+                state["%s_%s" % (name, key)] = val
+        return state
+
+    def set_state(self, state):
+        self.last_data_timestamp = int(state["last_data_timestamp"])
+        self.dataset_size = int(state["dataset_size"])
+        self.dataset_dimensionality = int(state["dataset_dimensionality"])
+        d = self.dataset_dimensionality
+        self._h.reset()
+        # k must be known before rows arrive so that their preferred-dimension entries are recognised
+        self._h.set_params(self.epsilon_squared, self.delta_squared, self.k, self.beta, 0.0, 0.0, self.upsilon,
+                           self.upsilon ** 2, self.delta, max(d, 1))
+        for kind, name in ((_lib.PCORE, "pcore"), (_lib.OUTLIER, "outlier")):
+            ids = state["%s_id" % name]
+            for i in range(len(ids)):
+                self._h.inject(kind, state["%s_cf1" % name][i], state["%s_cf2" % name][i], state["%s_cen" % name][i],
+                               state["%s_pref" % name][i], state["%s_w" % name][i], ids[i], state["%s_uid" % name][i])
+        self._h.set_counters(state["pcore_MC_last_id"], state["outlier_MC_last_id"])
+        self._invalidate()

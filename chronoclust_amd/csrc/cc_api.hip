@@ -443,6 +443,18 @@ int cc_counters(cc_handle* h, int64_t* pcore_last_id, int64_t* outlier_last_id)
     return CC_OK;
 }
 
+int cc_set_counters(cc_handle* h, int64_t pcore_last_id, int64_t outlier_last_id)
+{
+    if (!h || pcore_last_id < 0 || outlier_last_id < 0) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        h->hc.pcore_last_id = pcore_last_id;
+        h->hc.outlier_last_id = outlier_last_id;
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
 int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d)
 {
     if (!h || (!x && n > 0) || n < 0) return CC_ERR_BAD_ARG;

@@ -89,6 +89,15 @@ class TrackByHistoricalAssociation(object):
             self._handle = _lib.Handle(0)
         return self._handle
 
+    def __getstate__(self):  # the GPU handle is not part of a checkpoint
+        return {"current_clusters": self.current_clusters,
+                "previous_timepoint_clusters": self.previous_timepoint_clusters}
+
+    def __setstate__(self, state):
+        self.current_clusters = state["current_clusters"]
+        self.previous_timepoint_clusters = state["previous_timepoint_clusters"]
+        self._handle = None
+
     def set_current_clusters(self, clusters):
         self.current_clusters = clusters
 

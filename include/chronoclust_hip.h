@@ -131,6 +131,8 @@ int cc_online(cc_handle* h, const double* x, int64_t n, int32_t d, int64_t* out_
 int cc_count(cc_handle* h, int kind);
 int cc_dim(cc_handle* h);
 int cc_counters(cc_handle* h, int64_t* pcore_last_id, int64_t* outlier_last_id);
+/* Checkpoint restore: the id counters of hddstream.py:63-64 (the reference's own pickle drops them). */
+int cc_set_counters(cc_handle* h, int64_t pcore_last_id, int64_t outlier_last_id);
 int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w,
               double* cf1, double* cf2, double* cen, double* pref);
 /* Appends one microcluster to a list (tests, checkpoint restore). */

@@ -136,3 +136,51 @@ def test_association_scenarios_from_reference_unit_tests(scenario):
             assert [c.get_historical_associates_as_str() for c in assoc.current_clusters] == ev["assoc_after"]
         elif ev["op"] == "assoc_next":
             assoc.transfer_current_to_previous()
+
+
+def test_restore_program_continues_exactly(tmp_path):
+    """Stop after three timepoints, restart with restore_program=True on all five files: the outputs are the
+    reference's golden again (the reference's own resume cannot do this)."""
+    from chronoclust_amd import app
+    c1 = os.path.join(GOLDEN, "c1")
+    data = [os.path.join(c1, "synthetic_d%d.csv.gz" % t) for t in range(5)]
+    gating = os.path.join(c1, "gating_centroids.csv")
+    out = str(tmp_path)
+    try:
+        # the scaler is fitted on all five files in both runs, as a user resuming the same job would have it
+        import chronoclust_amd.app as A
+        real_enumerate = enumerate
+
+        class Stop(Exception):
+            pass
+
+        def run_first_three():
+            orig = A.save_program_state
+
+            def save_and_maybe_stop(h, o, ta, tl):
+                orig(h, o, ta, tl)
+                if h.last_data_timestamp == 2:
+                    raise Stop()
+            A.save_program_state = save_and_maybe_stop
+            try:
+                app.run(data=data, output_directory=out, gating_centroid_file=gating, **scenarios.C1_PARAMS)
+            except Stop:
+                pass
+            finally:
+                A.save_program_state = orig
+        run_first_three()
+        _reset_logging()
+        assert open(os.path.join(out, "result.csv")).read().count("\n") < 24
+        app.run(data=data, output_directory=out, gating_centroid_file=gating, restore_program=True,
+                **scenarios.C1_PARAMS)
+    finally:
+        _reset_logging()
+    with open(os.path.join(c1, "expected_result.csv"), newline="") as f:
+        exp = f.read()
+    with open(os.path.join(out, "result.csv"), newline="") as f:
+        got = f.read()
+    assert got.replace("\r\n", "\n") == exp.replace("\r\n", "\n")
+    rec = np.load(os.path.join(c1, "hdd_state.npz"))
+    for t in range(5):
+        exp_text = gzip.decompress(rec["t%d_points_csv" % t].tobytes())
+        assert open(os.path.join(out, "cluster_points_D%d.csv" % t), "rb").read() == exp_text
