@@ -54,18 +54,33 @@ __device__ __forceinline__ double cc_sqvar(double cf1, double cf2, double w)
     return a - b;
 }
 
+// The parameters the per-MC arithmetic needs, read from the control block once per kernel into registers
+// (reading them through the Ctl pointer inside loops would re-load them after every store).
+struct Par {
+    double delta_sq, k, inv_k, eps_sq, beta_mu;
+    int pow2, pi, filter, d;
+};
+
+__device__ __forceinline__ Par cc_load_par(const Ctl* ctl)
+{
+    Par p;
+    p.delta_sq = ctl->delta_sq; p.k = ctl->k; p.inv_k = ctl->inv_k; p.eps_sq = ctl->eps_sq; p.beta_mu = ctl->beta_mu;
+    p.pow2 = ctl->pow2; p.pi = ctl->pi; p.filter = ctl->filter; p.d = ctl->d;
+    return p;
+}
+
 // x / pref with pref in {1.0, k}; when k is a power of two x * (1/k) is the same double
-__device__ __forceinline__ double cc_div_pref(double x, double pref, const Ctl* c)
+__device__ __forceinline__ double cc_div_pref(double x, double pref, const Par& c)
 {
     if (pref == 1.0) return x;
-    return (c->pow2 && pref == c->k) ? x * c->inv_k : x / pref;
+    return (c.pow2 && pref == c.k) ? x * c.inv_k : x / pref;
 }
 
 // microcluster.py:213-233 + mc_functions.py:45-56: projected radius^2 of (base + point) with the
 // preferred dimensions of the enlarged MC.  base_cf1 == nullptr means an empty MC.
 // Also returns count(pref' > 1) and count(pref' != 1) of the enlarged MC.
 __device__ inline double cc_tentative_radius(const double* bcf1, const double* bcf2, double bw, const double* p,
-                                             int d, const Ctl* c, int* cnt_gt1, int* cnt_ne1)
+                                             int d, const Par& c, int* cnt_gt1, int* cnt_ne1)
 {
     const double w1 = bw + 1.0;
     double r2 = 0.0;
@@ -75,7 +90,7 @@ __device__ inline double cc_tentative_radius(const double* bcf1, const double* b
         double c1 = (bcf1 ? bcf1[i] : 0.0) + x;
         double c2 = (bcf2 ? bcf2[i] : 0.0) + x * x;
         double var = cc_sqvar(c1, c2, w1);
-        double pr = (var <= c->delta_sq) ? c->k : 1.0;  // microcluster.py:109-114 (NaN -> 1.0)
+        double pr = (var <= c.delta_sq) ? c.k : 1.0;  // microcluster.py:109-114 (NaN -> 1.0)
         g += (pr > 1.0);
         n += (pr != 1.0);
         r2 = r2 + cc_div_pref(var, pr, c);
@@ -137,8 +152,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
     const long long cursor = ctl->cursor;
     const size_t n_pts = (size_t)ctl->n_points;
-    const double inv_k = ctl->inv_k;
-    const bool filter = ctl->filter != 0;
+    const Par par = cc_load_par(ctl);
+    const double inv_k = par.inv_k;
+    const bool filter = par.filter != 0;
 
     // LDS: per-wave tiles while scanning, then (same bytes) the candidate exchange of the final merge
     constexpr int TILE_DOUBLES = NW * CC_SCAN_TM * DP;
@@ -312,8 +328,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                             // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
                             int ne1 = 0;
                             cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
-                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, ctl, nullptr, &ne1);
-                            if (ne1 > ctl->pi) return;
+                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
+                            if (ne1 > par.pi) return;
                         }
                         if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
                             bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
@@ -389,7 +405,7 @@ struct GroupAdd {
 // microcluster.py:213-233 + mc_functions.py:45-56, computed by the 32 lanes of a group together.
 // Every lane of the group must call it with the same arguments.  bcf1 == nullptr: empty base.
 __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, double bw, const double* p, int d,
-                                        const Ctl* c)
+                                        const Par& c)
 {
     const int gl = threadIdx.x & 31;
     GroupAdd g;
@@ -406,7 +422,7 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
             g.c1[h] = (bcf1 ? bcf1[i] : 0.0) + x;
             g.c2[h] = (bcf2 ? bcf2[i] : 0.0) + x * x;
             const double var = cc_sqvar(g.c1[h], g.c2[h], w1);
-            const double pr = (var <= c->delta_sq) ? c->k : 1.0;
+            const double pr = (var <= c.delta_sq) ? c.k : 1.0;
             g.pr[h] = pr;
             term[h] = cc_div_pref(var, pr, c);
             gt[h] = pr > 1.0;
@@ -456,8 +472,9 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     if (ctl->fc[round - 1] >= B) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= B) return;
-    const int d = ctl->d;
-    const bool filter = ctl->filter != 0;
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
+    const bool filter = par.filter != 0;
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     const double* p = X + (ctl->cursor + j) * d;
     Cand first[2] = {Cand{CC_INF, CC_IDX_INF, -1}, Cand{CC_INF, CC_IDX_INF, -1}};
@@ -484,12 +501,12 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         for (int i = 0; i < d; ++i) {
             double x = p[i] - ver.cen[(size_t)v * d + i];
             x = x * x;
-            acc = acc + cc_div_pref(x, ver.pref[(size_t)v * d + i], ctl);
+            acc = acc + cc_div_pref(x, ver.pref[(size_t)v * d + i], par);
         }
         if (kv == 0 && filter) {
             int ne1 = 0;
-            cc_tentative_radius(ver.cf1 + (size_t)v * d, ver.cf2 + (size_t)v * d, ver.w[v], p, d, ctl, nullptr, &ne1);
-            if (ne1 > ctl->pi) continue;
+            cc_tentative_radius(ver.cf1 + (size_t)v * d, ver.cf2 + (size_t)v * d, ver.w[v], p, d, par, nullptr, &ne1);
+            if (ne1 > par.pi) continue;
         }
         const int key = ver.key[v];
         if (kv == 0) {
@@ -520,7 +537,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
-    const int d = ctl->d;
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
     const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
 
     // candidates are kept in named scalars (no runtime-indexed arrays: those would live in scratch memory)
@@ -607,8 +625,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             bcf1 = ver.cf1 + (size_t)wrow * d; bcf2 = ver.cf2 + (size_t)wrow * d; bw = ver.w[wrow];
             target = ver.tgt[wrow];
         }
-        const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, ctl);  // hddstream.py:334-337
-        if (g.r2 <= ctl->eps_sq) {
+        const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, par);  // hddstream.py:334-337
+        if (g.r2 <= par.eps_sq) {
             T = target;
             path = stage;
         }
@@ -695,8 +713,11 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         if (cc_group_ballot(m)) return;  // an earlier point heads this chain and walks over j
     }
 
-    const int d = ctl->d;
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
     const int M0 = ctl->m_rows;
+    const long long cursor = ctl->cursor;
+    const int pk_base = ctl->n_pkeys;
     const bool isnew = t >= M0;
     const bool valid_chain = !isnew || (t == M0 + j);  // a claim on a MC nobody creates any more is void
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
@@ -733,15 +754,15 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 ver.tgt[cur] = t; ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
             }
         } else {
-            const double* p = X + (ctl->cursor + cur) * d;
+            const double* p = X + (cursor + cur) * d;
             const double w1 = bw + 1.0;  // microcluster.py:147
-            const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, ctl);
+            const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, par);
             const bool creates = isnew && cur == j;
-            const bool ok = creates || (g.r2 <= ctl->eps_sq);
+            const bool ok = creates || (g.r2 <= par.eps_sq);
             if (ok) {
                 // hddstream.py:416-430: promotion is only examined after an add to an existing outlier MC
-                if (bkind == CC_KIND_OUTLIER && !creates && w1 >= ctl->beta_mu && g.gt1 <= ctl->pi) {
-                    bkind = CC_KIND_PCORE; bkey = ctl->n_pkeys + cur; bupg = cur;
+                if (bkind == CC_KIND_OUTLIER && !creates && w1 >= par.beta_mu && g.gt1 <= par.pi) {
+                    bkind = CC_KIND_PCORE; bkey = pk_base + cur; bupg = cur;
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
