@@ -403,9 +403,10 @@ struct GroupAdd {
 };
 
 // microcluster.py:213-233 + mc_functions.py:45-56, computed by the 32 lanes of a group together.
-// Every lane of the group must call it with the same arguments.  bcf1 == nullptr: empty base.
-__device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, double bw, const double* p, int d,
-                                        const Par& c)
+// Every lane of the group must call it with the same bw / d; b1, b2, px are this lane's two dimensions of the
+// base CF1, CF2 and of the point.
+__device__ inline GroupAdd cc_group_add_regs(const double (&b1)[2], const double (&b2)[2], double bw,
+                                             const double (&px)[2], int d, const Par& c)
 {
     const int gl = threadIdx.x & 31;
     GroupAdd g;
@@ -418,9 +419,9 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
         g.c1[h] = 0.0; g.c2[h] = 0.0; g.pr[h] = 1.0;
         term[h] = 0.0; gt[h] = false; ne[h] = false;
         if (i < d) {
-            const double x = p[i];
-            g.c1[h] = (bcf1 ? bcf1[i] : 0.0) + x;
-            g.c2[h] = (bcf2 ? bcf2[i] : 0.0) + x * x;
+            const double x = px[h];
+            g.c1[h] = b1[h] + x;
+            g.c2[h] = b2[h] + x * x;
             const double var = cc_sqvar(g.c1[h], g.c2[h], w1);
             const double pr = (var <= c.delta_sq) ? c.k : 1.0;
             g.pr[h] = pr;
@@ -443,6 +444,23 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
     for (int i = 0; i < d; ++i) r2 = r2 + row[i];  // mc_functions.py:54, left to right
     g.r2 = r2;
     return g;
+}
+
+// the same from memory: bcf1 == nullptr means an empty base
+__device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, double bw, const double* p, int d,
+                                        const Par& c)
+{
+    const int gl = threadIdx.x & 31;
+    double b1[2] = {0.0, 0.0}, b2[2] = {0.0, 0.0}, px[2] = {0.0, 0.0};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = gl + 32 * h;
+        if (i < d) {
+            px[h] = p[i];
+            if (bcf1) { b1[h] = bcf1[i]; b2[h] = bcf2[i]; }
+        }
+    }
+    return cc_group_add_regs(b1, b2, bw, px, d, c);
 }
 
 __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
@@ -723,15 +741,30 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     if (!isnew && gl == 0) tab.touch[t] = (stamp << 20) | (unsigned long long)j;
 
-    const double *bcf1 = nullptr, *bcf2 = nullptr, *bcen = nullptr, *bpref = nullptr;
+    // this lane's two dimensions of the chain's running state stay in registers from step to step
+    double bc1[2] = {0.0, 0.0}, bc2[2] = {0.0, 0.0}, bce[2] = {0.0, 0.0}, bpr[2] = {1.0, 1.0};
     double bw = 0.0;
     int bkind = CC_KIND_OUTLIER, bkey = ctl->n_okeys + j, bupg = -1;
     if (!isnew) {
-        bcf1 = tab.cf1 + (size_t)t * d; bcf2 = tab.cf2 + (size_t)t * d;
-        bcen = tab.cen + (size_t)t * d; bpref = tab.pref + (size_t)t * d;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i < d) {
+                bc1[h] = tab.cf1[(size_t)t * d + i]; bc2[h] = tab.cf2[(size_t)t * d + i];
+                bce[h] = tab.cen[(size_t)t * d + i]; bpr[h] = tab.pref[(size_t)t * d + i];
+            }
+        }
         bw = tab.w[t]; bkind = tab.kind[t]; bkey = tab.key[t];
     }
     int cur = j;
+    double px[2] = {0.0, 0.0};  // this lane's two dimensions of point `cur`
+    if (valid_chain) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i < d) px[h] = X[(cursor + cur) * d + i];
+        }
+    }
     while (true) {
         int nx = CC_IDX_INF;
         for (int base = (cur + 1) & ~127; base < B; base += 128) {
@@ -747,16 +780,22 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 break;
             }
         }
-        double* vcf1 = ver.cf1 + (size_t)cur * d; double* vcf2 = ver.cf2 + (size_t)cur * d;
-        double* vcen = ver.cen + (size_t)cur * d; double* vpref = ver.pref + (size_t)cur * d;
+        // the next point of the chain is fetched while this one is being absorbed
+        double pn[2] = {0.0, 0.0};
+        if (valid_chain && nx != CC_IDX_INF) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = gl + 32 * h;
+                if (i < d) pn[h] = X[(cursor + nx) * d + i];
+            }
+        }
         if (!valid_chain) {
             if (gl == 0) {
                 ver.tgt[cur] = t; ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
             }
         } else {
-            const double* p = X + (cursor + cur) * d;
             const double w1 = bw + 1.0;  // microcluster.py:147
-            const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, par);
+            const GroupAdd g = cc_group_add_regs(bc1, bc2, bw, px, d, par);
             const bool creates = isnew && cur == j;
             const bool ok = creates || (g.r2 <= par.eps_sq);
             if (ok) {
@@ -766,30 +805,31 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int i = gl + 32 * h;
-                    if (i < d) {
-                        vcf1[i] = g.c1[h]; vcf2[i] = g.c2[h];
-                        vcen[i] = g.c1[h] / w1;  // mc_functions.py:31-33
-                        vpref[i] = g.pr[h];
-                    }
+                    bc1[h] = g.c1[h]; bc2[h] = g.c2[h];
+                    bce[h] = g.c1[h] / w1;  // mc_functions.py:31-33
+                    bpr[h] = g.pr[h];
                 }
-            } else {
+                bw = w1;
+            }
+            // the version row of `cur` = the MC's state right after `cur` (unchanged if the radius test failed)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int i = gl + 32 * h;
-                    if (i < d) { vcf1[i] = bcf1[i]; vcf2[i] = bcf2[i]; vcen[i] = bcen[i]; vpref[i] = bpref[i]; }
+            for (int h = 0; h < 2; ++h) {
+                const int i = gl + 32 * h;
+                if (i < d) {
+                    ver.cf1[(size_t)cur * d + i] = bc1[h]; ver.cf2[(size_t)cur * d + i] = bc2[h];
+                    ver.cen[(size_t)cur * d + i] = bce[h]; ver.pref[(size_t)cur * d + i] = bpr[h];
                 }
             }
-            if (ok) bw = w1;
             if (gl == 0) {
                 ver.w[cur] = bw;
                 ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
                 ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
             }
-            bcf1 = vcf1; bcf2 = vcf2; bcen = vcen; bpref = vpref;
         }
         if (nx == CC_IDX_INF) break;
         cur = nx;
+        px[0] = pn[0];
+        px[1] = pn[1];
     }
 }
 
