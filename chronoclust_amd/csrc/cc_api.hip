@@ -61,17 +61,17 @@ struct TableStore {
     DevBuf<double> cf1, cf2, cen, pref, w;
     DevBuf<int> kind, key;
     DevBuf<long long> id, uid;
-    DevBuf<unsigned long long> touch;
+    DevBuf<unsigned long long> touch, last;
     size_t cap = 0;
     int d = 0;
     void alloc(size_t rows, int dim)
     {
         cf1.ensure(rows * dim); cf2.ensure(rows * dim); cen.ensure(rows * dim); pref.ensure(rows * dim);
-        w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(rows);
+        w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(2 * rows); last.ensure(2 * rows);
         cap = rows;
         d = dim;
     }
-    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, w.p, kind.p, key.p, id.p, uid.p, touch.p}; }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, cap}; }
     void swap(TableStore& o)
     {
         std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
@@ -79,6 +79,7 @@ struct TableStore {
         std::swap(w.p, o.w.p); std::swap(w.n, o.w.n); std::swap(kind.p, o.kind.p); std::swap(kind.n, o.kind.n);
         std::swap(key.p, o.key.p); std::swap(key.n, o.key.n); std::swap(id.p, o.id.p); std::swap(id.n, o.id.n);
         std::swap(uid.p, o.uid.p); std::swap(uid.n, o.uid.n); std::swap(touch.p, o.touch.p); std::swap(touch.n, o.touch.n);
+        std::swap(last.p, o.last.p); std::swap(last.n, o.last.n);
         std::swap(cap, o.cap); std::swap(d, o.d);
     }
 };
@@ -214,7 +215,8 @@ void ensure_table(cc_handle* h, size_t rows)
         HIPCHK(hipMemcpyAsync(nt.id.p, o.id.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.uid.p, o.uid.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
     }
-    HIPCHK(hipMemsetAsync(nt.touch.p, 0, want * 8, h->stream));
+    HIPCHK(hipMemsetAsync(nt.touch.p, 0, 2 * want * 8, h->stream));
+    HIPCHK(hipMemsetAsync(nt.last.p, 0, 2 * want * 8, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->tab.swap(nt);
 }
@@ -539,8 +541,8 @@ int cc_online_run(cc_handle* h)
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
             const Table tab = h->tab.view();
-            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, tab.touch};
-            const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next, tab.touch};
+            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
+            const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
             for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
@@ -764,7 +766,12 @@ int cc_decay_downgrade(cc_handle* h, double factor)
             perm[np + i] = r; nkind[np + i] = CC_KIND_OUTLIER; nkey[np + i] = i;
             nid[np + i] = downgraded[r] ? uid[r] : id[r];  // hddstream.py:535
         }
-        if (h->tab2.cap < h->tab.cap || h->tab2.d != d) h->tab2.alloc(h->tab.cap, d);
+        if (h->tab2.cap < h->tab.cap || h->tab2.d != d) {
+            h->tab2.alloc(h->tab.cap, d);
+            // stamps are compared with atomic max: fresh memory must not hold anything that looks newer
+            HIPCHK(hipMemsetAsync(h->tab2.touch.p, 0, 2 * h->tab2.cap * 8, h->stream));
+            HIPCHK(hipMemsetAsync(h->tab2.last.p, 0, 2 * h->tab2.cap * 8, h->stream));
+        }
         DevBuf<int> dperm, dkind, dkey;
         DevBuf<long long> dnid;
         dperm.ensure(n); dkind.ensure(n); dkey.ensure(n); dnid.ensure(n);

@@ -31,7 +31,13 @@ struct Table {
     int* key;      // [cap]  position in its Python list (pcore_MC or outlier_MC) as an order key
     long long* id;   // [cap]  current id (pcore id or outlier id)
     long long* uid;  // [cap]  prev_outlier_id = creation number
-    unsigned long long* touch;  // [cap]  (stamp << 20 | first toucher) of the current validation round
+    // Validation stamps, written by k_decide with atomic max for the round that follows it:
+    //   touch = stamp << 20 | (0xFFFFF - first window point that targets this MC)
+    //   last  = stamp << 20 | last window point that targets this MC
+    // Two copies each, indexed by round parity: round r reads copy r & 1 while k_decide fills copy (r + 1) & 1.
+    unsigned long long* touch;  // [2][cap]
+    unsigned long long* last;   // [2][cap]
+    size_t cap;                 // rows allocated (offset of the second copy)
 };
 
 // Version rows of the current window: row j = state of point j's target microcluster right after point j
@@ -60,7 +66,6 @@ struct Rows {
     const int* kind;
     const int* key;
     const int* next;  // only for version rows
-    const unsigned long long* touch;  // table stamps (dirty scan prologue)
 };
 
 struct Ctl {

@@ -50,7 +50,8 @@ __global__ void k_gather_rows(Table src, Table dst, const int* perm, const int* 
         dst.kind[e] = nkind[e];
         dst.key[e] = nkey[e];
         dst.id[e] = nid[e];
-        dst.touch[e] = 0ull;
+        dst.touch[e] = 0ull; dst.touch[dst.cap + e] = 0ull;
+        dst.last[e] = 0ull; dst.last[dst.cap + e] = 0ull;
     }
 }
 

@@ -500,8 +500,8 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     for (int kd = 0; kd < 2; ++kd) {
         const Cand c1 = clean[(size_t)j * 4 + kd * 2];
         if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
-        const unsigned long long tc = tab.touch[c1.slot];
-        const int head = (int)(tc & 0xFFFFFull);
+        const unsigned long long tc = tab.touch[(size_t)(round & 1) * tab.cap + c1.slot];
+        const int head = 0xFFFFF - (int)(tc & 0xFFFFFull);
         if ((tc >> 20) != stamp || head >= j) {
             cap[kd] = c1.dist;  // c1 is clean at j
             continue;
@@ -603,8 +603,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     auto dirty = [&](int slot) -> bool {
         if (round == 0) return false;
-        const unsigned long long t = tab.touch[slot];
-        return (t >> 20) == stamp && (int)(t & 0xFFFFFull) < j;
+        const unsigned long long t = tab.touch[(size_t)(round & 1) * tab.cap + slot];
+        return (t >> 20) == stamp && (0xFFFFF - (int)(t & 0xFFFFFull)) < j;
     };
 
     const int M0 = ctl->m_rows;
@@ -659,6 +659,14 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
+        if (T != CC_T_UNKNOWN) {
+            // first / last point of this window that targets T, for the round that replays these claims
+            // (provisional ids of new MCs index the free rows behind the table)
+            const unsigned long long sn = (stamp + 1ull) << 20;
+            const size_t wr = (size_t)((round + 1) & 1) * tab.cap + (size_t)T;  // the copy the next round reads
+            atomicMax(&tab.touch[wr], sn | (unsigned long long)(0xFFFFF - j));
+            atomicMax(&tab.last[wr], sn | (unsigned long long)j);
+        }
     }
 }
 
@@ -716,20 +724,13 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     }
     // sT is padded to a multiple of 128 entries with a sentinel, so the 16-byte reads below stay in range
     const int4* sT4 = reinterpret_cast<const int4*>(sT);
-    for (int base = 0; base < j; base += 512) {  // 4 x 128 entries per ballot (reads past j are masked by i < j)
-        bool m = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int b2 = base + u * 128;
-            if (b2 < Bpad) {
-                const int i = b2 + gl * 4;
-                const int4 v = sT4[(b2 >> 2) + gl];
-                m = m || (i < j && v.x == t) || (i + 1 < j && v.y == t) || (i + 2 < j && v.z == t) ||
-                    (i + 3 < j && v.w == t);
-            }
-        }
-        if (cc_group_ballot(m)) return;  // an earlier point heads this chain and walks over j
-    }
+    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    // k_decide recorded the first and the last window point that target t: the first one heads the chain and
+    // walks it; everybody else is walked over
+    const size_t rd = (size_t)(round & 1) * tab.cap + (size_t)t;
+    const unsigned long long ft = tab.touch[rd], lt = tab.last[rd];
+    if ((ft >> 20) != stamp || 0xFFFFF - (int)(ft & 0xFFFFFull) != j) return;
+    const int last_j = ((lt >> 20) == stamp) ? (int)(lt & 0xFFFFFull) : j;
 
     const Par par = cc_load_par(ctl);
     const int d = par.d;
@@ -738,8 +739,6 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const int pk_base = ctl->n_pkeys;
     const bool isnew = t >= M0;
     const bool valid_chain = !isnew || (t == M0 + j);  // a claim on a MC nobody creates any more is void
-    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
-    if (!isnew && gl == 0) tab.touch[t] = (stamp << 20) | (unsigned long long)j;
 
     // this lane's two dimensions of the chain's running state stay in registers from step to step
     double bc1[2] = {0.0, 0.0}, bc2[2] = {0.0, 0.0}, bce[2] = {0.0, 0.0}, bpr[2] = {1.0, 1.0};
@@ -767,7 +766,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     }
     while (true) {
         int nx = CC_IDX_INF;
-        for (int base = (cur + 1) & ~127; base < B; base += 128) {
+        for (int base = (cur + 1) & ~127; base <= last_j && cur < last_j; base += 128) {
             const int i = base + gl * 4;
             const int4 v = sT4[(base >> 2) + gl];
             const unsigned mm = ((i > cur && v.x == t) ? 1u : 0u) | ((i + 1 > cur && v.y == t) ? 2u : 0u) |
