@@ -235,6 +235,57 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         }
         CC_WAVE_SYNC();
 
+        if (!DIRTY) {
+            // Clean scan: a lean row loop.  Rows run to the last dimension (the second-best bound is never tight
+            // enough to drop a row early on 64 unrelated points: measured), so there are no exit checks; the only
+            // per-row work besides the 4 * DP fp64 operations is one comparison against the second-best.
+            for (int m = 0; m < tm; ++m) {
+                const int kind = __builtin_amdgcn_readfirstlane(s_kind_w[m]);
+                double acc[PT];
+#pragma unroll
+                for (int t = 0; t < PT; ++t) acc[t] = 0.0;
+#pragma unroll
+                for (int i = 0; i < DP; ++i) {
+                    const double c = s_c_base[m * DP + i];
+                    const double sc = s_s_base[m * DP + i];
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        double x = p[t][i] - c;       // mc_functions.py:37
+                        x = x * x;                    // :38
+                        x = POW2 ? x * sc : x / sc;   // :39
+                        acc[t] = acc[t] + x;          // :41, left to right
+                    }
+                }
+                const int rowg = rt + m;
+                const int key = s_key_w[m];
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    const double b2 = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
+                    if (!(valid[t] && acc[t] <= b2)) continue;
+                    auto consider = [&](auto KC) {
+                        constexpr int K = decltype(KC)::value;
+                        if (!cand_less(acc[t], key, bd[K][t][1], bk[K][t][1])) return;
+                        if (K == 0 && filter) {
+                            // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                            int ne1 = 0;
+                            cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
+                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
+                            if (ne1 > par.pi) return;
+                        }
+                        if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
+                            bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
+                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowg;
+                        } else {
+                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowg;
+                        }
+                    };
+                    if (kind == 0) consider(std::integral_constant<int, 0>{});
+                    else if (kind == 1) consider(std::integral_constant<int, 1>{});
+                }
+            }
+            continue;
+        }
+
         // The dirty scan (few waves, early exit after 4 dimensions) takes two MC rows per iteration: two
         // independent accumulation chains hide each other's latency.  The clean scan mostly runs rows to the end,
         // where pairing only adds work, and takes one.
