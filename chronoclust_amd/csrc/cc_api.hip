@@ -58,7 +58,7 @@ struct DevBuf {
 };
 
 struct TableStore {
-    DevBuf<double> cf1, cf2, cen, pref, w;
+    DevBuf<double> cf1, cf2, cen, pref, scl, w;
     DevBuf<int> kind, key;
     DevBuf<long long> id, uid;
     DevBuf<unsigned long long> touch, last;
@@ -67,15 +67,17 @@ struct TableStore {
     void alloc(size_t rows, int dim)
     {
         cf1.ensure(rows * dim); cf2.ensure(rows * dim); cen.ensure(rows * dim); pref.ensure(rows * dim);
+        scl.ensure(rows * dim);
         w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(2 * rows); last.ensure(2 * rows);
         cap = rows;
         d = dim;
     }
-    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, cap}; }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, cap}; }
     void swap(TableStore& o)
     {
         std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
         std::swap(cen.p, o.cen.p); std::swap(cen.n, o.cen.n); std::swap(pref.p, o.pref.p); std::swap(pref.n, o.pref.n);
+        std::swap(scl.p, o.scl.p); std::swap(scl.n, o.scl.n);
         std::swap(w.p, o.w.p); std::swap(w.n, o.w.n); std::swap(kind.p, o.kind.p); std::swap(kind.n, o.kind.n);
         std::swap(key.p, o.key.p); std::swap(key.n, o.key.n); std::swap(id.p, o.id.p); std::swap(id.n, o.id.n);
         std::swap(uid.p, o.uid.p); std::swap(uid.n, o.uid.n); std::swap(touch.p, o.touch.p); std::swap(touch.n, o.touch.n);
@@ -114,7 +116,7 @@ struct cc_handle {
 
     // window buffers
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
-    DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_w;
+    DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_scl, v_w;
     DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
     DevBuf<Cand> part, clean, dpart, dseed;
     DevBuf<int> T0, T1, rk;
@@ -209,6 +211,7 @@ void ensure_table(cc_handle* h, size_t rows)
         HIPCHK(hipMemcpyAsync(nt.cf2.p, o.cf2.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.cen.p, o.cen.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.pref.p, o.pref.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(nt.scl.p, o.scl.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.w.p, o.w.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.kind.p, o.kind.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(nt.key.p, o.key.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -238,7 +241,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     win = std::max(win, h->win_alloc);
     seg = std::max(seg, h->seg_alloc);
     const size_t w = (size_t)win, d = (size_t)std::max(h->d, h->d_alloc);
-    h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_w.ensure(w);
+    h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_scl.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_tgt.ensure(w);
     h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
@@ -248,7 +251,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
 
 Versions versions_view(cc_handle* h)
 {
-    return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_w.p, h->v_kind.p,
+    return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_scl.p, h->v_w.p, h->v_kind.p,
                     h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p};
 }
 
@@ -519,6 +522,9 @@ int cc_online_run(cc_handle* h)
         for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
         push_ctl(h);
 
+        if (c.m_rows > 0)
+            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
+                               c.m_rows, h->d, c.pow2, c.inv_k);
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
         size_t ev_used = 2;
@@ -541,8 +547,8 @@ int cc_online_run(cc_handle* h)
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
             const Table tab = h->tab.view();
-            const Rows trows{tab.cen, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
-            const Rows vrows{ver.cen, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
+            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
+            const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
             for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);

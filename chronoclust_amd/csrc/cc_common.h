@@ -26,6 +26,7 @@ struct Table {
     double* cf2;   // [cap, d]
     double* cen;   // [cap, d]  stored centroid (NOT recomputed after decay, hddstream.py:283-286)
     double* pref;  // [cap, d]  1.0 or k
+    double* scl;   // [cap, d]  the operand the distance uses: 1/pref when k is a power of two, else pref
     double* w;     // [cap]
     int* kind;     // [cap]  CC_KIND_*
     int* key;      // [cap]  position in its Python list (pcore_MC or outlier_MC) as an order key
@@ -47,6 +48,7 @@ struct Versions {
     double* cf2;
     double* cen;
     double* pref;
+    double* scl;
     double* w;
     int* kind;
     int* key;
@@ -59,6 +61,7 @@ struct Versions {
 // Read-only view the scan kernel walks (either the table or the version rows).
 struct Rows {
     const double* cen;
+    const double* scl;   // distance operand per dimension (see Table::scl)
     const double* pref;
     const double* cf1;
     const double* cf2;

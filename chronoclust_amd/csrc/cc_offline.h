@@ -30,6 +30,15 @@ __global__ void k_downgrade_flags(Table tab, int m_rows, int d, double beta_mu, 
     flags[r] = ((w < beta_mu || cnt > pi) ? 1 : 0) | ((w <= omicron) ? 2 : 0);
 }
 
+// scl column from pref (run before every online phase: covers injected rows and parameter changes)
+__global__ void k_rebuild_scl(Table tab, int m_rows, int d, int pow2, double inv_k)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= m_rows * d) return;
+    const double pr = tab.pref[e];
+    tab.scl[e] = pow2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
+}
+
 // dst row i <- src row perm[i]; kind / key / id are rewritten from the host-computed lists
 __global__ void k_gather_rows(Table src, Table dst, const int* perm, const int* nkind, const int* nkey,
                               const long long* nid, int n, int d)
@@ -42,6 +51,7 @@ __global__ void k_gather_rows(Table src, Table dst, const int* perm, const int* 
         dst.cf2[e] = src.cf2[s];
         dst.cen[e] = src.cen[s];
         dst.pref[e] = src.pref[s];
+        dst.scl[e] = src.scl[s];
     }
     if (e < n) {
         const int s = perm[e];

@@ -216,17 +216,28 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
         if (tm == 0) break;
         CC_WAVE_SYNC();
-        for (int e = lane; e < tm * DP; e += 64) {
-            const int m = e / DP, i = e - m * DP;
-            double c = 0.0, s = 1.0;
-            if (i < d) {
-                const size_t g = (size_t)(rt + m) * d + i;
-                c = rows.cen[g];
-                const double pr = rows.pref[g];
-                s = POW2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
+        {
+            // the tile is one contiguous block of tm * d doubles per column: a straight copy, all loads of the
+            // tile in flight before the first LDS store (LDS row stride = d; dimensions d..DP-1 are never read)
+            constexpr int NL = (CC_SCAN_TM * DP + 63) / 64;
+            const double* gc = rows.cen + (size_t)rt * d;
+            const double* gs = rows.scl + (size_t)rt * d;
+            double tc[NL], ts[NL];
+            // LDS rows are DP doubles long (compile-time stride); when d < DP the padding holds (0, 1): zero terms
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;  // index into the padded tile
+                const int m = e / DP, i = e - m * DP;
+                const bool in = (m < tm) && (i < d);
+                const int ge = m * d + i;     // index into the contiguous global block (== e when d == DP)
+                tc[q] = in ? gc[ge] : 0.0;
+                ts[q] = in ? gs[ge] : 1.0;
             }
-            s_c_base[m * DP + i] = c;
-            s_s_base[m * DP + i] = s;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;
+                if (e < CC_SCAN_TM * DP) { s_c_base[e] = tc[q]; s_s_base[e] = ts[q]; }
+            }
         }
         if (lane < tm) {
             s_kind_w[lane] = rows.kind[rt + lane];
@@ -244,10 +255,12 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                 double acc[PT];
 #pragma unroll
                 for (int t = 0; t < PT; ++t) acc[t] = 0.0;
+                const double* rc = s_c_base + m * DP;
+                const double* rs = s_s_base + m * DP;
 #pragma unroll
                 for (int i = 0; i < DP; ++i) {
-                    const double c = s_c_base[m * DP + i];
-                    const double sc = s_s_base[m * DP + i];
+                    const double c = rc[i];
+                    const double sc = rs[i];
 #pragma unroll
                     for (int t = 0; t < PT; ++t) {
                         double x = p[t][i] - c;       // mc_functions.py:37
@@ -868,6 +881,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 if (i < d) {
                     ver.cf1[(size_t)cur * d + i] = bc1[h]; ver.cf2[(size_t)cur * d + i] = bc2[h];
                     ver.cen[(size_t)cur * d + i] = bce[h]; ver.pref[(size_t)cur * d + i] = bpr[h];
+                    ver.scl[(size_t)cur * d + i] = par.pow2 ? (bpr[h] == 1.0 ? 1.0 : par.inv_k) : bpr[h];
                 }
             }
             if (gl == 0) {
@@ -1002,6 +1016,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
         tab.cf2[row * d + i] = ver.cf2[(size_t)j * d + i];
         tab.cen[row * d + i] = ver.cen[(size_t)j * d + i];
         tab.pref[row * d + i] = ver.pref[(size_t)j * d + i];
+        tab.scl[row * d + i] = ver.scl[(size_t)j * d + i];
         if (i == 0) {
             tab.w[row] = ver.w[j];
             tab.kind[row] = ver.kind[j];
