@@ -116,7 +116,8 @@ struct cc_handle {
 
     // window buffers
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
-    DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_scl, v_w;
+    DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_scl, v_w, v_dsq, v_tau;
+    DevBuf<unsigned long long> v_tile_dsq;
     DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
     DevBuf<Cand> part, clean, dpart, dseed;
     DevBuf<int> T0, T1, rk;
@@ -243,6 +244,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     const size_t w = (size_t)win, d = (size_t)std::max(h->d, h->d_alloc);
     h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_scl.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
+    h->v_dsq.ensure(w); h->v_tau.ensure(w); h->v_tile_dsq.ensure(w / 16 + 2);
     h->v_tgt.ensure(w);
     h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
@@ -252,7 +254,8 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
 Versions versions_view(cc_handle* h)
 {
     return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_scl.p, h->v_w.p, h->v_kind.p,
-                    h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p};
+                    h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p, h->v_dsq.p, h->v_tile_dsq.p,
+                    h->v_tau.p};
 }
 
 // ---- scan dispatch over the padded dimensionality ---------------------------------
@@ -547,8 +550,9 @@ int cc_online_run(cc_handle* h)
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
             const Table tab = h->tab.view();
-            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr};
-            const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next};
+            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr};
+            const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
+                             ver.tile_dsq, ver.tau};
             for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);

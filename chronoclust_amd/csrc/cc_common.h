@@ -56,6 +56,11 @@ struct Versions {
     int* upg;   // index of the window point whose add promoted the microcluster, or -1
     int* acc;   // 1 if point j was absorbed (radius test passed or new microcluster)
     int* tgt;   // target id of the chain this row belongs to
+    // squared displacement of the version's centroid from its MC's window-start centroid, in the window-start
+    // metric; +inf for MCs created or promoted inside the window (k_chain).  tile_dsq[i / 16] = max over 16 rows.
+    double* dsq;
+    unsigned long long* tile_dsq;
+    double* tau;  // per window point: a version with sqrt(dsq) below this cannot matter to it (k_dseed)
 };
 
 // Read-only view the scan kernel walks (either the table or the version rows).
@@ -69,6 +74,8 @@ struct Rows {
     const int* kind;
     const int* key;
     const int* next;  // only for version rows
+    const unsigned long long* tile_dsq;  // only for version rows (see Versions)
+    const double* tau;                   // only for version rows
 };
 
 struct Ctl {

@@ -146,7 +146,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const int sub = blockIdx.y * NW + wv;
     // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
     const int nrows = DIRTY ? min(B, j0 + 64 * PT - 1) : ctl->m_rows;
-    const int per = (nrows + nsub - 1) / nsub;
+    // dirty scan: sub-ranges are whole 16-row tiles so that the per-tile displacement maxima line up
+    const int per = DIRTY ? (((nrows + nsub - 1) / nsub + CC_SCAN_TM - 1) / CC_SCAN_TM) * CC_SCAN_TM
+                          : (nrows + nsub - 1) / nsub;
     const int r0 = sub * per;
     const int r1 = min(nrows, r0 + per);
     const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
@@ -211,10 +213,28 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         }
     }
 
+    // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave
+    double wave_tau = -CC_INF;
+    if (DIRTY) {
+        wave_tau = CC_INF;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double tj = valid[t] ? rows.tau[jj[t]] : CC_INF;
+            wave_tau = tj < wave_tau ? tj : wave_tau;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(wave_tau, off);
+            wave_tau = o < wave_tau ? o : wave_tau;
+        }
+    }
     for (int tt = 0; tt < ntiles; ++tt) {
         const int rt = r0 + tt * CC_SCAN_TM;
         const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
         if (tm == 0) break;
+        if (DIRTY) {
+            const double tdq = __longlong_as_double((long long)rows.tile_dsq[rt >> 4]);
+            if (tdq < CC_INF && sqrt(tdq) * (1.0 + 1e-9) < wave_tau) continue;  // nothing in this tile can matter
+        }
         CC_WAVE_SYNC();
         {
             // the tile is one contiguous block of tm * d doubles per column: a straight copy, all loads of the
@@ -559,26 +579,27 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     const bool filter = par.filter != 0;
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     const double* p = X + (ctl->cursor + j) * d;
-    Cand first[2] = {Cand{CC_INF, CC_IDX_INF, -1}, Cand{CC_INF, CC_IDX_INF, -1}};
+    Cand first0 = Cand{CC_INF, CC_IDX_INF, -1}, first1 = Cand{CC_INF, CC_IDX_INF, -1};
     double cap[2] = {CC_INF, CC_INF};
-    for (int kd = 0; kd < 2; ++kd) {
-        const Cand c1 = clean[(size_t)j * 4 + kd * 2];
-        if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
-        const unsigned long long tc = tab.touch[(size_t)(round & 1) * tab.cap + c1.slot];
+    bool provable = par.k > 0.0;  // false: some live version of a list MC could not be located -> no pruning
+    const double K = par.k >= 1.0 ? par.k : 1.0 / par.k;  // worst-case ratio of a dimension's weight before / after
+
+    // the live version of MC `slot` when point j arrives (-1: untouched so far, -2: not found in 16 steps)
+    auto live_version = [&](int slot) -> int {
+        const unsigned long long tc = tab.touch[(size_t)(round & 1) * tab.cap + slot];
         const int head = 0xFFFFF - (int)(tc & 0xFFFFFull);
-        if ((tc >> 20) != stamp || head >= j) {
-            cap[kd] = c1.dist;  // c1 is clean at j
-            continue;
-        }
-        cap[kd] = clean[(size_t)j * 4 + kd * 2 + 1].dist;
+        if ((tc >> 20) != stamp || head >= j) return -1;
         int v = head;
         for (int steps = 0; ver.next[v] < j; ++steps) {
             v = ver.next[v];
-            if (steps >= 16) { v = -1; break; }
+            if (steps >= 16) return -2;
         }
-        if (v < 0) continue;
+        return v;
+    };
+    // exact distance of point j to version row v; enters the first-candidate slot of the version's kind
+    auto seed_version = [&](int v) {
         const int kv = ver.kind[v];
-        if (kv == CC_KIND_DEAD) continue;
+        if (kv == CC_KIND_DEAD) return;
         double acc = 0.0;
         for (int i = 0; i < d; ++i) {
             double x = p[i] - ver.cen[(size_t)v * d + i];
@@ -588,19 +609,64 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         if (kv == 0 && filter) {
             int ne1 = 0;
             cc_tentative_radius(ver.cf1 + (size_t)v * d, ver.cf2 + (size_t)v * d, ver.w[v], p, d, par, nullptr, &ne1);
-            if (ne1 > par.pi) continue;
+            if (ne1 > par.pi) return;
         }
         const int key = ver.key[v];
         if (kv == 0) {
-            if (cand_less(acc, key, first[0].dist, first[0].key)) first[0] = Cand{acc, key, v};
+            if (cand_less(acc, key, first0.dist, first0.key)) first0 = Cand{acc, key, v};
         } else {
-            if (cand_less(acc, key, first[1].dist, first[1].key)) first[1] = Cand{acc, key, v};
+            if (cand_less(acc, key, first1.dist, first1.key)) first1 = Cand{acc, key, v};
+        }
+    };
+
+    double d2v[2] = {CC_INF, CC_INF};
+    bool have1[2] = {false, false};
+    for (int kd = 0; kd < 2; ++kd) {
+        const Cand c1 = clean[(size_t)j * 4 + kd * 2];
+        const Cand c2 = clean[(size_t)j * 4 + kd * 2 + 1];
+        if (c2.slot >= 0) d2v[kd] = c2.dist;
+        if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
+        have1[kd] = true;
+        const int v1 = live_version(c1.slot);
+        if (v1 == -1) cap[kd] = c1.dist;  // c1 is clean at j: a live version has to beat c1 itself
+        else {
+            cap[kd] = d2v[kd];
+            if (v1 >= 0) seed_version(v1);
+            else provable = false;
+        }
+        if (c2.slot >= 0) {
+            const int v2 = live_version(c2.slot);
+            if (v2 >= 0) seed_version(v2);
+            else if (v2 == -2) provable = false;
         }
     }
+    seed[(size_t)j * 4 + 0] = first0;
+    seed[(size_t)j * 4 + 1] = Cand{cap[0], 0, 0};
+    seed[(size_t)j * 4 + 2] = first1;
+    seed[(size_t)j * 4 + 3] = Cand{cap[1], 0, 0};
+
+    // Pruning threshold.  Let v be a live version of a MC s that is in neither list of its kind for this point and
+    // was of that kind at window start: its window-start distance is >= d2.  Weighted norms obey the triangle
+    // inequality and a dimension's weight changes by at most the factor K, so
+    //     dist_v >= (sqrt(d2) - sqrt(dsq_v))^2 / K,
+    // and v cannot beat `cap` (or the seeded candidate, whichever is smaller) when
+    //     sqrt(dsq_v) < sqrt(d2) - sqrt(K * cap).
+    // Live versions of the list MCs themselves are seeded above.  With the pdim filter on, pcore MCs outside the
+    // list may be closer than d2 (they were filtered out), so nothing is pruned for that kind.
+    double tau = CC_INF;
     for (int kd = 0; kd < 2; ++kd) {
-        seed[(size_t)j * 4 + kd * 2] = first[kd];
-        seed[(size_t)j * 4 + kd * 2 + 1] = Cand{cap[kd], 0, 0};
+        double t;
+        if (kd == 0 && filter) t = -CC_INF;
+        else if (!have1[kd]) t = CC_INF;  // no MC of this kind at window start: its versions have dsq = +inf
+        else {
+            const double fb = (kd == 0) ? first0.dist : first1.dist;
+            const double ce = fb < cap[kd] ? fb : cap[kd];
+            t = (d2v[kd] == CC_INF) ? CC_INF : (sqrt(d2v[kd]) - sqrt(K * ce));
+        }
+        tau = t < tau ? t : tau;
     }
+    if (!provable) tau = -CC_INF;
+    ver.tau[j] = (tau == CC_INF) ? CC_INF : tau * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
 }
 
 // ---------------------------------------------------------------------------------
@@ -723,6 +789,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
+        if ((j & 15) == 0) ver.tile_dsq[j >> 4] = 0ull;  // the next k_chain takes maxima into it
         if (T != CC_T_UNKNOWN) {
             // first / last point of this window that targets T, for the round that replays these claims
             // (provisional ids of new MCs index the free rows behind the table)
@@ -819,6 +886,10 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         }
         bw = tab.w[t]; bkind = tab.kind[t]; bkey = tab.key[t];
     }
+    // window-start centroid and metric of this MC, for the displacement of its versions
+    const double c0[2] = {bce[0], bce[1]};
+    const double w0[2] = {1.0 / bpr[0], 1.0 / bpr[1]};
+    const int kind0 = bkind;
     int cur = j;
     double px[2] = {0.0, 0.0};  // this lane's two dimensions of point `cur`
     if (valid_chain) {
@@ -884,10 +955,22 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                     ver.scl[(size_t)cur * d + i] = par.pow2 ? (bpr[h] == 1.0 ? 1.0 : par.inv_k) : bpr[h];
                 }
             }
+            // squared displacement from the window-start centroid in the window-start metric (any summation order:
+            // it only feeds a conservative bound); +inf when no bound exists (new MC, promoted inside the window)
+            double dq = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const double df = bce[h] - c0[h];
+                dq += df * df * w0[h];
+            }
+            for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
+            if (isnew || bkind != kind0 || !(dq >= 0.0)) dq = CC_INF;
             if (gl == 0) {
                 ver.w[cur] = bw;
                 ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
                 ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
+                ver.dsq[cur] = dq;
+                atomicMax(&ver.tile_dsq[cur >> 4], (unsigned long long)__double_as_longlong(dq));
             }
         }
         if (nx == CC_IDX_INF) break;
