@@ -368,7 +368,7 @@ int cc_create(int device, cc_handle** out)
         h->ctl.ensure(1);
         h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
-        h->tun.window = 4096;
+        h->tun.window = 8192;
         h->tun.rounds = 3;
         h->tun.segments = 128;
         h->tun.windows_per_sync = 16;
@@ -402,7 +402,7 @@ const char* cc_last_error(const cc_handle* h) { return h ? h->err.c_str() : "nul
 int cc_set_tuning(cc_handle* h, const cc_tuning* t)
 {
     if (!h || !t) return CC_ERR_BAD_ARG;
-    if (t->window > 0) h->tun.window = std::min(t->window, 8192);
+    if (t->window > 0) h->tun.window = std::min(t->window, 16384);
     if (t->rounds > 0) h->tun.rounds = std::min(t->rounds, CC_MAX_ROUNDS);
     if (t->segments > 0) h->tun.segments = std::min(t->segments, 1024);
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;

@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const long long n_points = ctl->n_points;
     const int win_cfg = ctl->win_cfg;
 
-    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 8192
+    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 16384
     const int per = (B + 1023) >> 10;  // points per thread
-    int loc[8];
+    int loc[16];
     int mine = 0;
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
