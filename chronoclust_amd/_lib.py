@@ -27,7 +27,7 @@ class CcParams(C.Structure):
 class CcTuning(C.Structure):
     _fields_ = [("window", C.c_int32), ("rounds", C.c_int32), ("segments", C.c_int32),
                 ("windows_per_sync", C.c_int32), ("time_kernels", C.c_int32), ("dirty_segments", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("early_window", C.c_int32), ("points_per_lane", C.c_int32)]
 
 
 class CcStats(C.Structure):
@@ -133,9 +133,9 @@ class Handle(object):
         return rc
 
     def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0, dirty_segments=0,
-                   points_per_lane=0):
-        t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels, dirty_segments)
-        t.reserved[0] = int(points_per_lane)
+                   points_per_lane=0, early_window=0):
+        t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels, dirty_segments, int(early_window),
+                     int(points_per_lane))
         self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
 
     def reset(self):

@@ -272,7 +272,7 @@ void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* p
     constexpr int NW = ScanWaves<DP>::value;
     // points per lane: 2 for the clean scan at small d (more independent work per staged MC row), else 1
     constexpr int PT = (!DIRTY && DP <= 20) ? 2 : 1;
-    const bool pt2 = PT == 2 && h->tun.reserved[0] == 2;  // measured 10 % slower on C2: off unless asked for
+    const bool pt2 = PT == 2 && h->tun.points_per_lane == 2;  // measured 10 % slower on C2: off unless asked for
     const dim3 block(64 * NW);
     if (pt2) {
         const dim3 grid((win + 64 * PT - 1) / (64 * PT), S);
@@ -408,7 +408,8 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
     h->tun.time_kernels = t->time_kernels;
     if (t->dirty_segments > 0) h->tun.dirty_segments = std::min(t->dirty_segments, 1024);
-    h->tun.reserved[0] = t->reserved[0];  // 2: two points per lane in the clean scan (A/B switch)
+    h->tun.points_per_lane = t->points_per_lane;
+    if (t->early_window > 0) h->tun.early_window = t->early_window;
     return CC_OK;
 }
 
@@ -513,8 +514,9 @@ int cc_online_run(cc_handle* h)
         Ctl& c = h->hc;
         c.cursor = 0;
         c.n_points = N;
-        c.win_cfg = win;
-        c.win_b = (int)std::min<long long>(win, N);
+        const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
+        c.win_cfg = (c.m_rows == 0) ? std::min(win, early0) : win;
+        c.win_b = (int)std::min<long long>(c.win_cfg, N);
         c.max_rounds = R;
         c.last_round = 0;
         c.fc[0] = 0;
@@ -545,6 +547,8 @@ int cc_online_run(cc_handle* h)
         // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
         const int Rmax = R;
         int Rcur = R;
+        long long rows_prev = c.m_rows, cursor_prev = 0;
+        const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
         long long trunc_prev = 0;
         while (done < N) {
@@ -596,6 +600,19 @@ int cc_online_run(cc_handle* h)
                 trunc_prev = h->hc.stat_truncated;
                 if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
                 else Rcur = std::max(1, std::min(Rcur, used));
+            }
+            {
+                // While many MCs are being created the validation of a window is quadratic in its size (their
+                // versions cannot be pruned): shorter windows there, the configured size once the table is stable.
+                const long long grew = (long long)h->hc.m_rows - rows_prev, pts = h->hc.cursor - cursor_prev;
+                rows_prev = h->hc.m_rows;
+                cursor_prev = h->hc.cursor;
+                const int want = (pts > 0 && grew * 50 > pts) ? std::min(win, early_win) : win;
+                if (want != h->hc.win_cfg && done < N) {
+                    h->hc.win_cfg = want;
+                    h->hc.win_b = (int)std::min<long long>(want, N - done);
+                    push_ctl(h);
+                }
             }
         }
         HIPCHK(hipEventRecord(ev1, h->stream));

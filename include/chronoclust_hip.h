@@ -77,7 +77,8 @@ typedef struct cc_tuning {
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */
     int32_t time_kernels;    /* 1: bracket every scan launch with HIP events     */
     int32_t dirty_segments;  /* sub-ranges of the version-row scan (0: = segments)*/
-    int32_t reserved[2];
+    int32_t early_window;    /* window while the table grows fast (0: 4096)       */
+    int32_t points_per_lane; /* 2: two points per lane in the clean scan (A/B)    */
 } cc_tuning;
 
 typedef struct cc_stats {
