@@ -177,6 +177,33 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     for (int t = 0; t < PT; ++t) {
         jj[t] = j0 + t * 64 + lane;
         valid[t] = jj[t] < B;
+    }
+    // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave; when that
+    // rules out every tile of the sub-range the wave only hands its seeds on and never loads its points
+    double wave_tau = -CC_INF;
+    bool any_tile = true;
+    if (DIRTY) {
+        wave_tau = CC_INF;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const double tj = valid[t] ? rows.tau[jj[t]] : CC_INF;
+            wave_tau = tj < wave_tau ? tj : wave_tau;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(wave_tau, off);
+            wave_tau = o < wave_tau ? o : wave_tau;
+        }
+        any_tile = false;
+        for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+            const double tdq = __longlong_as_double((long long)rows.tile_dsq[rt >> 4]);
+            if (!(tdq < CC_INF && sqrt(tdq) * (1.0 + 1e-9) < wave_tau)) any_tile = true;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[t][i] = 0.0;
+        if (!any_tile) continue;
         // Xt is the dimension-major copy of the points: consecutive lanes read consecutive doubles
         const double* xp = Xt + cursor + (valid[t] ? jj[t] : 0);
 #pragma unroll
@@ -213,20 +240,6 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         }
     }
 
-    // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave
-    double wave_tau = -CC_INF;
-    if (DIRTY) {
-        wave_tau = CC_INF;
-#pragma unroll
-        for (int t = 0; t < PT; ++t) {
-            const double tj = valid[t] ? rows.tau[jj[t]] : CC_INF;
-            wave_tau = tj < wave_tau ? tj : wave_tau;
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o = __shfl_xor(wave_tau, off);
-            wave_tau = o < wave_tau ? o : wave_tau;
-        }
-    }
     for (int tt = 0; tt < ntiles; ++tt) {
         const int rt = r0 + tt * CC_SCAN_TM;
         const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
