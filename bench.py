@@ -156,8 +156,8 @@ def main():
                            "fp64_valu": {"algorithmic_top_s": 4.0 * pair_dims / secs / 1e12,
                                          "peak_top_s": FP64_VALU_PEAK_TOPS,
                                          "frac": 4.0 * pair_dims / secs / 1e12 / FP64_VALU_PEAK_TOPS,
-                                         "note": "4 non-FMA fp64 ops per (point, microcluster, dim); brute-force "
-                                                 "count, the kernel's exact early exit skips part of it"}}
+                                         "note": "4 non-FMA fp64 ops per (point, microcluster, dim): sub, mul, "
+                                                 "mul, add in the reference's order; every pair runs all dims"}}
     if "roofline" in out:
         # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
         # separate runs, profiles/r01_pmc_traffic.json); only quoted when it was measured on this workload shape
