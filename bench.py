@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=150_000)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
     args = ap.parse_args()
 
     from chronoclust_amd import multi
@@ -72,8 +74,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        if args.share_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from chronoclust_amd import _lib
     n, d, g = args.points, args.dim, args.blobs
@@ -114,7 +121,7 @@ def main():
         online_ms += s["run_ms"]
     sync()
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda")
+    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
     uid, _ = h.labels_download()
 
     if rank != 0:
