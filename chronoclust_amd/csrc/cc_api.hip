@@ -105,7 +105,9 @@ struct cc_handle {
     TableStore tab, tab2;
     Ctl hc{};  // host mirror of the device control block
     DevBuf<Ctl> ctl;
-    bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
+    bool tainted = false;
+    int adapt_win = 0;      // window size the last call settled at (0: none yet)
+    int clean_batches = 0;  // consecutive batches without a truncated window  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -515,7 +517,9 @@ int cc_online_run(cc_handle* h)
         c.cursor = 0;
         c.n_points = N;
         const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
-        c.win_cfg = (c.m_rows == 0) ? std::min(win, early0) : win;
+        // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
+        if (h->adapt_win > 0) c.win_cfg = std::min(win, h->adapt_win);
+        else c.win_cfg = (c.m_rows < 1024) ? std::min(win, 256) : std::min(win, early0);
         c.win_b = (int)std::min<long long>(c.win_cfg, N);
         c.max_rounds = R;
         c.last_round = 0;
@@ -547,7 +551,9 @@ int cc_online_run(cc_handle* h)
         // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
         const int Rmax = R;
         int Rcur = R;
-        long long rows_prev = c.m_rows, cursor_prev = 0;
+        long long rows_prev = c.m_rows, cursor_prev = 0, windows_prev = 0, trunc_batch = 0;
+        bool first_batch = true;
+        int batch_windows = std::max(2, h->tun.windows_per_sync / 4);
         const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
         long long trunc_prev = 0;
@@ -557,7 +563,7 @@ int cc_online_run(cc_handle* h)
             const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr};
             const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
                              ver.tile_dsq, ver.tau};
-            for (int wv = 0; wv < h->tun.windows_per_sync; ++wv) {
+            for (int wv = 0; wv < batch_windows; ++wv) {
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
                     HIPCHK(hipEventRecord(a, h->stream));
@@ -598,21 +604,42 @@ int cc_online_run(cc_handle* h)
                 }
                 const long long trunc = h->hc.stat_truncated - trunc_prev;
                 trunc_prev = h->hc.stat_truncated;
+                trunc_batch = trunc;
                 if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
                 else Rcur = std::max(1, std::min(Rcur, used));
             }
             {
-                // While many MCs are being created the validation of a window is quadratic in its size (their
-                // versions cannot be pruned): shorter windows there, the configured size once the table is stable.
+                // Window size for the next batch.
+                //  - While many MCs are being created the validation of a window is quadratic in its size (their
+                //    versions cannot be pruned): at most `early_win` there, the configured size once the table is stable.
+                //  - When windows commit short of their size (few MCs, overlapping data: the validation frontier stops
+                //    early) the speculated remainder is wasted: aim at the average committed length; grow back
+                //    by doubling while nothing is truncated.
                 const long long grew = (long long)h->hc.m_rows - rows_prev, pts = h->hc.cursor - cursor_prev;
+                const long long wins = h->hc.stat_windows - windows_prev;
                 rows_prev = h->hc.m_rows;
                 cursor_prev = h->hc.cursor;
-                const int want = (pts > 0 && grew * 50 > pts) ? std::min(win, early_win) : win;
+                windows_prev = h->hc.stat_windows;
+                const int target = (pts > 0 && grew * 50 > pts) ? std::min(win, early_win) : win;
+                int want = h->hc.win_cfg;
+                if (trunc_batch > 0 && wins > 0) {
+                    const long long avg = pts / wins;
+                    want = (int)std::min<long long>(target, std::max<long long>(128, ((avg + 63) / 64) * 64));
+                    h->clean_batches = 0;
+                } else if (++h->clean_batches >= 2 || want < 1024) {
+                    want = std::min(target, std::max(want, 64) * 2);
+                }
+                want = std::min(want, target);
+                h->adapt_win = want;
                 if (want != h->hc.win_cfg && done < N) {
                     h->hc.win_cfg = want;
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
                     push_ctl(h);
                 }
+                // settle quickly at the start of a call and whenever windows are being truncated
+                batch_windows = (trunc_batch > 0 || first_batch) ? std::max(2, h->tun.windows_per_sync / 4)
+                                                                 : h->tun.windows_per_sync;
+                first_batch = false;
             }
         }
         HIPCHK(hipEventRecord(ev1, h->stream));
