@@ -272,27 +272,22 @@ template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part, int S, int round)
 {
     constexpr int NW = ScanWaves<DP>::value;
-    // points per lane: 2 for the clean scan at small d (more independent work per staged MC row), else 1
-    constexpr int PT = (!DIRTY && DP <= 20) ? 2 : 1;
-    const bool pt2 = PT == 2 && h->tun.points_per_lane == 2;  // measured 10 % slower on C2: off unless asked for
     const dim3 block(64 * NW);
-    if (pt2) {
-        const dim3 grid((win + 64 * PT - 1) / (64 * PT), S);
-        if (h->hc.pow2)
-            hipLaunchKernelGGL((k_scan<DP, PT, true, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p,
-                               rows, clean, part, round);
-        else
-            hipLaunchKernelGGL((k_scan<DP, PT, false, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p,
-                               h->Xt.p, rows, clean, part, round);
-        return;
-    }
     const dim3 grid((win + 63) / 64, S);
-    if (h->hc.pow2)
-        hipLaunchKernelGGL((k_scan<DP, 1, true, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows,
-                           clean, part, round);
-    else
-        hipLaunchKernelGGL((k_scan<DP, 1, false, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p,
-                           rows, clean, part, round);
+    // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
+    // survive its pruning) tests the flag at run time
+    const bool filter = DIRTY || h->hc.filter != 0;
+#define CC_LAUNCH_SCAN(F, P)                                                                                      \
+    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows, \
+                       clean, part, round)
+    if (filter) {
+        if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
+        else CC_LAUNCH_SCAN(true, false);
+    } else if constexpr (!DIRTY) {
+        if (h->hc.pow2) CC_LAUNCH_SCAN(false, true);
+        else CC_LAUNCH_SCAN(false, false);
+    }
+#undef CC_LAUNCH_SCAN
 }
 
 // S = partials per point (workgroups per point tile); sub-ranges per tile = S * waves per workgroup

@@ -114,6 +114,21 @@ __device__ __forceinline__ void cc_top2_push(Cand& a, Cand& b, const Cand& x)
     a.slot = beats_a ? x.slot : a.slot;
 }
 
+// v_min_f64 / v_max_f64 as plain selections (the operands are never NaN here; the library fmin / fmax would
+// add a canonicalising instruction per operand)
+__device__ __forceinline__ double cc_vmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double cc_vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---------------------------------------------------------------------------------
 // k_scan: points (one or PT per lane, in registers) x MC rows (wave-uniform, staged in LDS)
 // ---------------------------------------------------------------------------------
@@ -126,13 +141,14 @@ __device__ __forceinline__ void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 // are split into gridDim.y * NW sub-ranges; each wave streams its sub-range through its own LDS tile
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
-template <int DP, int PT, bool POW2, bool DIRTY, int NW>
+template <int DP, bool FILTER, bool POW2, bool DIRTY, int NW>
 __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
                                                              Cand* __restrict__ part, int round)
 {
+    constexpr int PT = 1;  // window points per lane (two measured 10 % slower on C2)
     const int B = ctl->win_b;
     if (B == 0) return;
     if (DIRTY && ctl->fc[round - 1] >= B) return;  // already at a fixed point
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     if (j0 >= B) return;
     const int d = ctl->d;
     const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
     const int S = gridDim.y;  // partials per point
     const int nsub = S * NW;
     const int sub = blockIdx.y * NW + wv;
@@ -156,7 +172,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const size_t n_pts = (size_t)ctl->n_points;
     const Par par = cc_load_par(ctl);
     const double inv_k = par.inv_k;
-    const bool filter = par.filter != 0;
+    // FILTER = false: the host knows that the pdim filter of hddstream.py:317-321 is vacuous (pi >= d)
+    const bool filter = FILTER && par.filter != 0;
 
     // LDS: per-wave tiles while scanning, then (same bytes) the candidate exchange of the final merge
     constexpr int TILE_DOUBLES = NW * CC_SCAN_TM * DP;
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         for (int t = 0; t < PT; ++t) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                bd[kd][t][r] = CC_INF;
+                bd[kd][t][r] = (DIRTY || valid[t]) ? CC_INF : -CC_INF;
                 bk[kd][t][r] = CC_IDX_INF;
                 bs[kd][t][r] = -1;
             }
@@ -242,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
 
     for (int tt = 0; tt < ntiles; ++tt) {
         const int rt = r0 + tt * CC_SCAN_TM;
-        const int tm = max(0, min(CC_SCAN_TM, r1 - rt));
+        const int tm = __builtin_amdgcn_readfirstlane(max(0, min(CC_SCAN_TM, r1 - rt)));
         if (tm == 0) break;
         if (DIRTY) {
             const double tdq = __longlong_as_double((long long)rows.tile_dsq[rt >> 4]);
@@ -272,22 +289,28 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                 if (e < CC_SCAN_TM * DP) { s_c_base[e] = tc[q]; s_s_base[e] = ts[q]; }
             }
         }
-        if (lane < tm) {
+        // kinds of the tile's rows as two wave-uniform bit masks (clean scan) / LDS columns (dirty scan)
+        unsigned pmask = 0, omask = 0;
+        if (!DIRTY) {
+            const int kd = (lane < tm) ? rows.kind[rt + lane] : CC_KIND_DEAD;
+            pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
+            omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
+        } else if (lane < tm) {
             s_kind_w[lane] = rows.kind[rt + lane];
             s_key_w[lane] = rows.key[rt + lane];
-            s_next_w[lane] = DIRTY ? rows.next[rt + lane] : 0;
+            s_next_w[lane] = rows.next[rt + lane];
         }
         CC_WAVE_SYNC();
 
         if (!DIRTY) {
             // Clean scan: a lean row loop.  Rows run to the last dimension (the second-best bound is never tight
-            // enough to drop a row early on 64 unrelated points: measured), so there are no exit checks; the only
-            // per-row work besides the 4 * DP fp64 operations is one comparison against the second-best.
+            // enough to drop a row early on 64 unrelated points: measured), so there are no exit checks.  The
+            // running best-two hold (distance, row) only; while no distance of the wave equals a held one the
+            // update is pure selection (min / max and three selects).  Exact ties - the only place where the
+            // list-order keys decide (hddstream.py:326/373: strict `<`, first in list order wins) - and the pdim
+            // filter take the general path, which fetches the keys it needs.
             for (int m = 0; m < tm; ++m) {
-                const int kind = __builtin_amdgcn_readfirstlane(s_kind_w[m]);
                 double acc[PT];
-#pragma unroll
-                for (int t = 0; t < PT; ++t) acc[t] = 0.0;
                 const double* rc = s_c_base + m * DP;
                 const double* rs = s_s_base + m * DP;
 #pragma unroll
@@ -299,35 +322,55 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                         double x = p[t][i] - c;       // mc_functions.py:37
                         x = x * x;                    // :38
                         x = POW2 ? x * sc : x / sc;   // :39
-                        acc[t] = acc[t] + x;          // :41, left to right
+                        // :41, left to right; the terms are >= +0, so 0.0 + x is x and the first one starts the sum
+                        acc[t] = (i == 0) ? x : acc[t] + x;
                     }
                 }
                 const int rowg = rt + m;
-                const int key = s_key_w[m];
+                auto update = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
 #pragma unroll
-                for (int t = 0; t < PT; ++t) {
-                    const double b2 = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
-                    if (!(valid[t] && acc[t] <= b2)) continue;
-                    auto consider = [&](auto KC) {
-                        constexpr int K = decltype(KC)::value;
-                        if (!cand_less(acc[t], key, bd[K][t][1], bk[K][t][1])) return;
+                    for (int t = 0; t < PT; ++t) {
+                        const double a = acc[t];
+                        double& d0 = bd[K][t][0];
+                        double& d1 = bd[K][t][1];
+                        int& s0 = bs[K][t][0];
+                        int& s1 = bs[K][t][1];
+                        // (lanes without a point hold -inf and never enter; no wave-level skip: with the few rows a
+                        // wave sees, some lane enters on almost every row, and straight-line code updates in place)
+                        bool ins = a < d1;    // enters the pair
+                        bool first = a < d0;  // ... as its first element
+                        const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                        const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                        if ((e1 | e0) != 0ull) {
+                            if (a == d1 || a == d0) {
+                                const int key = rows.key[rowg];
+                                if (a == d1) ins = key < (s1 >= 0 ? rows.key[s1] : CC_IDX_INF);
+                                if (a == d0) first = key < (s0 >= 0 ? rows.key[s0] : CC_IDX_INF);
+                            }
+                        }
                         if (K == 0 && filter) {
-                            // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
-                            int ne1 = 0;
-                            cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
-                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
-                            if (ne1 > par.pi) return;
-                        }
-                        if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
-                            bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
-                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowg;
+                            if (ins) {
+                                // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                                int ne1 = 0;
+                                cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
+                                                    rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
+                                if (ne1 > par.pi) ins = false;
+                            }
+                            first = first && ins;
+                            d1 = first ? d0 : (ins ? a : d1);
+                            d0 = first ? a : d0;
                         } else {
-                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowg;
+                            // every row enters on distance alone: the distances of the pair are a plain selection
+                            d1 = cc_vmin(d1, cc_vmax(d0, a));
+                            d0 = cc_vmin(d0, a);
                         }
-                    };
-                    if (kind == 0) consider(std::integral_constant<int, 0>{});
-                    else if (kind == 1) consider(std::integral_constant<int, 1>{});
-                }
+                        s1 = first ? s0 : (ins ? rowg : s1);
+                        s0 = first ? rowg : s0;
+                    }
+                };
+                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
             }
             continue;
         }
@@ -444,6 +487,15 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         }
     }
 
+    if (!DIRTY) {
+        // the clean scan kept (distance, row) only: the list-order keys of the survivors
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) bk[kd][t][r] = bs[kd][t][r] >= 0 ? rows.key[bs[kd][t][r]] : CC_IDX_INF;
+    }
     // merge the waves' candidates through LDS; wave 0 writes the workgroup's partial
     Cand* const s_m = reinterpret_cast<Cand*>(smem);  // [NW - 1][PT][4][64], reuses the tile bytes
     auto s_m_at = [&](int w, int t, int c) -> Cand& { return s_m[((w * PT + t) * 4 + c) * 64 + lane]; };
