@@ -105,9 +105,11 @@ struct cc_handle {
     TableStore tab, tab2;
     Ctl hc{};  // host mirror of the device control block
     DevBuf<Ctl> ctl;
-    bool tainted = false;
+    bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
-    int clean_batches = 0;  // consecutive batches without a truncated window  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
+    int clean_batches = 0;  // consecutive batches without a truncated window
+    int since_shrink = 1000;  // batches since the window was last shrunk
+    bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -370,6 +372,8 @@ int cc_create(int device, cc_handle** out)
         h->tun.segments = 128;
         h->tun.windows_per_sync = 16;
         h->tun.time_kernels = 0;
+        const char* tr = getenv("CHRONOCLUST_HIP_TRACE");
+        h->trace = tr && tr[0] == '1';
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -617,12 +621,19 @@ int cc_online_run(cc_handle* h)
                 windows_prev = h->hc.stat_windows;
                 const int target = (pts > 0 && grew * 50 > pts) ? std::min(win, early_win) : win;
                 int want = h->hc.win_cfg;
-                if (trunc_batch > 0 && wins > 0) {
+                if (trunc_batch * 4 >= wins && trunc_batch > 0) {
+                    // a quarter or more of the windows stopped short: the window is too long for this data
                     const long long avg = pts / wins;
                     want = (int)std::min<long long>(target, std::max<long long>(128, ((avg + 63) / 64) * 64));
                     h->clean_batches = 0;
-                } else if (++h->clean_batches >= 2 || want < 1024) {
-                    want = std::min(target, std::max(want, 64) * 2);
+                    h->since_shrink = 0;
+                } else {
+                    // an occasional short window (one more validation round needed than enqueued) is no reason to
+                    // shrink; grow by doubling after one clean batch, after two if a shrink is recent
+                    ++h->since_shrink;
+                    if (trunc_batch == 0) ++h->clean_batches;
+                    const int need = (h->since_shrink > 8 || want < 1024) ? 1 : 2;
+                    if (trunc_batch == 0 && h->clean_batches >= need) want = std::min(target, std::max(want, 64) * 2);
                 }
                 want = std::min(want, target);
                 h->adapt_win = want;
@@ -631,9 +642,12 @@ int cc_online_run(cc_handle* h)
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
                     push_ctl(h);
                 }
+                if (h->trace)
+                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld | next window %d rounds %d\n",
+                            done, h->hc.m_rows, wins, pts, trunc_batch, want, Rcur);
                 // settle quickly at the start of a call and whenever windows are being truncated
-                batch_windows = (trunc_batch > 0 || first_batch) ? std::max(2, h->tun.windows_per_sync / 4)
-                                                                 : h->tun.windows_per_sync;
+                batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
+                                                                                  : h->tun.windows_per_sync;
                 first_batch = false;
             }
         }
