@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=0)
     ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--lookahead", type=int, default=0, help="0/1 on (default), 2 off, 3 forced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=150_000)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -87,7 +88,7 @@ def main():
     X = make_blobs(multi.stream_seed(42, rank), n, d, g)
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
-    h.set_tuning(window=args.window, rounds=args.rounds, segments=args.segments,
+    h.set_tuning(window=args.window, rounds=args.rounds, segments=args.segments, lookahead=args.lookahead,
                  time_kernels=0 if args.no_kernel_timing else 1)
     set_params(h, cfg, n, d)
     h.points_upload(X)  # inputs are resident in HBM before the timed region
@@ -145,7 +146,8 @@ def main():
         "config": {"workload": "C2: 1 timepoint, %dx%d synthetic blobs (seed 42+rank), %d microclusters; "
                                "exact sequential semantics; online + offline phases per step" % (n, d, g),
                    "points": n, "dim": d, "microclusters": int(s["rows"]), "clusters": n_clusters,
-                   "streams": world, "window": args.window or 8192, "windows_per_step": int(s["windows"]),
+                   "streams": world, "window": args.window or 12288, "windows_per_step": int(s["windows"]),
+                   "lookahead_windows_per_step": int(s["lookahead_windows"]),
                    "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
         "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,
     }

@@ -61,7 +61,8 @@ struct TableStore {
     DevBuf<double> cf1, cf2, cen, pref, scl, w;
     DevBuf<int> kind, key;
     DevBuf<long long> id, uid;
-    DevBuf<unsigned long long> touch, last;
+    DevBuf<unsigned long long> touch, last, carry_of, cnt;
+    DevBuf<int> memb;
     size_t cap = 0;
     int d = 0;
     void alloc(size_t rows, int dim)
@@ -69,10 +70,11 @@ struct TableStore {
         cf1.ensure(rows * dim); cf2.ensure(rows * dim); cen.ensure(rows * dim); pref.ensure(rows * dim);
         scl.ensure(rows * dim);
         w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(2 * rows); last.ensure(2 * rows);
+        carry_of.ensure(rows); cnt.ensure(rows); memb.ensure(rows * CC_CHAIN_MEMB);
         cap = rows;
         d = dim;
     }
-    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, cap}; }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, carry_of.p, cnt.p, memb.p, cap}; }
     void swap(TableStore& o)
     {
         std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
@@ -82,6 +84,8 @@ struct TableStore {
         std::swap(key.p, o.key.p); std::swap(key.n, o.key.n); std::swap(id.p, o.id.p); std::swap(id.n, o.id.n);
         std::swap(uid.p, o.uid.p); std::swap(uid.n, o.uid.n); std::swap(touch.p, o.touch.p); std::swap(touch.n, o.touch.n);
         std::swap(last.p, o.last.p); std::swap(last.n, o.last.n);
+        std::swap(carry_of.p, o.carry_of.p); std::swap(carry_of.n, o.carry_of.n);
+        std::swap(cnt.p, o.cnt.p); std::swap(cnt.n, o.cnt.n); std::swap(memb.p, o.memb.p); std::swap(memb.n, o.memb.n);
         std::swap(cap, o.cap); std::swap(d, o.d);
     }
 };
@@ -95,6 +99,7 @@ struct HostCluster {
 struct cc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // lookahead scans
     std::string err;
     cc_params par{};
     bool have_par = false;
@@ -122,8 +127,13 @@ struct cc_handle {
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
     DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_scl, v_w, v_dsq, v_tau;
     DevBuf<unsigned long long> v_tile_dsq;
-    DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt;
-    DevBuf<Cand> part, clean, dpart, dseed;
+    DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt, v_skip, v_skip_car;
+    DevBuf<Cand> part, clean, dpart, dpart2, dseed;  // part: two copies (window parity), dpart2: carry-set scan
+    size_t part_stride = 0;
+    // carry set of the previous window (lookahead)
+    DevBuf<double> c_cf1v, c_cf2v, c_cenv, c_prefv, c_sclv, c_wv, c_c0, c_w0, c_dsq;
+    DevBuf<int> c_kind, c_key, c_slot, c_kind0;
+    DevBuf<unsigned long long> c_tile_dsq;
     DevBuf<int> T0, T1, rk;
     DevBuf<CommitRec> rec;
     DevBuf<int8_t> dpath;
@@ -225,6 +235,8 @@ void ensure_table(cc_handle* h, size_t rows)
     }
     HIPCHK(hipMemsetAsync(nt.touch.p, 0, 2 * want * 8, h->stream));
     HIPCHK(hipMemsetAsync(nt.last.p, 0, 2 * want * 8, h->stream));
+    HIPCHK(hipMemsetAsync(nt.carry_of.p, 0, want * 8, h->stream));
+    HIPCHK(hipMemsetAsync(nt.cnt.p, 0, want * 8, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->tab.swap(nt);
 }
@@ -250,16 +262,29 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_dsq.ensure(w); h->v_tau.ensure(w); h->v_tile_dsq.ensure(w / 16 + 2);
     h->v_tgt.ensure(w);
-    h->part.ensure(w * seg * 4); h->dpart.ensure(w * seg * 2); h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
-    h->T0.ensure(w); h->T1.ensure(w); h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
+    h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2);
+    h->part_stride = w * seg * 4;
+    h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
+    h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
+    h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
+    h->c_sclv.ensure(w * d); h->c_wv.ensure(w); h->c_c0.ensure(w * d); h->c_w0.ensure(w * d);
+    h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(w / 16 + 2);
+    h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
+    h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
+}
+
+Carry carry_view(cc_handle* h)
+{
+    return Carry{h->c_cf1v.p, h->c_cf2v.p, h->c_cenv.p, h->c_prefv.p, h->c_sclv.p, h->c_wv.p, h->c_kind.p, h->c_key.p,
+                 h->c_slot.p, h->c_c0.p, h->c_w0.p, h->c_kind0.p, h->c_dsq.p, h->c_tile_dsq.p};
 }
 
 Versions versions_view(cc_handle* h)
 {
     return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_scl.p, h->v_w.p, h->v_kind.p,
                     h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p, h->v_dsq.p, h->v_tile_dsq.p,
-                    h->v_tau.p};
+                    h->v_tau.p, h->v_skip.p, h->v_skip_car.p};
 }
 
 // ---- scan dispatch over the padded dimensionality ---------------------------------
@@ -271,7 +296,8 @@ struct ScanWaves {
 };
 
 template <int DP, bool DIRTY>
-void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part, int S, int round)
+void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
+                    int mode)
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
@@ -279,9 +305,9 @@ void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* p
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;
-#define CC_LAUNCH_SCAN(F, P)                                                                                      \
-    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, h->stream, h->ctl.p, h->X.p, h->Xt.p, rows, \
-                       clean, part, round)
+#define CC_LAUNCH_SCAN(F, P)                                                                                   \
+    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
+                       part, round, mode, h->part_stride)
     if (filter) {
         if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
         else CC_LAUNCH_SCAN(true, false);
@@ -292,18 +318,21 @@ void launch_scan_dp(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* p
 #undef CC_LAUNCH_SCAN
 }
 
-// S = partials per point (workgroups per point tile); sub-ranges per tile = S * waves per workgroup
+// S = partials per point (workgroups per point tile); sub-ranges per tile = S * waves per workgroup.
+// Clean scan: mode 0 = current window, 1 = lookahead (round = parity of that window's sequence number);
+// dirty scan: mode 0 = version rows, 1 = carry set.
 template <bool DIRTY>
-void launch_scan(cc_handle* h, int win, Rows rows, const Cand* clean, Cand* part, int S, int round)
+void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
+                 int mode)
 {
     const int d = h->d;
-    if (d <= 4) launch_scan_dp<4, DIRTY>(h, win, rows, clean, part, S, round);
-    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, win, rows, clean, part, S, round);
-    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, win, rows, clean, part, S, round);
-    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, win, rows, clean, part, S, round);
-    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, win, rows, clean, part, S, round);
-    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, win, rows, clean, part, S, round);
-    else launch_scan_dp<64, DIRTY>(h, win, rows, clean, part, S, round);
+    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
 }
 
 int scan_waves_for_dim(int) { return 4; }
@@ -363,13 +392,18 @@ int cc_create(int device, cc_handle** out)
     if (!h) return CC_ERR_OOM;
     h->device = device;
     int rc = guarded(h, [&]() {
-        HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        // the validation kernels (first stream) are short latency chains, the lookahead scans (second stream) fill the
+        // machine: when both have workgroups pending the validation ones go first
+        int prio_lo = 0, prio_hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
         h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
-        h->tun.window = 8192;
+        h->tun.window = 12288;
         h->tun.rounds = 3;
-        h->tun.segments = 128;
+        h->tun.segments = 64;
         h->tun.windows_per_sync = 16;
         h->tun.time_kernels = 0;
         const char* tr = getenv("CHRONOCLUST_HIP_TRACE");
@@ -394,6 +428,10 @@ void cc_destroy(cc_handle* h)
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
     }
+    if (h->stream2) {
+        (void)hipStreamSynchronize(h->stream2);
+        (void)hipStreamDestroy(h->stream2);
+    }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
 }
@@ -409,7 +447,7 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
     h->tun.time_kernels = t->time_kernels;
     if (t->dirty_segments > 0) h->tun.dirty_segments = std::min(t->dirty_segments, 1024);
-    h->tun.points_per_lane = t->points_per_lane;
+    h->tun.lookahead = t->lookahead;
     if (t->early_window > 0) h->tun.early_window = t->early_window;
     return CC_OK;
 }
@@ -424,6 +462,9 @@ int cc_reset(cc_handle* h)
         c.pcore_last_id = c.outlier_last_id = 0;
         c.cursor = 0;
         h->tainted = false;
+        h->adapt_win = 0;  // an empty table starts with small windows again
+        h->clean_batches = 0;
+        h->since_shrink = 1000;
         h->clusters.clear();
         h->n_core = 0;
         refresh_ctl_params(h);
@@ -504,12 +545,15 @@ int cc_online_run(cc_handle* h)
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
         const int S = std::max(1, h->tun.segments / scan_waves_for_dim(h->d));
-        const int Sd = h->tun.dirty_segments > 0 ? std::max(1, h->tun.dirty_segments / scan_waves_for_dim(h->d)) : S;
+        const int Sd_full = h->tun.dirty_segments > 0 ? std::max(1, h->tun.dirty_segments / scan_waves_for_dim(h->d)) : S;
+        // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
+        // few workgroups per point tile then, the full split while they really run (set per batch below)
+        int Sd = Sd_full;
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
         refresh_ctl_params(h);
-        ensure_window_buffers(h, win, std::max(S, Sd));
+        ensure_window_buffers(h, win, std::max(S, Sd_full));
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * h->tun.windows_per_sync + 1);
 
         Ctl& c = h->hc;
@@ -517,15 +561,39 @@ int cc_online_run(cc_handle* h)
         c.n_points = N;
         const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
+        const int start_small = 256;
         if (h->adapt_win > 0) c.win_cfg = std::min(win, h->adapt_win);
-        else c.win_cfg = (c.m_rows < 1024) ? std::min(win, 256) : std::min(win, early0);
+        else c.win_cfg = std::min(win, (c.m_rows < 1024) ? start_small : early0);
         c.win_b = (int)std::min<long long>(c.win_cfg, N);
         c.max_rounds = R;
         c.last_round = 0;
         c.fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) c.fc[i] = CC_IDX_INF;
         c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
+        c.stat_lookahead = 0;
+        c.stat_tiles = c.stat_dirty_tiles = 0;
         c.stat_table_rows = 0;
+        // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
+        const bool la_forced = h->tun.lookahead == 3;                    // from the first window on, whatever happens (tests)
+        const bool la_enabled = h->tun.lookahead != 2;                   // 0 (default) and 1: while windows commit in full
+        bool la_on = false;
+        auto set_lookahead = [&](bool on) {
+            // (re)start: the current window is a fresh one, the lookahead scan enqueued next covers the one after it
+            la_on = on;
+            c.la_on = on ? 1 : 0;
+            c.mode = 0;
+            c.car_n = 0;
+            const int q = (int)((c.window_seq + 1ull) & 1ull);
+            const long long c1 = c.cursor + c.win_b;
+            const long long left1 = c.n_points - c1;
+            c.la_cursor[q] = c1;
+            c.la_b[q] = (on && left1 > 0) ? (int)std::min<long long>(left1, c.win_cfg) : 0;
+            c.la_rows[q] = c.m_rows;
+            c.la_cursor[q ^ 1] = 0;
+            c.la_b[q ^ 1] = 0;
+            c.la_rows[q ^ 1] = 0;
+        };
+        set_lookahead(la_forced);
         c.stat_pair_rows = 0.0;
         for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
         push_ctl(h);
@@ -540,10 +608,14 @@ int cc_online_run(cc_handle* h)
         const bool timing = h->tun.time_kernels != 0;
 
         const Versions ver = versions_view(h);
-        
+        const Carry car = carry_view(h);
+        hipStream_t sA = h->stream, sB = h->stream2;
+        hipEvent_t evCommit = get_event(h, 2), evScan = get_event(h, 3);
+        ev_used = 4;
+
         const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
         const int cblocks = (win + 7) / 8;
-        const int rblocks = std::min((win * h->d + 255) / 256, 1024);
+        const int rblocks = std::min((win + 7) / 8, 1024);
         long long done = 0;
         int m_known = c.m_rows;
         // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
@@ -552,47 +624,69 @@ int cc_online_run(cc_handle* h)
         int Rcur = R;
         long long rows_prev = c.m_rows, cursor_prev = 0, windows_prev = 0, trunc_batch = 0;
         bool first_batch = true;
-        int batch_windows = std::max(2, h->tun.windows_per_sync / 4);
+        int batch_windows = (c.win_cfg < 1024) ? 2 : std::max(2, h->tun.windows_per_sync / 4);
         const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
-        long long trunc_prev = 0;
+        long long trunc_prev = 0, tiles_prev = 0, dtiles_prev = 0;
+        unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
             const Table tab = h->tab.view();
-            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr};
+            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, nullptr, 0};
             const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
-                             ver.tile_dsq, ver.tau};
-            for (int wv = 0; wv < batch_windows; ++wv) {
-                if (timing) {
-                    hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
-                    HIPCHK(hipEventRecord(a, h->stream));
-                    launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
-                    HIPCHK(hipEventRecord(b, h->stream));
-                    timed.push_back({ev_used, 0.0});
-                    ev_used += 2;
+                             ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, 0};
+            const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
+                             car.tile_dsq, car.dsq, ver.tau, ver.skip_car, car.slot, tab.touch, tab.cap};
+            if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
+            for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
+                auto timed_scan = [&](hipStream_t st, int mode, int round) {
+                    if (timing) {
+                        hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
+                        HIPCHK(hipEventRecord(a, st));
+                        launch_scan<false>(h, st, win, trows, nullptr, h->part.p, S, round, mode);
+                        HIPCHK(hipEventRecord(b, st));
+                        timed.push_back({ev_used, 0.0});
+                        ev_used += 2;
+                    } else {
+                        launch_scan<false>(h, st, win, trows, nullptr, h->part.p, S, round, mode);
+                    }
+                };
+                if (la_on) {
+                    // second stream: the snapshot scan of the window after this one, against the table as the
+                    // previous commit left it, while this window is validated on the first stream
+                    HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
+                    timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
+                    HIPCHK(hipEventRecord(evScan, sB));
+                    launch_scan<false>(h, sA, win, trows, nullptr, h->part.p, S, 0, 0);  // no-op unless this window is fresh
                 } else {
-                    launch_scan<false>(h, win, trows, nullptr, h->part.p, S, 0);
+                    timed_scan(sA, 0, 0);
                 }
-                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
-                                   h->part.p, h->clean.p, h->dpart.p, (const int*)nullptr, h->T0.p, h->dpath.p, S, Sd, 0);
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
+                                   h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
+                                   h->dpath.p, S, Sd, 0);
                 for (int r = 1; r <= Rcur; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
-                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), (size_t)((win + 127) & ~127) * sizeof(int), h->stream,
-                                       h->ctl.p, h->X.p, tab, ver, told, r);
-                    hipLaunchKernelGGL(k_dseed, dim3((win + 63) / 64), dim3(64), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
+                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), 0, sA,
+                                       h->ctl.p, h->X.p, tab, ver, car, told, r);
+                    hipLaunchKernelGGL(k_dseed, dim3((win + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, r);
-                    launch_scan<true>(h, win, vrows, h->dseed.p, h->dpart.p, Sd, r);
-                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, h->stream, h->ctl.p, h->X.p, tab, ver,
-                                       h->part.p, h->clean.p, h->dpart.p, told, tnew, h->dpath.p, S, Sd, r);
+                    launch_scan<true>(h, sA, win, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
+                    if (la_on) launch_scan<true>(h, sA, win, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
+                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
+                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r);
                 }
-                hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, h->stream, h->ctl.p, tab, ver, h->T0.p, h->T1.p,
+                hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                    h->dpath.p, h->lab_uid.p, h->lab_path.p, h->rk.p, h->rec.p);
-                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, h->stream, h->rec.p, tab, ver, h->rk.p,
-                                   h->d);
+                if (la_on) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));  // the lookahead scan reads the table
+                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->d);
+                if (la_on) HIPCHK(hipEventRecord(evCommit, sA));
             }
             HIPCHK(hipGetLastError());
             pull_ctl(h);
+            if (la_on) HIPCHK(hipStreamSynchronize(sB));
+            seq_host = h->hc.window_seq;
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
             {
@@ -619,7 +713,13 @@ int cc_online_run(cc_handle* h)
                 rows_prev = h->hc.m_rows;
                 cursor_prev = h->hc.cursor;
                 windows_prev = h->hc.stat_windows;
-                const int target = (pts > 0 && grew * 50 > pts) ? std::min(win, early_win) : win;
+                //  - The same holds while MCs are being promoted: a promoted MC competes in a list it was not scanned
+                //    for, so the dirty scans run unpruned; the device counts the point tiles whose dirty scan ran.
+                const long long tiles = h->hc.stat_tiles - tiles_prev, dtiles = h->hc.stat_dirty_tiles - dtiles_prev;
+                tiles_prev = h->hc.stat_tiles;
+                dtiles_prev = h->hc.stat_dirty_tiles;
+                const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
+                const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
                 int want = h->hc.win_cfg;
                 if (trunc_batch * 4 >= wins && trunc_batch > 0) {
                     // a quarter or more of the windows stopped short: the window is too long for this data
@@ -633,21 +733,28 @@ int cc_online_run(cc_handle* h)
                     ++h->since_shrink;
                     if (trunc_batch == 0) ++h->clean_batches;
                     const int need = (h->since_shrink > 8 || want < 1024) ? 1 : 2;
-                    if (trunc_batch == 0 && h->clean_batches >= need) want = std::min(target, std::max(want, 64) * 2);
+                    if (trunc_batch == 0 && h->clean_batches >= need)
+                        want = std::min(target, std::max(want, 64) * (want < 1024 ? 4 : 2));  // small windows: fast start
                 }
                 want = std::min(want, target);
                 h->adapt_win = want;
-                if (want != h->hc.win_cfg && done < N) {
+                // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few
+                // overlapping MCs) the scan of a window that then starts elsewhere is wasted
+                Sd = (tiles > 0 && dtiles * 16 < tiles) ? std::max(1, Sd_full / 8) : Sd_full;
+                const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
+                if ((want != h->hc.win_cfg || want_la != la_on) && done < N) {
                     h->hc.win_cfg = want;
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
+                    set_lookahead(want_la);
                     push_ctl(h);
                 }
                 if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld | next window %d rounds %d\n",
-                            done, h->hc.m_rows, wins, pts, trunc_batch, want, Rcur);
+                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld lookahead %lld dirty tiles %lld / %lld | next window %d rounds %d\n",
+                            done, h->hc.m_rows, wins, pts, trunc_batch, (long long)h->hc.stat_lookahead, dtiles, tiles, want, Rcur);
                 // settle quickly at the start of a call and whenever windows are being truncated
                 batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
                                                                                   : h->tun.windows_per_sync;
+                if (want < 1024 && trunc_batch == 0) batch_windows = 2;
                 first_batch = false;
             }
         }
@@ -663,6 +770,7 @@ int cc_online_run(cc_handle* h)
         h->stats.rows = h->hc.m_rows;
         h->stats.scan_pair_dims = h->hc.stat_pair_rows * (double)h->d;
         h->stats.table_rows_scanned = h->hc.stat_table_rows;
+        h->stats.lookahead_windows = h->hc.stat_lookahead;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {
@@ -834,6 +942,8 @@ int cc_decay_downgrade(cc_handle* h, double factor)
             // stamps are compared with atomic max: fresh memory must not hold anything that looks newer
             HIPCHK(hipMemsetAsync(h->tab2.touch.p, 0, 2 * h->tab2.cap * 8, h->stream));
             HIPCHK(hipMemsetAsync(h->tab2.last.p, 0, 2 * h->tab2.cap * 8, h->stream));
+            HIPCHK(hipMemsetAsync(h->tab2.carry_of.p, 0, h->tab2.cap * 8, h->stream));
+            HIPCHK(hipMemsetAsync(h->tab2.cnt.p, 0, h->tab2.cap * 8, h->stream));
         }
         DevBuf<int> dperm, dkind, dkey;
         DevBuf<long long> dnid;

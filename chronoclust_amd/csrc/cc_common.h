@@ -38,7 +38,40 @@ struct Table {
     // Two copies each, indexed by round parity: round r reads copy r & 1 while k_decide fills copy (r + 1) & 1.
     unsigned long long* touch;  // [2][cap]
     unsigned long long* last;   // [2][cap]
+    // Lookahead (see Carry): carry_of = window_seq << 20 | carried index, for the rows the previous window changed
+    unsigned long long* carry_of;  // [cap]
+    // Chain members.  k_decide appends every window point to the list of the MC it targets (arrival order of the
+    // atomics, i.e. unordered): cnt = stamp << 24 | members, memb[16 * row + i] = the first 16 of them.  The point
+    // that heads the chain sorts them (k_chain); longer chains are found by scanning the claims.
+    unsigned long long* cnt;  // [cap]
+    int* memb;                // [cap, 16]
     size_t cap;                 // rows allocated (offset of the second copy)
+};
+
+// Candidate slots >= CC_CAR_BASE refer to carried rows (index = slot - CC_CAR_BASE), below to version rows.
+#define CC_CAR_BASE (1 << 24)
+#define CC_CHAIN_MEMB 16
+
+// Lookahead.  While window W is validated, the snapshot scan of window W + 1 already runs - against the table as
+// it is before W's commit.  What that scan could not see is exactly the set of rows W's commit changes or adds:
+// the carry set.  For W + 1 they are treated like version rows that precede its first point: a carried row is
+// the live state of its MC until a point of W + 1 targets it.  Indexed by W's point index (only the last version
+// of every chain is alive, the rest is CC_KIND_DEAD).  Written by k_commit_b.
+struct Carry {
+    double* cf1;   // [B, d] state as committed
+    double* cf2;
+    double* cen;
+    double* pref;
+    double* scl;
+    double* w;     // [B]
+    int* kind;
+    int* key;      // final list-order key
+    int* slot;     // table row
+    double* c0;    // [B, d] centroid of the row before the commit (= in the snapshot W + 1 was scanned against)
+    double* w0;    // [B, d] 1 / pref of the row before the commit
+    int* kind0;    // kind before the commit; CC_KIND_DEAD: the row did not exist
+    double* dsq;   // [B] squared displacement of the committed centroid from c0 in the w0 metric (see Versions::dsq)
+    unsigned long long* tile_dsq;  // per 16 rows: max of dsq, +inf bits if unbounded
 };
 
 // Version rows of the current window: row j = state of point j's target microcluster right after point j
@@ -61,6 +94,10 @@ struct Versions {
     double* dsq;
     unsigned long long* tile_dsq;
     double* tau;  // per window point: a version with sqrt(dsq) below this cannot matter to it (k_dseed)
+    // per 64-point tile: 1 if no version row (skip) / no carried row (skip_car) can matter to any of its points,
+    // so the dirty scan of the tile is not run and k_decide takes the seeds (k_dseed)
+    int* skip;
+    int* skip_car;
 };
 
 // Read-only view the scan kernel walks (either the table or the version rows).
@@ -75,7 +112,12 @@ struct Rows {
     const int* key;
     const int* next;  // only for version rows
     const unsigned long long* tile_dsq;  // only for version rows (see Versions)
+    const double* dsq;                   // only for version / carried rows: per-row squared displacement
     const double* tau;                   // only for version rows
+    const int* skip;                     // dirty scans: per 64-point tile, 1 = nothing to do (Versions::skip)
+    const int* slot;                     // only for carried rows: table row
+    const unsigned long long* touch;     // only for carried rows: Table::touch
+    size_t cap;                          //                         Table::cap
 };
 
 struct Ctl {
@@ -97,11 +139,22 @@ struct Ctl {
     int filter;  // pi < d: the pdim filter of hddstream.py:317-321 is not vacuous
     int pow2;    // k is a power of two: x / k == x * (1/k) bit for bit
     int pad0;
+    // lookahead
+    int mode;    // current window: 0 = its snapshot scan saw the table as it is (fresh), 1 = as it was one commit earlier
+    int car_n;   // rows of the carry set (= size of the previous window) when mode == 1, else 0
+    int la_on;   // set by the host: lookahead scans are being enqueued
+    int pad1;
+    // the window after the current one, per parity of its window_seq: what its lookahead scan covers
+    long long la_cursor[2];
+    int la_b[2];
+    int la_rows[2];
     // statistics
     long long stat_windows, stat_rounds, stat_truncated;
     long long stat_table_rows;  // sum over windows of the table rows scanned
     double stat_pair_rows;      // sum over windows of (window points x table rows)
     long long round_hist[CC_MAX_ROUNDS + 2];  // windows by the validation round they ended in
+    long long stat_lookahead;  // windows whose snapshot scan ran ahead (mode 1)
+    long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
 };
 
 __host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)

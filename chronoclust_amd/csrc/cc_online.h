@@ -146,14 +146,41 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
-                                                             Cand* __restrict__ part, int round)
+                                                             Cand* __restrict__ part, int round, int mode,
+                                                             size_t part_stride)
 {
     constexpr int PT = 1;  // window points per lane (two measured 10 % slower on C2)
-    const int B = ctl->win_b;
+    // Which window, which rows:
+    //   clean, mode 0: the current window against the table as it is (only if the window has no lookahead scan)
+    //   clean, mode 1: lookahead - the window after the current one (parity `round` of its window_seq), while the
+    //                  current one is being validated; its parameters sit in their own slot of the control block
+    //   dirty, mode 0: the current window against its own version rows
+    //   dirty, mode 1: the current window against the carry set of the previous window (lookahead windows only)
+    int B, m_rows_scan;
+    long long cursor;
+    if (!DIRTY && mode == 1) {
+        const int q = round & 1;
+        B = ctl->la_b[q];
+        m_rows_scan = ctl->la_rows[q];
+        cursor = ctl->la_cursor[q];
+        part += (size_t)q * part_stride;
+    } else {
+        B = ctl->win_b;
+        m_rows_scan = ctl->m_rows;
+        cursor = ctl->cursor;
+        if (!DIRTY) {
+            if (ctl->mode != 0) return;  // this window's snapshot scan ran ahead
+            part += (size_t)(ctl->window_seq & 1ull) * part_stride;
+        }
+    }
     if (B == 0) return;
     if (DIRTY && ctl->fc[round - 1] >= B) return;  // already at a fixed point
+    const bool carried = DIRTY && mode == 1;
+    const int car_n = carried ? ((ctl->mode != 0) ? ctl->car_n : 0) : 0;
+    if (carried && car_n == 0) return;
     const int j0 = blockIdx.x * (64 * PT);
     if (j0 >= B) return;
+    if (DIRTY && rows.skip[blockIdx.x] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
     const int d = ctl->d;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
@@ -161,17 +188,18 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const int nsub = S * NW;
     const int sub = blockIdx.y * NW + wv;
     // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
-    const int nrows = DIRTY ? min(B, j0 + 64 * PT - 1) : ctl->m_rows;
+    // (a carried row matters to every point up to the first one that targets its MC)
+    const int nrows = DIRTY ? (carried ? car_n : min(B, j0 + 64 * PT - 1)) : m_rows_scan;
     // dirty scan: sub-ranges are whole 16-row tiles so that the per-tile displacement maxima line up
     const int per = DIRTY ? (((nrows + nsub - 1) / nsub + CC_SCAN_TM - 1) / CC_SCAN_TM) * CC_SCAN_TM
                           : (nrows + nsub - 1) / nsub;
     const int r0 = sub * per;
     const int r1 = min(nrows, r0 + per);
     const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
-    const long long cursor = ctl->cursor;
     const size_t n_pts = (size_t)ctl->n_points;
     const Par par = cc_load_par(ctl);
     const double inv_k = par.inv_k;
+    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     // FILTER = false: the host knows that the pdim filter of hddstream.py:317-321 is vacuous (pi >= d)
     const bool filter = FILTER && par.filter != 0;
 
@@ -298,7 +326,20 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         } else if (lane < tm) {
             s_kind_w[lane] = rows.kind[rt + lane];
             s_key_w[lane] = rows.key[rt + lane];
-            s_next_w[lane] = rows.next[rt + lane];
+            if (!carried) s_next_w[lane] = rows.next[rt + lane];
+            else if (rows.kind[rt + lane] == CC_KIND_DEAD) s_next_w[lane] = -1;  // not a carried row (no slot either)
+            else {
+                // a carried row is live up to and including the first point of this window that targets its MC
+                const unsigned long long tc = rows.touch[(size_t)(round & 1) * rows.cap + (size_t)rows.slot[rt + lane]];
+                s_next_w[lane] = ((tc >> 20) == stamp) ? (0xFFFFF - (int)(tc & 0xFFFFFull)) : CC_IDX_INF;
+            }
+        }
+        // dirty scan: the rows of the tile that can matter to some point of the wave (the per-tile test above, per row;
+        // while MCs are being created or promoted almost every tile holds a row without a bound, but few rows do)
+        unsigned rowmask = 0xFFFFu;
+        if (DIRTY) {
+            const double rq = (lane < tm) ? rows.dsq[rt + lane] : 0.0;
+            rowmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < tm && !(rq < CC_INF && sqrt(rq) * (1.0 + 1e-9) < wave_tau));
         }
         CC_WAVE_SYNC();
 
@@ -380,8 +421,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         // where pairing only adds work, and takes one.
         constexpr bool RB2 = DIRTY;
         for (int m = 0; m < tm; m += (RB2 ? 2 : 1)) {
-            const int kindA = __builtin_amdgcn_readfirstlane(s_kind_w[m]);
-            const int kindB = (RB2 && m + 1 < tm) ? __builtin_amdgcn_readfirstlane(s_kind_w[m + 1]) : CC_KIND_DEAD;
+            const int kindA = ((rowmask >> m) & 1u) ? __builtin_amdgcn_readfirstlane(s_kind_w[m]) : CC_KIND_DEAD;
+            const int kindB = (RB2 && m + 1 < tm && ((rowmask >> (m + 1)) & 1u))
+                                  ? __builtin_amdgcn_readfirstlane(s_kind_w[m + 1]) : CC_KIND_DEAD;
             double boundA[PT], boundB[PT];
             auto row_bounds = [&](int mm, int kind, double (&bound)[PT]) -> bool {
                 if (kind == CC_KIND_DEAD) {
@@ -396,7 +438,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                     bool a = valid[t];
                     if (DIRTY) {
                         const int nx = __builtin_amdgcn_readfirstlane(s_next_w[mm]);
-                        a = a && rowg < jj[t] && jj[t] <= nx;
+                        a = a && (carried || rowg < jj[t]) && jj[t] <= nx;
                         const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
                         const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
                         bound[t] = b1 < cp ? b1 : cp;
@@ -456,6 +498,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
 
             auto insert_row = [&](int mm, int kind, const double (&acc)[PT], const double (&bound)[PT]) {
                 const int rowg = rt + mm;
+                const int rowc = carried ? CC_CAR_BASE + rowg : rowg;  // what the candidate's slot says
                 const int key = s_key_w[mm];
 #pragma unroll
                 for (int t = 0; t < PT; ++t) {
@@ -473,9 +516,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                         }
                         if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
                             bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
-                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowg;
+                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowc;
                         } else {
-                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowg;
+                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowc;
                         }
                     };
                     if (kind == 0) consider(std::integral_constant<int, 0>{});
@@ -630,15 +673,33 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 // seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
 // ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                              Versions ver, const Cand* __restrict__ clean, Cand* __restrict__ seed,
-                                              int round)
+__global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                              Versions ver, Carry car, const Cand* __restrict__ clean,
+                                              Cand* __restrict__ seed, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= B) return;
+    if (blockIdx.x * blockDim.x >= B) return;
+    const bool la_mode = ctl->mode != 0;
+    // largest displacement of any version row / carried row (the workgroup is one wave)
+    double maxd = 0.0, maxd_car = 0.0;
+    {
+        unsigned long long m = 0ull, mc = 0ull;
+        for (int i = threadIdx.x; i < (B + 15) / 16; i += 64) { const unsigned long long v = ver.tile_dsq[i]; m = v > m ? v : m; }
+        if (la_mode)
+            for (int i = threadIdx.x; i < (ctl->car_n + 15) / 16; i += 64) { const unsigned long long v = car.tile_dsq[i]; mc = v > mc ? v : mc; }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(m, off), oc = __shfl_xor(mc, off);
+            m = o > m ? o : m;
+            mc = oc > mc ? oc : mc;
+        }
+        maxd = __longlong_as_double((long long)m);      // displacements are >= 0: their bit patterns order like the values
+        maxd_car = __longlong_as_double((long long)mc);
+    }
+    double tau_out = CC_INF;  // lanes past the window do not constrain the tile
+    if (j < B) {
     const Par par = cc_load_par(ctl);
     const int d = par.d;
     const bool filter = par.filter != 0;
@@ -649,11 +710,19 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     bool provable = par.k > 0.0;  // false: some live version of a list MC could not be located -> no pruning
     const double K = par.k >= 1.0 ? par.k : 1.0 / par.k;  // worst-case ratio of a dimension's weight before / after
 
-    // the live version of MC `slot` when point j arrives (-1: untouched so far, -2: not found in 16 steps)
+    const unsigned long long wseq = ctl->window_seq;
+    // the live version of MC `slot` when point j arrives (-1: untouched so far, -2: not found in 16 steps,
+    // >= CC_CAR_BASE: the carried row - the previous window changed the MC after this window's snapshot scan)
     auto live_version = [&](int slot) -> int {
         const unsigned long long tc = tab.touch[(size_t)(round & 1) * tab.cap + slot];
         const int head = 0xFFFFF - (int)(tc & 0xFFFFFull);
-        if ((tc >> 20) != stamp || head >= j) return -1;
+        if ((tc >> 20) != stamp || head >= j) {
+            if (la_mode) {
+                const unsigned long long co = tab.carry_of[slot];
+                if ((co >> 20) == wseq) return CC_CAR_BASE + (int)(co & 0xFFFFFull);
+            }
+            return -1;
+        }
         int v = head;
         for (int steps = 0; ver.next[v] < j; ++steps) {
             v = ver.next[v];
@@ -663,20 +732,25 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     };
     // exact distance of point j to version row v; enters the first-candidate slot of the version's kind
     auto seed_version = [&](int v) {
-        const int kv = ver.kind[v];
+        const bool cr = v >= CC_CAR_BASE;
+        const size_t r = (size_t)(cr ? v - CC_CAR_BASE : v);
+        const int kv = cr ? car.kind[r] : ver.kind[r];
         if (kv == CC_KIND_DEAD) return;
+        const double* vcen = (cr ? car.cen : ver.cen) + r * d;
+        const double* vpref = (cr ? car.pref : ver.pref) + r * d;
         double acc = 0.0;
         for (int i = 0; i < d; ++i) {
-            double x = p[i] - ver.cen[(size_t)v * d + i];
+            double x = p[i] - vcen[i];
             x = x * x;
-            acc = acc + cc_div_pref(x, ver.pref[(size_t)v * d + i], par);
+            acc = acc + cc_div_pref(x, vpref[i], par);
         }
         if (kv == 0 && filter) {
             int ne1 = 0;
-            cc_tentative_radius(ver.cf1 + (size_t)v * d, ver.cf2 + (size_t)v * d, ver.w[v], p, d, par, nullptr, &ne1);
+            cc_tentative_radius((cr ? car.cf1 : ver.cf1) + r * d, (cr ? car.cf2 : ver.cf2) + r * d,
+                                cr ? car.w[r] : ver.w[r], p, d, par, nullptr, &ne1);
             if (ne1 > par.pi) return;
         }
-        const int key = ver.key[v];
+        const int key = cr ? car.key[r] : ver.key[r];
         if (kv == 0) {
             if (cand_less(acc, key, first0.dist, first0.key)) first0 = Cand{acc, key, v};
         } else {
@@ -731,7 +805,23 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         tau = t < tau ? t : tau;
     }
     if (!provable) tau = -CC_INF;
-    ver.tau[j] = (tau == CC_INF) ? CC_INF : tau * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
+    tau_out = (tau == CC_INF) ? CC_INF : tau * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
+    ver.tau[j] = tau_out;
+    }
+    // the tile as a whole: when even the largest displacement stays below every point's threshold, no row can matter
+    // to any point of the tile and its dirty scan is not run at all (the same test k_scan makes per 16 rows)
+    double tile_tau = tau_out;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(tile_tau, off);
+        tile_tau = o < tile_tau ? o : tile_tau;
+    }
+    if (threadIdx.x == 0) {
+        const int sk = (maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tile_tau) ? 1 : 0;
+        ver.skip[blockIdx.x] = sk;
+        atomicAdd((unsigned long long*)&ctl->stat_tiles, 1ull);
+        if (!sk) atomicAdd((unsigned long long*)&ctl->stat_dirty_tiles, 1ull);
+        ver.skip_car[blockIdx.x] = (!la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tile_tau)) ? 1 : 0;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -740,9 +830,12 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                                Versions ver, const Cand* __restrict__ part, Cand* __restrict__ clean,
-                                                const Cand* __restrict__ dpart, const int* __restrict__ Told,
-                                                int* __restrict__ Tnew, int8_t* __restrict__ dpath, int S, int Sd, int round)
+                                                Versions ver, Carry car, const Cand* __restrict__ part,
+                                                size_t part_stride, Cand* __restrict__ clean,
+                                                const Cand* __restrict__ dpart, const Cand* __restrict__ dpart2,
+                                                const Cand* __restrict__ dseed,
+                                                const int* __restrict__ Told, int* __restrict__ Tnew,
+                                                int8_t* __restrict__ dpath, int S, int Sd, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
@@ -756,7 +849,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
 
     // candidates are kept in named scalars (no runtime-indexed arrays: those would live in scratch memory)
     Cand p1 = none, p2 = none, o1 = none, o2 = none;  // best two pcore / outlier snapshot candidates
+    const unsigned long long wseq = ctl->window_seq;
+    const bool la_mode = ctl->mode != 0;
     if (round == 0) {
+        part += (size_t)(wseq & 1ull) * part_stride;  // the snapshot scan of this window wrote the copy of its parity
         for (int s = gl; s < S; s += 32) {
             const Cand* q = part + ((size_t)j * S + s) * 4;
             cc_top2_push(p1, p2, q[0]);
@@ -783,10 +879,24 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     Cand dvp = none, dvo = none;  // best live version per kind
     if (round > 0) {
         Cand dummy = none;
+        // a dirty scan that k_dseed ruled out for this point's tile was not run: the seeds are its whole result
+        const bool ran = ver.skip[j >> 6] == 0;
+        const bool ran_car = la_mode && ver.skip_car[j >> 6] == 0;
+        if (gl == 0 && !(ran && (ran_car || !la_mode))) {
+            dvp = dseed[(size_t)j * 4 + 0];
+            dvo = dseed[(size_t)j * 4 + 2];
+        }
         for (int s = gl; s < Sd; s += 32) {
-            const Cand* q = dpart + ((size_t)j * Sd + s) * 2;
-            cc_top2_push(dvp, dummy, q[0]);
-            cc_top2_push(dvo, dummy, q[1]);
+            if (ran) {
+                const Cand* q = dpart + ((size_t)j * Sd + s) * 2;
+                cc_top2_push(dvp, dummy, q[0]);
+                cc_top2_push(dvo, dummy, q[1]);
+            }
+            if (ran_car) {  // the carry set is scanned separately
+                const Cand* q2 = dpart2 + ((size_t)j * Sd + s) * 2;
+                cc_top2_push(dvp, dummy, q2[0]);
+                cc_top2_push(dvo, dummy, q2[1]);
+            }
         }
         for (int off = 16; off >= 1; off >>= 1) {
             const Cand b0 = cc_shfl_xor_cand(dvp, off), b1 = cc_shfl_xor_cand(dvo, off);
@@ -796,10 +906,13 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     }
 
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    // the snapshot distance of `slot` no longer describes the MC: a point before j targets it, or (lookahead) the
+    // previous window changed it after the snapshot was scanned
     auto dirty = [&](int slot) -> bool {
         if (round == 0) return false;
         const unsigned long long t = tab.touch[(size_t)(round & 1) * tab.cap + slot];
-        return (t >> 20) == stamp && (0xFFFFF - (int)(t & 0xFFFFFull)) < j;
+        if ((t >> 20) == stamp && (0xFFFFF - (int)(t & 0xFFFFFull)) < j) return true;
+        return la_mode && (tab.carry_of[slot] >> 20) == wseq;
     };
 
     const int M0 = ctl->m_rows;
@@ -834,6 +947,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         if (wkind == 1) {
             bcf1 = tab.cf1 + (size_t)wrow * d; bcf2 = tab.cf2 + (size_t)wrow * d; bw = tab.w[wrow];
             target = wrow;
+        } else if (wrow >= CC_CAR_BASE) {
+            const size_t r = (size_t)(wrow - CC_CAR_BASE);
+            bcf1 = car.cf1 + r * d; bcf2 = car.cf2 + r * d; bw = car.w[r];
+            target = car.slot[r];
         } else {
             bcf1 = ver.cf1 + (size_t)wrow * d; bcf2 = ver.cf2 + (size_t)wrow * d; bw = ver.w[wrow];
             target = ver.tgt[wrow];
@@ -862,6 +979,20 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             const size_t wr = (size_t)((round + 1) & 1) * tab.cap + (size_t)T;  // the copy the next round reads
             atomicMax(&tab.touch[wr], sn | (unsigned long long)(0xFFFFF - j));
             atomicMax(&tab.last[wr], sn | (unsigned long long)j);
+            // ... and the list of all of them (the counter restarts whenever its stamp is an old one)
+            const unsigned long long sc = (stamp + 1ull) << 24;
+            unsigned long long* cw = tab.cnt + T;
+            const unsigned long long old = __hip_atomic_load(cw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int pos = CC_CHAIN_MEMB + 1;
+            if ((old & ~0xFFFFFFull) == sc) {
+                // live counter; one that already says "more than the list holds" needs no further count
+                if ((int)(old & 0xFFFFFFull) <= CC_CHAIN_MEMB) pos = (int)(atomicAdd(cw, 1ull) & 0xFFFFFFull);
+            } else if (atomicCAS(cw, old, sc | 1ull) == old) {
+                pos = 0;  // restarted the counter
+            } else {
+                pos = (int)(atomicAdd(cw, 1ull) & 0xFFFFFFull);  // somebody else of this launch restarted it meanwhile
+            }
+            if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)T * CC_CHAIN_MEMB + pos] = j;
         }
     }
 }
@@ -872,54 +1003,22 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                               Versions ver, const int* __restrict__ T, int round)
+                                               Versions ver, Carry car, const int* __restrict__ T, int round)
 {
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->last_round = round;
-    extern __shared__ __attribute__((aligned(16))) int sT[];
-    const int Bpad = (B + 127) & ~127;
-    {
-        // 16-byte loads, four in flight per thread before the first LDS store (T is 16-byte aligned, Bpad % 4 == 0)
-        const int4* T4 = reinterpret_cast<const int4*>(T);
-        int4* s4 = reinterpret_cast<int4*>(sT);
-        const int n4 = Bpad >> 2;
-        for (int base = 0; base < n4; base += 4 * (int)blockDim.x) {
-            int4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = base + u * (int)blockDim.x + (int)threadIdx.x;
-                v[u] = make_int4(-1000000, -1000000, -1000000, -1000000);
-                if (q < n4) {
-                    if (q * 4 + 3 < B) v[u] = T4[q];
-                    else {
-                        if (q * 4 + 0 < B) v[u].x = T[q * 4 + 0];
-                        if (q * 4 + 1 < B) v[u].y = T[q * 4 + 1];
-                        if (q * 4 + 2 < B) v[u].z = T[q * 4 + 2];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int q = base + u * (int)blockDim.x + (int)threadIdx.x;
-                if (q < n4) s4[q] = v[u];
-            }
-        }
-    }
-    __syncthreads();
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
-    const int t = sT[j];
+    const int t = T[j];
     if (t == CC_T_UNKNOWN) {
         if (gl == 0) {
             ver.kind[j] = CC_KIND_DEAD; ver.next[j] = j; ver.tgt[j] = t; ver.acc[j] = 0; ver.upg[j] = -1;
         }
         return;
     }
-    // sT is padded to a multiple of 128 entries with a sentinel, so the 16-byte reads below stay in range
-    const int4* sT4 = reinterpret_cast<const int4*>(sT);
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     // k_decide recorded the first and the last window point that target t: the first one heads the chain and
     // walks it; everybody else is walked over
@@ -927,6 +1026,27 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const unsigned long long ft = tab.touch[rd], lt = tab.last[rd];
     if ((ft >> 20) != stamp || 0xFFFFF - (int)(ft & 0xFFFFFull) != j) return;
     const int last_j = ((lt >> 20) == stamp) ? (int)(lt & 0xFFFFFull) : j;
+    // the members of the chain: up to CC_CHAIN_MEMB of them were listed by k_decide (unordered) - lane l keeps the
+    // l-th smallest; a longer chain is found by scanning the claims (16-byte loads; the buffer is padded)
+    const unsigned long long cw = tab.cnt[t];
+    const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
+    const bool listed = n_memb <= CC_CHAIN_MEMB;
+    int sorted_memb = CC_IDX_INF;
+    if (listed) {
+        const int mine = (gl < n_memb) ? tab.memb[(size_t)t * CC_CHAIN_MEMB + gl] : CC_IDX_INF;
+        int rank = 0;
+        for (int q = 0; q < n_memb; ++q) rank += (__shfl(mine, q, 32) < mine) ? 1 : 0;
+        // lane l takes the member whose rank is l (ranks are distinct: the members are)
+        for (int q = 0; q < n_memb; ++q) {
+            const int v = __shfl(mine, q, 32), r = __shfl(rank, q, 32);
+            if (r == gl) sorted_memb = v;
+        }
+    }
+    const int4* T4 = reinterpret_cast<const int4*>(T);
+    int step = 0;
+    int blk = -1;  // block of claims held in vb (chains that are not listed)
+    bool have_nb = false;
+    int4 vb = make_int4(0, 0, 0, 0), vn = make_int4(0, 0, 0, 0);
 
     const Par par = cc_load_par(ctl);
     const int d = par.d;
@@ -951,10 +1071,23 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         }
         bw = tab.w[t]; bkind = tab.kind[t]; bkey = tab.key[t];
     }
-    // window-start centroid and metric of this MC, for the displacement of its versions
-    const double c0[2] = {bce[0], bce[1]};
-    const double w0[2] = {1.0 / bpr[0], 1.0 / bpr[1]};
-    const int kind0 = bkind;
+    // centroid, metric and kind of this MC in the snapshot the window was scanned against, for the displacement of
+    // its versions: the table row, unless (lookahead) the previous window changed it after that scan
+    double c0[2] = {bce[0], bce[1]};
+    double w0[2] = {1.0 / bpr[0], 1.0 / bpr[1]};
+    int kind0 = bkind;
+    if (!isnew && ctl->mode != 0) {
+        const unsigned long long co = tab.carry_of[t];
+        if ((co >> 20) == ctl->window_seq) {
+            const size_t r = (size_t)(co & 0xFFFFFull);
+            kind0 = car.kind0[r];  // CC_KIND_DEAD (never a live kind): not in the snapshot -> no bound
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = gl + 32 * h;
+                if (i < d) { c0[h] = car.c0[r * d + i]; w0[h] = car.w0[r * d + i]; }
+            }
+        }
+    }
     int cur = j;
     double px[2] = {0.0, 0.0};  // this lane's two dimensions of point `cur`
     if (valid_chain) {
@@ -966,11 +1099,22 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     }
     while (true) {
         int nx = CC_IDX_INF;
+        ++step;
+        if (listed) nx = (step < n_memb) ? __shfl(sorted_memb, step, 32) : CC_IDX_INF;
+        else
         for (int base = (cur + 1) & ~127; base <= last_j && cur < last_j; base += 128) {
             const int i = base + gl * 4;
-            const int4 v = sT4[(base >> 2) + gl];
-            const unsigned mm = ((i > cur && v.x == t) ? 1u : 0u) | ((i + 1 > cur && v.y == t) ? 2u : 0u) |
-                                ((i + 2 > cur && v.z == t) ? 4u : 0u) | ((i + 3 > cur && v.w == t) ? 8u : 0u);
+            // the 128 claims of a block stay in registers while the chain moves inside it; the following block is
+            // requested as soon as a block is entered, so its latency hides behind the chain steps
+            if (base != blk) {
+                vb = (have_nb && base == blk + 128) ? vn : T4[(base >> 2) + gl];
+                blk = base;
+                have_nb = base + 128 <= last_j;
+                if (have_nb) vn = T4[((base + 128) >> 2) + gl];
+            }
+            const int4 v = vb;
+            const unsigned mm = ((i > cur && i < B && v.x == t) ? 1u : 0u) | ((i + 1 > cur && i + 1 < B && v.y == t) ? 2u : 0u) |
+                                ((i + 2 > cur && i + 2 < B && v.z == t) ? 4u : 0u) | ((i + 3 > cur && i + 3 < B && v.w == t) ? 8u : 0u);
             const unsigned b = cc_group_ballot(mm != 0u);
             if (b) {
                 const int l = __builtin_ctz(b);
@@ -1057,9 +1201,11 @@ struct CommitRec {
     int pk0, ok0; // list-order key bases
     long long pid0, oid0;
     const int* T; // the claims the prefix was validated against
+    int carry;    // 1: the next window is a lookahead window -> k_commit_b also writes the carry set
+    unsigned long long next_seq;  // its window_seq
 };
 
-__global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver,
+__global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver, Carry car,
                                                    const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
                                                    const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
                                                    int8_t* __restrict__ lab_path, int* __restrict__ rk,
@@ -1122,8 +1268,32 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         lab_uid[cursor + j] = (t < M0) ? tab.uid[t] : oid0 + (rk[t - M0] & 0xFFFF);
         lab_path[cursor + j] = (int8_t)(dpath[j] | ((ver.upg[j] == j) ? 4 : 0));
     }
+    // Lookahead: the snapshot scan of the next window is already under way (or done) if the host enqueues such
+    // scans; it is usable when this window committed in full, so that the next one starts where that scan assumed.
+    const unsigned long long seq = ctl->window_seq;
+    const long long next_cursor = cursor + n;
+    const long long left = n_points - next_cursor;
+    const int next_b = (int)(left < (long long)win_cfg ? left : (long long)win_cfg);
+    const int qn = (int)((seq + 1ull) & 1ull);
+    const bool la_ok = ctl->la_on != 0 && n == B && next_b > 0 && ctl->la_b[qn] == next_b &&
+                       ctl->la_cursor[qn] == next_cursor;
+    if (la_ok)
+        for (int i = tid; i < (B + 15) / 16 + 1; i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into it
     if (tid == 0) {
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
+        rec->carry = la_ok ? 1 : 0;
+        rec->next_seq = seq + 1ull;
+        ctl->mode = la_ok ? 1 : 0;
+        ctl->car_n = la_ok ? B : 0;
+        ctl->stat_lookahead += la_ok ? 1 : 0;
+        // what the lookahead scan launched after this commit covers: the window after the next one, assuming the
+        // next one commits in full
+        const int q2 = (int)(seq & 1ull);  // parity of seq + 2
+        const long long c2 = next_cursor + next_b;
+        const long long left2 = n_points - c2;
+        ctl->la_cursor[q2] = c2;
+        ctl->la_b[q2] = (ctl->la_on != 0 && left2 > 0) ? (int)(left2 < (long long)win_cfg ? left2 : (long long)win_cfg) : 0;
+        ctl->la_rows[q2] = M0 + tot_new;
         ctl->m_rows = M0 + tot_new;
         ctl->n_okeys = ok0 + tot_new;
         ctl->outlier_last_id = oid0 + tot_new;
@@ -1137,46 +1307,84 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_table_rows += M0;
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
-        ctl->window_seq += 1;
-        const long long left = n_points - (cursor + n);
-        ctl->win_b = (int)(left < (long long)win_cfg ? left : (long long)win_cfg);
+        ctl->window_seq = seq + 1ull;
+        ctl->win_b = next_b;
         ctl->last_round = 0;
         ctl->fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) ctl->fc[i] = CC_IDX_INF;
     }
 }
 
+// One 32-lane group per point of the validated prefix; the group whose point holds the last version of a MC copies
+// it into the table.  When the next window is a lookahead window (rec->carry) the same rows, together with what
+// the table row held before, become the carry set (see Carry).
 __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ rec, Table tab, Versions ver,
-                                                  const int* __restrict__ rk, int d)
+                                                  Carry car, const int* __restrict__ rk, int d)
 {
     const int n = rec->n;
     if (n == 0) return;
     const int M0 = rec->M0;
     const int* T = rec->T;
-    const int stride = gridDim.x * blockDim.x;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n * d; e += stride) {
-        const int j = e / d, i = e - j * d;
-        if (ver.next[j] < n) continue;  // a later point of the prefix holds the MC's last version
+    const bool carry = rec->carry != 0;
+    const int gl = threadIdx.x & 31;
+    const int groups = (gridDim.x * blockDim.x) >> 5;
+    for (int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; j < n; j += groups) {
+        if (ver.next[j] < n) {  // a later point of the prefix holds the MC's last version
+            if (carry && gl == 0) { car.kind[j] = CC_KIND_DEAD; car.slot[j] = 0; }
+            continue;
+        }
         const int t = T[j];
         const int c = t - M0;
         const size_t row = (t < M0) ? (size_t)t : (size_t)(M0 + (rk[c] & 0xFFFF));
-        tab.cf1[row * d + i] = ver.cf1[(size_t)j * d + i];
-        tab.cf2[row * d + i] = ver.cf2[(size_t)j * d + i];
-        tab.cen[row * d + i] = ver.cen[(size_t)j * d + i];
-        tab.pref[row * d + i] = ver.pref[(size_t)j * d + i];
-        tab.scl[row * d + i] = ver.scl[(size_t)j * d + i];
-        if (i == 0) {
+        const int u = ver.upg[j];
+        const int kind = ver.kind[j];
+        int key;
+        if (u >= 0) key = rec->pk0 + (rk[u] >> 16);
+        else if (t >= M0) key = rec->ok0 + (rk[c] & 0xFFFF);
+        else key = tab.key[row];
+        const int kind0 = (t < M0) ? tab.kind[row] : CC_KIND_DEAD;
+        double dq = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i >= d) continue;
+            const size_t e = row * d + i, v = (size_t)j * d + i;
+            const double ncen = ver.cen[v], npref = ver.pref[v], nscl = ver.scl[v], n1 = ver.cf1[v], n2 = ver.cf2[v];
+            if (carry) {
+                const double oc = (t < M0) ? tab.cen[e] : 0.0;
+                const double ow = (t < M0) ? 1.0 / tab.pref[e] : 0.0;
+                car.c0[v] = oc; car.w0[v] = ow;
+                car.cf1[v] = n1; car.cf2[v] = n2; car.cen[v] = ncen; car.pref[v] = npref; car.scl[v] = nscl;
+                const double df = ncen - oc;
+                dq += df * df * ow;
+            }
+            tab.cf1[e] = n1; tab.cf2[e] = n2; tab.cen[e] = ncen; tab.pref[e] = npref; tab.scl[e] = nscl;
+        }
+        if (carry) {
+            for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
+            if (kind0 == CC_KIND_DEAD || kind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+        }
+        if (gl == 0) {
             tab.w[row] = ver.w[j];
-            tab.kind[row] = ver.kind[j];
-            const int u = ver.upg[j];
+            tab.kind[row] = kind;
             if (u >= 0) {
-                tab.key[row] = rec->pk0 + (rk[u] >> 16);
+                tab.key[row] = key;
                 tab.id[row] = rec->pid0 + (rk[u] >> 16);
             } else if (t >= M0) {
-                tab.key[row] = rec->ok0 + (rk[c] & 0xFFFF);
+                tab.key[row] = key;
                 tab.id[row] = rec->oid0 + (rk[c] & 0xFFFF);
             }
             if (t >= M0) tab.uid[row] = rec->oid0 + (rk[c] & 0xFFFF);
+            if (carry) {
+                car.w[j] = ver.w[j];
+                car.kind[j] = kind;
+                car.key[j] = key;
+                car.slot[j] = (int)row;
+                car.kind0[j] = kind0;
+                car.dsq[j] = dq;
+                atomicMax(&car.tile_dsq[j >> 4], (unsigned long long)__double_as_longlong(dq));
+                tab.carry_of[row] = (rec->next_seq << 20) | (unsigned long long)j;
+            }
         }
     }
 }

@@ -71,14 +71,16 @@ typedef struct cc_params {
 
 /* Tuning knobs of the exact windowed online path (0 = library default). */
 typedef struct cc_tuning {
-    int32_t window;          /* points speculated per window                     */
+    int32_t window;          /* points speculated per window (<= 16384, default 12288) */
     int32_t rounds;          /* max validation rounds per window                 */
     int32_t segments;        /* microcluster-range segments per point tile       */
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */
     int32_t time_kernels;    /* 1: bracket every scan launch with HIP events     */
     int32_t dirty_segments;  /* sub-ranges of the version-row scan (0: = segments)*/
     int32_t early_window;    /* window while the table grows fast (0: 4096)       */
-    int32_t points_per_lane; /* 2: two points per lane in the clean scan (A/B)    */
+    int32_t lookahead;       /* 0 / 1: scan the next window on a second stream
+                              * while this one is validated, as long as windows
+                              * commit in full (default); 2: off; 3: always      */
 } cc_tuning;
 
 typedef struct cc_stats {
@@ -92,7 +94,8 @@ typedef struct cc_stats {
     double  run_ms;          /* HIP-event time of the whole cc_online_run         */
     int64_t rows;            /* microcluster rows in the table after the run     */
     int64_t table_rows_scanned; /* sum over windows of the table rows a scan read  */
-    int64_t reserved[6];
+    int64_t lookahead_windows; /* windows whose snapshot scan ran ahead             */
+    int64_t reserved[5];
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

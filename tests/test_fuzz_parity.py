@@ -47,12 +47,13 @@ def test_fuzz_case(seed):
     from chronoclust_amd.clustering.hddstream import HDDStream
     from oracle import oracle as O
     cfg, window, Xs = _case(seed)
-    h = HDDStream(cfg, tuning=dict(window=window))
+    # lookahead scans: forced from the first window / library default (when windows commit in full) / off
+    h = HDDStream(cfg, tuning=dict(window=window, lookahead=(3, 0, 2)[seed % 3]))
     o = O.OracleHDDStream(cfg)
     for t, X in enumerate(Xs):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
-        ctx = "seed %d t %d cfg %s window %d n %d d %d" % (seed, t, cfg, window, len(X), X.shape[1])
+        ctx = "seed %d t %d cfg %s window %d lookahead %d n %d d %d" % (seed, t, cfg, window, (3, 0, 2)[seed % 3], len(X), X.shape[1])
         np.testing.assert_array_equal(h.labels_uid, o.labels_uid, err_msg=ctx)
         np.testing.assert_array_equal(h.labels_path, o.paths, err_msg=ctx)
         assert (h.pcore_MC_last_id, h.outlier_MC_last_id) == o.counters, ctx

@@ -15,6 +15,7 @@ if __name__ == "__main__":
     X = bench.make_blobs(42, n, d, g)
     cfg = bench.blob_config(n)
     h = _lib.Handle(0)
+    h.set_tuning(window=int(os.environ.get('WIN', '0')), segments=int(os.environ.get('SEG', '0')), lookahead=int(os.environ.get('LA', '0')))
     prev = 0.0
     prev_m = 0
     for m in [n, 10_000, 20_000, 40_000, 80_000, 160_000, 320_000, 640_000, n]:

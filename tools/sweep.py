@@ -27,7 +27,7 @@ if __name__ == "__main__":
     dsegs = [int(x) for x in os.environ.get("DSEGS", "0").split(",")]
     for win, seg, rd, dseg in itertools.product(wins, segs, rnds, dsegs):
         h.set_tuning(window=win, segments=seg, rounds=rd, time_kernels=int(os.environ.get("TK", "0")), dirty_segments=dseg,
-                     points_per_lane=int(os.environ.get("PT", "0")), early_window=int(os.environ.get("EARLY", "0")))
+                     lookahead=int(os.environ.get("LA", "0")), early_window=int(os.environ.get("EARLY", "0")))
         best = None
         for rep in range(2):
             h.reset()
