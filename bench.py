@@ -97,8 +97,8 @@ def main():
         h.reset()
         h.online_run()
         s = h.stats()
-        clusters, _ = h.offline()
-        return s, len(clusters)
+        arrays, _ = h.offline_arrays()  # cc_offline + cc_clusters_export: every cluster's members and CF vectors on the host
+        return s, len(arrays[2])
 
     def sync():
         torch.cuda.synchronize()

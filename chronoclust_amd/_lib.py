@@ -196,7 +196,8 @@ class Handle(object):
         self._check(self._lib.cc_inject_mc(self._h, kind, len(cf1), _ptr(cf1), _ptr(cf2), _ptr(cen), _ptr(pref),
                                            float(w), int(id), int(uid)))
 
-    def offline(self, dumps=False):
+    def offline_arrays(self, dumps=False):
+        """cc_offline + cc_clusters_export: (members, offsets, w, cf1, cf2, cen, pref), info - all clusters as arrays."""
         n = C.c_int32()
         m = self.count(PCORE) if dumps else 0
         core = np.zeros(m, np.int8) if dumps else None
@@ -211,9 +212,14 @@ class Handle(object):
         cf1, cf2, cen, pref = (np.empty((nc, d)) for _ in range(4))
         self._check(self._lib.cc_clusters_export(self._h, _ptr(mem, _i64p), _ptr(off, _i32p), _ptr(w), _ptr(cf1),
                                                  _ptr(cf2), _ptr(cen), _ptr(pref)))
-        clusters = [dict(members=mem[off[c]:off[c + 1]], w=float(w[c]), cf1=cf1[c], cf2=cf2[c], cen=cen[c],
-                         pref=pref[c]) for c in range(nc)]
         info = dict(core=core, pdim=pdim, nn=nn, nw=nw) if dumps else None
+        return (mem, off, w, cf1, cf2, cen, pref), info
+
+    def offline(self, dumps=False):
+        """The same, one dict per cluster."""
+        (mem, off, w, cf1, cf2, cen, pref), info = self.offline_arrays(dumps)
+        clusters = [dict(members=mem[off[c]:off[c + 1]], w=float(w[c]), cf1=cf1[c], cf2=cf2[c], cen=cen[c],
+                         pref=pref[c]) for c in range(len(w))]
         return clusters, info
 
     def num_core(self):

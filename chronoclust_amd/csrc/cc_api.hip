@@ -678,9 +678,10 @@ int cc_online_run(cc_handle* h)
                                        h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
-                                   h->dpath.p, h->lab_uid.p, h->lab_path.p, h->rk.p, h->rec.p);
+                                   h->rk.p, h->rec.p);
                 if (la_on) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));  // the lookahead scan reads the table
-                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->d);
+                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
+                                   h->lab_uid.p, h->lab_path.p, h->d);
                 if (la_on) HIPCHK(hipEventRecord(evCommit, sA));
             }
             HIPCHK(hipGetLastError());

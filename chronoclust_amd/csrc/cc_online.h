@@ -1190,8 +1190,8 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 }
 
 // ---------------------------------------------------------------------------------
-// commit: k_commit_a (one workgroup) ranks the new MCs / promotions of the validated prefix in point order,
-// writes the labels, and opens the next window; k_commit_b (many workgroups) copies the last version of every
+// commit: k_commit_a (one workgroup) ranks the new MCs / promotions of the validated prefix in point order and
+// opens the next window; k_commit_b (many workgroups) writes the labels and copies the last version of every
 // touched MC back into the table.
 // ---------------------------------------------------------------------------------
 
@@ -1201,15 +1201,14 @@ struct CommitRec {
     int pk0, ok0; // list-order key bases
     long long pid0, oid0;
     const int* T; // the claims the prefix was validated against
+    long long cursor;  // first point of the window in the call's input
     int carry;    // 1: the next window is a lookahead window -> k_commit_b also writes the carry set
     unsigned long long next_seq;  // its window_seq
 };
 
 __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver, Carry car,
                                                    const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
-                                                   const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
-                                                   int8_t* __restrict__ lab_path, int* __restrict__ rk,
-                                                   CommitRec* __restrict__ rec)
+                                                   int* __restrict__ rk, CommitRec* __restrict__ rec)
 {
     const int B = ctl->win_b;
     if (B == 0) {
@@ -1263,11 +1262,6 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     }
     __syncthreads();
     const int tot_new = tot & 0xFFFF, tot_up = tot >> 16;
-    for (int j = tid; j < n; j += 1024) {
-        const int t = T[j];
-        lab_uid[cursor + j] = (t < M0) ? tab.uid[t] : oid0 + (rk[t - M0] & 0xFFFF);
-        lab_path[cursor + j] = (int8_t)(dpath[j] | ((ver.upg[j] == j) ? 4 : 0));
-    }
     // Lookahead: the snapshot scan of the next window is already under way (or done) if the host enqueues such
     // scans; it is usable when this window committed in full, so that the next one starts where that scan assumed.
     const unsigned long long seq = ctl->window_seq;
@@ -1282,6 +1276,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     if (tid == 0) {
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         rec->carry = la_ok ? 1 : 0;
+        rec->cursor = cursor;
         rec->next_seq = seq + 1ull;
         ctl->mode = la_ok ? 1 : 0;
         ctl->car_n = la_ok ? B : 0;
@@ -1319,7 +1314,9 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
 // it into the table.  When the next window is a lookahead window (rec->carry) the same rows, together with what
 // the table row held before, become the carry set (see Carry).
 __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ rec, Table tab, Versions ver,
-                                                  Carry car, const int* __restrict__ rk, int d)
+                                                  Carry car, const int* __restrict__ rk,
+                                                  const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
+                                                  int8_t* __restrict__ lab_path, int d)
 {
     const int n = rec->n;
     if (n == 0) return;
@@ -1329,6 +1326,13 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
     const int gl = threadIdx.x & 31;
     const int groups = (gridDim.x * blockDim.x) >> 5;
     for (int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; j < n; j += groups) {
+        if (gl == 0) {
+            // the label of point j: creation number of the MC that holds it (microcluster.py:149); rows below M0 keep
+            // their uid in this commit
+            const int tj = T[j];
+            lab_uid[rec->cursor + j] = (tj < M0) ? tab.uid[tj] : rec->oid0 + (rk[tj - M0] & 0xFFFF);
+            lab_path[rec->cursor + j] = (int8_t)(dpath[j] | ((ver.upg[j] == j) ? 4 : 0));
+        }
         if (ver.next[j] < n) {  // a later point of the prefix holds the MC's last version
             if (carry && gl == 0) { car.kind[j] = CC_KIND_DEAD; car.slot[j] = 0; }
             continue;
