@@ -572,6 +572,7 @@ int cc_online_run(cc_handle* h)
         c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
         c.stat_lookahead = 0;
         c.stat_tiles = c.stat_dirty_tiles = 0;
+        c.stat_trunc_unknown = 0;
         c.stat_table_rows = 0;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         const bool la_forced = h->tun.lookahead == 3;                    // from the first window on, whatever happens (tests)
@@ -628,6 +629,8 @@ int cc_online_run(cc_handle* h)
         const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
         long long trunc_prev = 0, tiles_prev = 0, dtiles_prev = 0;
+        int rounds_batch = R;  // validation rounds that were enqueued per window in the batch just finished
+        long long unk_prev = 0, unk_batch = 0;  // truncated windows that stopped at an undecidable point
         unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
@@ -699,6 +702,9 @@ int cc_online_run(cc_handle* h)
                 const long long trunc = h->hc.stat_truncated - trunc_prev;
                 trunc_prev = h->hc.stat_truncated;
                 trunc_batch = trunc;
+                rounds_batch = Rcur;
+                unk_batch = h->hc.stat_trunc_unknown - unk_prev;
+                unk_prev = h->hc.stat_trunc_unknown;
                 if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
                 else Rcur = std::max(1, std::min(Rcur, used));
             }
@@ -722,7 +728,11 @@ int cc_online_run(cc_handle* h)
                 const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
                 const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
                 int want = h->hc.win_cfg;
-                if (trunc_batch * 4 >= wins && trunc_batch > 0) {
+                if (trunc_batch * 4 >= wins && trunc_batch > 0 && rounds_batch < Rmax && unk_batch * 2 < trunc_batch) {
+                    // windows stopped short because their decisions were still moving, with fewer validation rounds
+                    // enqueued than allowed: more rounds (above) are the remedy, not a shorter window
+                    h->clean_batches = 0;
+                } else if (trunc_batch * 4 >= wins && trunc_batch > 0) {
                     // a quarter or more of the windows stopped short: the window is too long for this data
                     const long long avg = pts / wins;
                     want = (int)std::min<long long>(target, std::max<long long>(128, ((avg + 63) / 64) * 64));

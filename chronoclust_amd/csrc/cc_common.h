@@ -154,6 +154,7 @@ struct Ctl {
     double stat_pair_rows;      // sum over windows of (window points x table rows)
     long long round_hist[CC_MAX_ROUNDS + 2];  // windows by the validation round they ended in
     long long stat_lookahead;  // windows whose snapshot scan ran ahead (mode 1)
+    long long stat_trunc_unknown;  // truncated windows that stopped at a point whose decision could not be made (the rest: one more round needed)
     long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
 };
 

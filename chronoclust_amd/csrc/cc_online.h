@@ -1299,6 +1299,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_rounds += r;
         ctl->round_hist[r] += 1;
         ctl->stat_truncated += (n < B) ? 1 : 0;
+        ctl->stat_trunc_unknown += (n < B && T[n] == CC_T_UNKNOWN) ? 1 : 0;
         ctl->stat_table_rows += M0;
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
