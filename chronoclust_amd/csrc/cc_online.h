@@ -673,7 +673,7 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 // seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
 // ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+__global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
                                               Cand* __restrict__ seed, int round)
 {
@@ -817,9 +817,7 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     }
     if (threadIdx.x == 0) {
         const int sk = (maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tile_tau) ? 1 : 0;
-        ver.skip[blockIdx.x] = sk;
-        atomicAdd((unsigned long long*)&ctl->stat_tiles, 1ull);
-        if (!sk) atomicAdd((unsigned long long*)&ctl->stat_dirty_tiles, 1ull);
+        ver.skip[blockIdx.x] = sk;  // (k_commit_a counts the tiles of the last round for the host's window policy)
         ver.skip_car[blockIdx.x] = (!la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tile_tau)) ? 1 : 0;
     }
 }
@@ -1217,7 +1215,14 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     }
     __shared__ int wsum[16];
     __shared__ int tot;
+    __shared__ int dirty_tiles;
     const int r = ctl->last_round;
+    if (threadIdx.x == 0) dirty_tiles = 0;
+    __syncthreads();
+    // point tiles whose dirty scan ran in the last validation round (the host keeps windows short while most do)
+    const int n_tiles = (r >= 1) ? (B + 63) / 64 : 0;
+    for (int i = threadIdx.x; i < n_tiles; i += 1024)
+        if (ver.skip[i] == 0) atomicAdd(&dirty_tiles, 1);
     const int* T = ((r - 1) & 1) ? Tbuf1 : Tbuf0;
     const int fcv = ctl->fc[r];
     const int n = fcv < B ? fcv : B;
@@ -1299,6 +1304,8 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_rounds += r;
         ctl->round_hist[r] += 1;
         ctl->stat_truncated += (n < B) ? 1 : 0;
+        ctl->stat_tiles += n_tiles;
+        ctl->stat_dirty_tiles += dirty_tiles;
         ctl->stat_trunc_unknown += (n < B && T[n] == CC_T_UNKNOWN) ? 1 : 0;
         ctl->stat_table_rows += M0;
         ctl->stat_pair_rows += (double)B * (double)M0;
