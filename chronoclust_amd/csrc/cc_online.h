@@ -34,6 +34,10 @@
 
 // Each wave stages its own LDS tile and is the only reader of it: DS operations of one wave execute in order,
 // so a wavefront-scope fence (no workgroup barrier) is enough between filling a tile and reading it.
+// The validation kernels are short dependent chains; beside a lookahead scan (four arithmetic-bound waves per SIMD)
+// they would get every fifth issue slot.  They raise their wave priority so that the SIMD arbiter takes them first.
+#define CC_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
+
 #define CC_WAVE_SYNC()                                          \
     do {                                                        \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                                                              size_t part_stride)
 {
     constexpr int PT = 1;  // window points per lane (two measured 10 % slower on C2)
+    if (DIRTY) CC_LATENCY_KERNEL();
     // Which window, which rows:
     //   clean, mode 0: the current window against the table as it is (only if the window has no lookahead scan)
     //   clean, mode 1: lookahead - the window after the current one (parity `round` of its window_seq), while the
@@ -677,6 +682,7 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
                                               Cand* __restrict__ seed, int round)
 {
+    CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
@@ -835,6 +841,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round)
 {
+    CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (round > 0 && ctl->fc[round - 1] >= B) return;
@@ -1003,6 +1010,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
 __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                Versions ver, Carry car, const int* __restrict__ T, int round)
 {
+    CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
@@ -1208,6 +1216,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
                                                    const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
                                                    int* __restrict__ rk, CommitRec* __restrict__ rec)
 {
+    CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) {
         if (threadIdx.x == 0) rec->n = 0;
@@ -1326,6 +1335,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                                                   const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
                                                   int8_t* __restrict__ lab_path, int d)
 {
+    CC_LATENCY_KERNEL();
     const int n = rec->n;
     if (n == 0) return;
     const int M0 = rec->M0;
