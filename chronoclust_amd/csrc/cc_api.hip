@@ -236,6 +236,8 @@ void ensure_table(cc_handle* h, size_t rows)
     HIPCHK(hipMemsetAsync(nt.touch.p, 0, 2 * want * 8, h->stream));
     HIPCHK(hipMemsetAsync(nt.last.p, 0, 2 * want * 8, h->stream));
     HIPCHK(hipMemsetAsync(nt.carry_of.p, 0, want * 8, h->stream));
+    // the carry marks of the last commit are live state: the next window may be a lookahead window
+    if (m > 0) HIPCHK(hipMemcpyAsync(nt.carry_of.p, h->tab.carry_of.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(nt.cnt.p, 0, want * 8, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->tab.swap(nt);
@@ -611,8 +613,11 @@ int cc_online_run(cc_handle* h)
         const Versions ver = versions_view(h);
         const Carry car = carry_view(h);
         hipStream_t sA = h->stream, sB = h->stream2;
-        hipEvent_t evCommit = get_event(h, 2), evScan = get_event(h, 3);
-        ev_used = 4;
+        // cross-stream hand-offs: a fresh event per hand-off (the pool is reused from batch to batch)
+        hipEvent_t evCommit = get_event(h, 2), evScan = nullptr;
+        const size_t ev_base = 4;
+        size_t ev_sync = ev_base;
+        ev_used = ev_base + 2 * (size_t)(h->tun.windows_per_sync + 2);
 
         const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
         const int cblocks = (win + 7) / 8;
@@ -641,6 +646,7 @@ int cc_online_run(cc_handle* h)
                              ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, 0};
             const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
                              car.tile_dsq, car.dsq, ver.tau, ver.skip_car, car.slot, tab.touch, tab.cap};
+            ev_sync = ev_base;
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
@@ -660,6 +666,7 @@ int cc_online_run(cc_handle* h)
                     // previous commit left it, while this window is validated on the first stream
                     HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
                     timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
+                    evScan = get_event(h, ev_sync++);
                     HIPCHK(hipEventRecord(evScan, sB));
                     launch_scan<false>(h, sA, win, trows, nullptr, h->part.p, S, 0, 0);  // no-op unless this window is fresh
                 } else {
@@ -685,7 +692,10 @@ int cc_online_run(cc_handle* h)
                 if (la_on) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));  // the lookahead scan reads the table
                 hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
                                    h->lab_uid.p, h->lab_path.p, h->d);
-                if (la_on) HIPCHK(hipEventRecord(evCommit, sA));
+                if (la_on) {
+                    evCommit = get_event(h, ev_sync++);
+                    HIPCHK(hipEventRecord(evCommit, sA));
+                }
             }
             HIPCHK(hipGetLastError());
             pull_ctl(h);
