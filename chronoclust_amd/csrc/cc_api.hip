@@ -556,7 +556,9 @@ int cc_online_run(cc_handle* h)
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
         refresh_ctl_params(h);
         ensure_window_buffers(h, win, std::max(S, Sd_full));
-        ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * h->tun.windows_per_sync + 1);
+        // every window of a batch may create one MC per point: rows for the largest batch that can be enqueued
+        const size_t batch_max = (size_t)std::max(2, h->tun.windows_per_sync);
+        ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * batch_max + 1);
 
         Ctl& c = h->hc;
         c.cursor = 0;
@@ -617,7 +619,7 @@ int cc_online_run(cc_handle* h)
         hipEvent_t evCommit = get_event(h, 2), evScan = nullptr;
         const size_t ev_base = 4;
         size_t ev_sync = ev_base;
-        ev_used = ev_base + 2 * (size_t)(h->tun.windows_per_sync + 2);
+        ev_used = ev_base + 2 * (batch_max + 2);
 
         const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
         const int cblocks = (win + 7) / 8;
@@ -638,7 +640,7 @@ int cc_online_run(cc_handle* h)
         long long unk_prev = 0, unk_batch = 0;  // truncated windows that stopped at an undecidable point
         unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
-            ensure_table(h, (size_t)m_known + (size_t)win * h->tun.windows_per_sync + 1);
+            ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
             const Table tab = h->tab.view();
             const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, 0};

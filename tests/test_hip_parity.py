@@ -126,6 +126,24 @@ def test_seeded_against_oracle(seed, n, d, g, sigma, over, window):
     assert s["points"] == len(X)
 
 
+@pytest.mark.parametrize("wps,window,sigma,eps", [(1, 64, 0.2, 0.05), (1, 96, 0.08, 0.06), (3, 64, 0.2, 0.05)])
+def test_lookahead_across_batches_and_table_growth(wps, window, sigma, eps):
+    """Lookahead windows at batch boundaries (host read-back after every `wps` windows) on overlapping, noisy data
+    whose table outgrows its allocation several times: the carry marks of the last commit have to survive a
+    reallocation, or stale snapshot candidates are taken for clean ones."""
+    from oracle import oracle as O
+    n, d, g = 7000, 5, 10
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=eps))
+    h = _hdd(cfg, window=window, windows_per_sync=wps, lookahead=3)
+    o = O.OracleHDDStream(cfg)
+    for t in range(2):
+        X = scenarios.make_blobs(800 + t, n, d, g, sigma)
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+    assert len(o.table(1)["id"]) + len(o.table(0)["id"]) > 1100  # the table was reallocated at least once
+
+
 def test_continue_same_daystamp_and_edge_sizes():
     """hddstream.py:199: the same daystamp continues the timepoint (no decay); N = 1 and N = 0 inputs."""
     from oracle import oracle as O
