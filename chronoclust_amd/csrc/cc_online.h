@@ -22,6 +22,12 @@
 // Everything before the frontier is exactly what the sequential loop would have
 // produced; a window always commits at least its first point.
 //
+// Lookahead: the snapshot scan of the next window may run on a second stream while
+// this window is validated, against the table one commit earlier.  What it cannot
+// see - the rows this window's commit changes - is kept as the "carry set" (struct
+// Carry) and enters the next window's validation like version rows that precede its
+// first point (k_dseed, k_scan<DIRTY=true, mode 1>, k_decide, k_chain, k_commit_b).
+//
 // Arithmetic: IEEE double, no contraction (-ffp-contract=off), sums over dimensions
 // left to right as in utilities/mc_functions.py under numba.
 #pragma once
