@@ -1038,41 +1038,14 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const unsigned long long ft = tab.touch[rd], lt = tab.last[rd];
     if ((ft >> 20) != stamp || 0xFFFFF - (int)(ft & 0xFFFFFull) != j) return;
     const int last_j = ((lt >> 20) == stamp) ? (int)(lt & 0xFFFFFull) : j;
-    // This group heads a chain.  Everything it needs from memory depends only on (t, j): all of it is requested
-    // here, before the first use, so that the round trips overlap (member count and list, the MC's table row, its
-    // carry mark, the head's point).
-    const Par par = cc_load_par(ctl);
-    const int d = par.d;
-    const int M0 = ctl->m_rows;
-    const long long cursor = ctl->cursor;
-    const int pk_base = ctl->n_pkeys;
-    const bool isnew = t >= M0;
-    const unsigned long long cw = tab.cnt[t];
-    const int memb_raw = (gl < CC_CHAIN_MEMB) ? tab.memb[(size_t)t * CC_CHAIN_MEMB + gl] : CC_IDX_INF;
-    const unsigned long long co = (!isnew && ctl->mode != 0) ? tab.carry_of[t] : 0ull;
-    double bc1[2] = {0.0, 0.0}, bc2[2] = {0.0, 0.0}, bce[2] = {0.0, 0.0}, bpr[2] = {1.0, 1.0};
-    double bw = 0.0;
-    int bkind = CC_KIND_OUTLIER, bkey = ctl->n_okeys + j, bupg = -1;
-    double px[2] = {0.0, 0.0};  // this lane's two dimensions of the point being absorbed
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int i = gl + 32 * h;
-        if (i < d) {
-            px[h] = X[(cursor + j) * d + i];
-            if (!isnew) {
-                bc1[h] = tab.cf1[(size_t)t * d + i]; bc2[h] = tab.cf2[(size_t)t * d + i];
-                bce[h] = tab.cen[(size_t)t * d + i]; bpr[h] = tab.pref[(size_t)t * d + i];
-            }
-        }
-    }
-    if (!isnew) { bw = tab.w[t]; bkind = tab.kind[t]; bkey = tab.key[t]; }
     // the members of the chain: up to CC_CHAIN_MEMB of them were listed by k_decide (unordered) - lane l keeps the
     // l-th smallest; a longer chain is found by scanning the claims (16-byte loads; the buffer is padded)
+    const unsigned long long cw = tab.cnt[t];
     const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
     const bool listed = n_memb <= CC_CHAIN_MEMB;
     int sorted_memb = CC_IDX_INF;
     if (listed) {
-        const int mine = (gl < n_memb) ? memb_raw : CC_IDX_INF;
+        const int mine = (gl < n_memb) ? tab.memb[(size_t)t * CC_CHAIN_MEMB + gl] : CC_IDX_INF;
         int rank = 0;
         for (int q = 0; q < n_memb; ++q) rank += (__shfl(mine, q, 32) < mine) ? 1 : 0;
         // lane l takes the member whose rank is l (ranks are distinct: the members are)
@@ -1087,15 +1060,36 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     bool have_nb = false;
     int4 vb = make_int4(0, 0, 0, 0), vn = make_int4(0, 0, 0, 0);
 
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
+    const int M0 = ctl->m_rows;
+    const long long cursor = ctl->cursor;
+    const int pk_base = ctl->n_pkeys;
+    const bool isnew = t >= M0;
     const bool valid_chain = !isnew || (t == M0 + j);  // a claim on a MC nobody creates any more is void
-    // (this lane's two dimensions of the chain's running state - bc1, bc2, bce, bpr - stay in registers from step
-    // to step)
+
+    // this lane's two dimensions of the chain's running state stay in registers from step to step
+    double bc1[2] = {0.0, 0.0}, bc2[2] = {0.0, 0.0}, bce[2] = {0.0, 0.0}, bpr[2] = {1.0, 1.0};
+    double bw = 0.0;
+    int bkind = CC_KIND_OUTLIER, bkey = ctl->n_okeys + j, bupg = -1;
+    if (!isnew) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i < d) {
+                bc1[h] = tab.cf1[(size_t)t * d + i]; bc2[h] = tab.cf2[(size_t)t * d + i];
+                bce[h] = tab.cen[(size_t)t * d + i]; bpr[h] = tab.pref[(size_t)t * d + i];
+            }
+        }
+        bw = tab.w[t]; bkind = tab.kind[t]; bkey = tab.key[t];
+    }
     // centroid, metric and kind of this MC in the snapshot the window was scanned against, for the displacement of
     // its versions: the table row, unless (lookahead) the previous window changed it after that scan
     double c0[2] = {bce[0], bce[1]};
     double w0[2] = {1.0 / bpr[0], 1.0 / bpr[1]};
     int kind0 = bkind;
     if (!isnew && ctl->mode != 0) {
+        const unsigned long long co = tab.carry_of[t];
         if ((co >> 20) == ctl->window_seq) {
             const size_t r = (size_t)(co & 0xFFFFFull);
             kind0 = car.kind0[r];  // CC_KIND_DEAD (never a live kind): not in the snapshot -> no bound
@@ -1107,18 +1101,13 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         }
     }
     int cur = j;
-    // a listed chain knows its points in advance: the next one is requested before the loop, and in every step the
-    // one after next, so that two point fetches are in flight while a point is absorbed
-    double pn[2] = {0.0, 0.0};
-    bool have_pn = false;
-    if (listed && valid_chain && n_memb > 1) {
-        const int n1 = __shfl(sorted_memb, 1, 32);
+    double px[2] = {0.0, 0.0};  // this lane's two dimensions of point `cur`
+    if (valid_chain) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = gl + 32 * h;
-            if (i < d) pn[h] = X[(cursor + n1) * d + i];
+            if (i < d) px[h] = X[(cursor + cur) * d + i];
         }
-        have_pn = true;
     }
     while (true) {
         int nx = CC_IDX_INF;
@@ -1146,24 +1135,14 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 break;
             }
         }
-        // the next point of the chain is fetched while this one is being absorbed (unless it already is on its way)
-        if (valid_chain && nx != CC_IDX_INF && !have_pn) {
+        // the next point of the chain is fetched while this one is being absorbed
+        double pn[2] = {0.0, 0.0};
+        if (valid_chain && nx != CC_IDX_INF) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int i = gl + 32 * h;
                 if (i < d) pn[h] = X[(cursor + nx) * d + i];
             }
-        }
-        double pn2[2] = {0.0, 0.0};
-        bool have_pn2 = false;
-        if (listed && valid_chain && step + 1 < n_memb) {
-            const int n2 = __shfl(sorted_memb, step + 1, 32);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = gl + 32 * h;
-                if (i < d) pn2[h] = X[(cursor + n2) * d + i];
-            }
-            have_pn2 = true;
         }
         if (!valid_chain) {
             if (gl == 0) {
@@ -1219,9 +1198,6 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         cur = nx;
         px[0] = pn[0];
         px[1] = pn[1];
-        pn[0] = pn2[0];
-        pn[1] = pn2[1];
-        have_pn = have_pn2;
     }
 }
 
