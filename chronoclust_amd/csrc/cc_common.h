@@ -41,16 +41,16 @@ struct Table {
     // Lookahead (see Carry): carry_of = window_seq << 20 | carried index, for the rows the previous window changed
     unsigned long long* carry_of;  // [cap]
     // Chain members.  k_decide appends every window point to the list of the MC it targets (arrival order of the
-    // atomics, i.e. unordered): cnt = stamp << 24 | members, memb[16 * row + i] = the first 16 of them.  The point
+    // atomics, i.e. unordered): cnt = stamp << 24 | members, memb[CC_CHAIN_MEMB * row + i] = the first CC_CHAIN_MEMB of them.  The point
     // that heads the chain sorts them (k_chain); longer chains are found by scanning the claims.
     unsigned long long* cnt;  // [cap]
-    int* memb;                // [cap, 16]
+    int* memb;                // [cap, CC_CHAIN_MEMB]
     size_t cap;                 // rows allocated (offset of the second copy)
 };
 
 // Candidate slots >= CC_CAR_BASE refer to carried rows (index = slot - CC_CAR_BASE), below to version rows.
 #define CC_CAR_BASE (1 << 24)
-#define CC_CHAIN_MEMB 16
+#define CC_CHAIN_MEMB 32
 
 // Lookahead.  While window W is validated, the snapshot scan of window W + 1 already runs - against the table as
 // it is before W's commit.  What that scan could not see is exactly the set of rows W's commit changes or adds:

@@ -735,11 +735,21 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
             }
             return -1;
         }
+        // the latest claimant before j: the largest listed member of the MC's chain below j (k_decide listed up to
+        // CC_CHAIN_MEMB of them, one 128-byte read), then along the chain for the members the list does not hold
         int v = head;
-        for (int steps = 0; ver.next[v] < j; ++steps) {
-            v = ver.next[v];
-            if (steps >= 16) return -2;
+        const unsigned long long cw = tab.cnt[slot];
+        const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
+        const int n_list = n_memb < CC_CHAIN_MEMB ? n_memb : CC_CHAIN_MEMB;
+        for (int i = 0; i < n_list; ++i) {
+            const int m = tab.memb[(size_t)slot * CC_CHAIN_MEMB + i];
+            v = (m < j && m > v) ? m : v;
         }
+        if (n_memb > CC_CHAIN_MEMB)
+            for (int steps = 0; ver.next[v] < j; ++steps) {
+                v = ver.next[v];
+                if (steps >= 64) return -2;
+            }
         return v;
     };
     // exact distance of point j to version row v; enters the first-candidate slot of the version's kind

@@ -19,6 +19,7 @@ if __name__ == "__main__":
         X = bench.make_blobs(42, n, d, g)
         cfg = bench.blob_config(n)
         h = _lib.Handle(0)
+        h.set_tuning(window=int(os.environ.get("WIN", "0")), segments=int(os.environ.get("SEG", "0")), lookahead=int(os.environ.get("LA", "0")))
         bench.set_params(h, cfg, n, d)
         t0 = time.perf_counter()
         h.points_upload(X)
