@@ -146,7 +146,7 @@ def main():
         "config": {"workload": "C2: 1 timepoint, %dx%d synthetic blobs (seed 42+rank), %d microclusters; "
                                "exact sequential semantics; online + offline phases per step" % (n, d, g),
                    "points": n, "dim": d, "microclusters": int(s["rows"]), "clusters": n_clusters,
-                   "streams": world, "window": args.window or 12288, "windows_per_step": int(s["windows"]),
+                   "streams": world, "window": args.window or 24576, "windows_per_step": int(s["windows"]),
                    "lookahead_windows_per_step": int(s["lookahead_windows"]),
                    "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
         "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,

@@ -403,7 +403,7 @@ int cc_create(int device, cc_handle** out)
         h->ctl.ensure(1);
         h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
-        h->tun.window = 12288;
+        h->tun.window = 24576;
         h->tun.rounds = 3;
         h->tun.segments = 64;
         h->tun.windows_per_sync = 16;
@@ -443,7 +443,7 @@ const char* cc_last_error(const cc_handle* h) { return h ? h->err.c_str() : "nul
 int cc_set_tuning(cc_handle* h, const cc_tuning* t)
 {
     if (!h || !t) return CC_ERR_BAD_ARG;
-    if (t->window > 0) h->tun.window = std::min(t->window, 16384);
+    if (t->window > 0) h->tun.window = std::min(t->window, 32768);
     if (t->rounds > 0) h->tun.rounds = std::min(t->rounds, CC_MAX_ROUNDS);
     if (t->segments > 0) h->tun.segments = std::min(t->segments, 1024);
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
@@ -566,7 +566,9 @@ int cc_online_run(cc_handle* h)
         const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
         const int start_small = 256;
-        if (h->adapt_win > 0) c.win_cfg = std::min(win, h->adapt_win);
+        // (a new timepoint begins with whatever changed since the last one - decayed weights, new populations -, which
+        // takes a few validation rounds per window: not with the largest window the previous one ended on)
+        if (h->adapt_win > 0) c.win_cfg = std::min(win, std::min(h->adapt_win, early0));
         else c.win_cfg = std::min(win, (c.m_rows < 1024) ? start_small : early0);
         c.win_b = (int)std::min<long long>(c.win_cfg, N);
         c.max_rounds = R;
@@ -586,6 +588,7 @@ int cc_online_run(cc_handle* h)
             // (re)start: the current window is a fresh one, the lookahead scan enqueued next covers the one after it
             la_on = on;
             c.la_on = on ? 1 : 0;
+            c.stall_b = 0;
             c.mode = 0;
             c.car_n = 0;
             const int q = (int)((c.window_seq + 1ull) & 1ull);
@@ -670,7 +673,9 @@ int cc_online_run(cc_handle* h)
                     timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
                     evScan = get_event(h, ev_sync++);
                     HIPCHK(hipEventRecord(evScan, sB));
-                    timed_scan(sA, 0, 0);  // no-op unless this window is fresh (timed as well: every launch of the kernel counts)
+                    // only the first window of a lookahead batch can need an in-place scan (the device idles the
+                    // rest of a batch whose lookahead chain breaks, see Ctl::stall_b)
+                    if (wv == 0 && h->hc.mode == 0) timed_scan(sA, 0, 0);
                 } else {
                     timed_scan(sA, 0, 0);
                 }
@@ -765,7 +770,7 @@ int cc_online_run(cc_handle* h)
                 // overlapping MCs) the scan of a window that then starts elsewhere is wasted
                 Sd = (tiles > 0 && dtiles * 16 < tiles) ? std::max(1, Sd_full / 8) : Sd_full;
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
-                if ((want != h->hc.win_cfg || want_la != la_on) && done < N) {
+                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {
                     h->hc.win_cfg = want;
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
                     set_lookahead(want_la);

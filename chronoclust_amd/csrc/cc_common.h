@@ -143,7 +143,10 @@ struct Ctl {
     int mode;    // current window: 0 = its snapshot scan saw the table as it is (fresh), 1 = as it was one commit earlier
     int car_n;   // rows of the carry set (= size of the previous window) when mode == 1, else 0
     int la_on;   // set by the host: lookahead scans are being enqueued
-    int pad1;
+    // In a lookahead batch only the first window can be scanned in place (the host enqueues that launch when it
+    // knows the window is a fresh one).  If a later window cannot use its lookahead scan (the previous one stopped
+    // short), the rest of the batch idles: win_b = 0 and the withheld size waits here for the host.
+    int stall_b;
     // the window after the current one, per parity of its window_seq: what its lookahead scan covers
     long long la_cursor[2];
     int la_b[2];

@@ -1259,9 +1259,9 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const long long n_points = ctl->n_points;
     const int win_cfg = ctl->win_cfg;
 
-    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 16384
+    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 32768
     const int per = (B + 1023) >> 10;  // points per thread
-    int loc[16];
+    int loc[32];
     int mine = 0;
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
@@ -1336,7 +1336,15 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
         ctl->window_seq = seq + 1ull;
-        ctl->win_b = next_b;
+        if (ctl->la_on != 0 && !la_ok && next_b > 0) {
+            // no usable lookahead scan and, in a lookahead batch, no in-place scan either: wait for the host
+            ctl->stall_b = next_b;
+            ctl->win_b = 0;
+            ctl->la_b[0] = 0;
+            ctl->la_b[1] = 0;
+        } else {
+            ctl->win_b = next_b;
+        }
         ctl->last_round = 0;
         ctl->fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) ctl->fc[i] = CC_IDX_INF;

@@ -71,7 +71,7 @@ typedef struct cc_params {
 
 /* Tuning knobs of the exact windowed online path (0 = library default). */
 typedef struct cc_tuning {
-    int32_t window;          /* points speculated per window (<= 16384, default 12288) */
+    int32_t window;          /* points speculated per window (<= 32768, default 24576) */
     int32_t rounds;          /* max validation rounds per window                 */
     int32_t segments;        /* microcluster-range segments per point tile       */
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */

@@ -54,7 +54,7 @@ def test_c2_labels_do_not_depend_on_window_or_segments(c2):
     from chronoclust_amd.clustering.hddstream import HDDStream
     X, cfg, h = c2
     for tuning in (dict(window=1536, segments=64, rounds=2, lookahead=3), dict(window=8192, segments=256, rounds=4, lookahead=2),
-                   dict(window=16384, segments=128, lookahead=3)):
+                   dict(window=16384, segments=128, lookahead=3), dict(window=32768, lookahead=3), dict(window=12288, lookahead=2)):
         g = HDDStream(cfg, tuning=tuning)
         g.online_microcluster_maintenance(X, 0)
         assert np.array_equal(g.labels_uid, h.labels_uid)
