@@ -168,8 +168,9 @@ def main():
                                          "note": "4 non-FMA fp64 ops per (point, microcluster, dim): sub, mul, "
                                                  "mul, add in the reference's order; every pair runs all dims"},
                            "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead "
-                                          "scans (second stream, beside the validation kernels of the previous window), "
-                                          "in-place scans, and the no-op in-place launches of lookahead batches"}
+                                          "scans (second stream, beside the validation kernels of the previous window, "
+                                          "including the few that go unused) and in-place scans (short windows of the "
+                                          "start-up phase included)"}
     if "roofline" in out:
         # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
         # separate runs, profiles/r01_pmc_traffic.json); only quoted when it was measured on this workload shape

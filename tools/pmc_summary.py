@@ -28,7 +28,7 @@ if __name__ == "__main__":
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --steps 1 --warmup 0`; "
                    "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of "
                    "a wide coalesced read; narrower accesses are uncalibrated, so this is an upper estimate); includes "
-                   "Infinity-Cache hits; averaged over all launches of the kernel in the run (about a third are no-op launches of "
-                   "lookahead batches). Most of it is the per-workgroup argmin partials (window x 16 x 64 B) that k_scan "
+                   "Infinity-Cache hits; averaged over all launches of the kernel in the run (the start-up phase uses short "
+                   "windows, a few lookahead scans go unused). Most of it is the per-workgroup argmin partials (window x 16 x 64 B) that k_scan "
                    "writes and k_decide merges, not input data."}
     print(json.dumps(out, indent=1))
