@@ -1259,16 +1259,19 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const long long n_points = ctl->n_points;
     const int win_cfg = ctl->win_cfg;
 
-    // packed flags: low 16 bits "creates a MC", high 16 bits "its add promoted the MC"; B <= 32768
+    // Per point: bit 0 "creates a MC", bit 1 "its add promoted the MC"; read with coalesced loads into LDS, then
+    // every thread ranks a contiguous run of points (packed counts: low 16 bits creations, high 16 bits
+    // promotions; B <= 32768).
+    __shared__ unsigned char sflag[32768];
+    for (int j = tid; j < B; j += 1024)
+        sflag[j] = (j < n) ? (unsigned char)(((T[j] == M0 + j) ? 1 : 0) | ((ver.upg[j] == j) ? 2 : 0)) : (unsigned char)0;
+    __syncthreads();
     const int per = (B + 1023) >> 10;  // points per thread
-    int loc[32];
     int mine = 0;
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
-        int f = 0;
-        if (j < n) f = ((T[j] == M0 + j) ? 1 : 0) | ((ver.upg[j] == j) ? 0x10000 : 0);
-        loc[q] = mine;
-        mine += f;
+        const int f = (j < B) ? (int)sflag[j] : 0;
+        mine += (f & 1) | ((f & 2) << 15);
     }
     // inclusive wave scan of the per-thread sums
     int v = mine;
@@ -1285,10 +1288,14 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         tot = run;
     }
     __syncthreads();
-    const int excl = v - mine + wsum[wid];
+    int run = v - mine + wsum[wid];
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
-        if (j < B) rk[j] = excl + loc[q];
+        if (j < B) {
+            rk[j] = run;
+            const int f = (int)sflag[j];
+            run += (f & 1) | ((f & 2) << 15);
+        }
     }
     __syncthreads();
     const int tot_new = tot & 0xFFFF, tot_up = tot >> 16;
