@@ -115,6 +115,7 @@ struct cc_handle {
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
+    int force_dirty_wgs = 0;
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -299,11 +300,13 @@ struct ScanWaves {
 
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                    int mode)
+                    int mode, int tile_wgs)
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
-    const dim3 grid((win + 63) / 64, S);
+    // dirty scans: tile_wgs > 0 = that many workgroups walk the point tiles (grid stride) instead of one each
+    const int tiles = (win + 63) / 64;
+    const dim3 grid((DIRTY && tile_wgs > 0) ? std::min(tiles, tile_wgs) : tiles, S);
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;
@@ -325,16 +328,16 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 // dirty scan: mode 0 = version rows, 1 = carry set.
 template <bool DIRTY>
 void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                 int mode)
+                 int mode, int tile_wgs = 0)
 {
     const int d = h->d;
-    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
 }
 
 int scan_waves_for_dim(int) { return 4; }
@@ -410,6 +413,9 @@ int cc_create(int device, cc_handle** out)
         h->tun.time_kernels = 0;
         const char* tr = getenv("CHRONOCLUST_HIP_TRACE");
         h->trace = tr && tr[0] == '1';
+        // testing: CHRONOCLUST_HIP_DIRTY_WGS=n launches every dirty scan with n workgroups per segment (grid stride)
+        const char* dw = getenv("CHRONOCLUST_HIP_DIRTY_WGS");
+        h->force_dirty_wgs = dw ? atoi(dw) : 0;
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -551,6 +557,7 @@ int cc_online_run(cc_handle* h)
         // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
         // few workgroups per point tile then, the full split while they really run (set per batch below)
         int Sd = Sd_full;
+        int dirty_wgs = h->force_dirty_wgs;  // > 0: the dirty scans are launched with this many workgroups per segment (grid stride over tiles)
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
@@ -624,9 +631,6 @@ int cc_online_run(cc_handle* h)
         size_t ev_sync = ev_base;
         ev_used = ev_base + 2 * (batch_max + 2);
 
-        const int dblocks = (win + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
-        const int cblocks = (win + 7) / 8;
-        const int rblocks = std::min((win + 7) / 8, 1024);
         long long done = 0;
         int m_known = c.m_rows;
         // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
@@ -652,18 +656,23 @@ int cc_online_run(cc_handle* h)
             const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
                              car.tile_dsq, car.dsq, ver.tau, ver.skip_car, car.slot, tab.touch, tab.cap};
             ev_sync = ev_base;
+            // grids cover the window size of this batch (no window of the batch is larger), not the configured maximum
+            const int gw = std::max(64, std::min(win, h->hc.win_cfg));
+            const int dblocks = (gw + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
+            const int cblocks = (gw + 7) / 8;
+            const int rblocks = std::min((gw + 7) / 8, 1024);
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
                     if (timing) {
                         hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
                         HIPCHK(hipEventRecord(a, st));
-                        launch_scan<false>(h, st, win, trows, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, trows, nullptr, h->part.p, S, round, mode);
                         HIPCHK(hipEventRecord(b, st));
                         timed.push_back({ev_used, 0.0});
                         ev_used += 2;
                     } else {
-                        launch_scan<false>(h, st, win, trows, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, trows, nullptr, h->part.p, S, round, mode);
                     }
                 };
                 if (la_on) {
@@ -687,10 +696,10 @@ int cc_online_run(cc_handle* h)
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), 0, sA,
                                        h->ctl.p, h->X.p, tab, ver, car, told, r);
-                    hipLaunchKernelGGL(k_dseed, dim3((win + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                    hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, r);
-                    launch_scan<true>(h, sA, win, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
-                    if (la_on) launch_scan<true>(h, sA, win, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
+                    launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0, dirty_wgs);
+                    if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1, dirty_wgs);
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
                                        h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r);
                 }
@@ -768,7 +777,9 @@ int cc_online_run(cc_handle* h)
                 h->adapt_win = want;
                 // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few
                 // overlapping MCs) the scan of a window that then starts elsewhere is wasted
-                Sd = (tiles > 0 && dtiles * 16 < tiles) ? std::max(1, Sd_full / 8) : Sd_full;
+                const bool quiet = tiles > 0 && dtiles * 16 < tiles;
+                Sd = quiet ? std::max(1, Sd_full / 8) : Sd_full;
+                dirty_wgs = h->force_dirty_wgs > 0 ? h->force_dirty_wgs : (quiet ? 16 : 0);
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
                 if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {
                     h->hc.win_cfg = want;

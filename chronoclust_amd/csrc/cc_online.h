@@ -139,6 +139,34 @@ __device__ __forceinline__ double cc_vmax(double a, double b)
     return r;
 }
 
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void cc_static_for(F&& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        cc_static_for<N, I + 1>(f);
+    }
+}
+
+// Fused last step of a distance term (mc_functions.py:39 + :41) when the divisor is a power of two.
+// The reference computes acc + round(x2 * sc); x2 * sc is exact for sc = 2^e unless it lands in the subnormal
+// range, so one rounding of x2 * sc + acc (v_fma_f64) is the same double.  The subnormal case is excluded by the
+// caller: when every nonzero coordinate of the point and of the centroid has magnitude >= 2^-400, a nonzero
+// difference is >= 2^-452 (both are multiples of 2^-452), its square >= 2^-905, and with 2^-64 <= sc <= 2^64 the
+// product stays normal.  Tiles or waves that hold a smaller nonzero coordinate take the unfused path.
+#define CC_TINY 0x1p-400
+__device__ __forceinline__ bool cc_is_tiny(double v) { return v != 0.0 && __builtin_fabs(v) < CC_TINY; }
+
+// wave-uniform operand of a dimension from bit BIT of its row mask: two scalar instructions (the compiler's own
+// selection takes three, and the scalar unit issues one instruction per wave turn like the vector unit)
+template <int BIT>
+__device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, double one)
+{
+    double r;
+    asm("s_bitcmp1_b32 %1, %2\n\ts_cselect_b64 %0, %3, %4" : "=s"(r) : "s"(mask), "n"(BIT), "s"(scaled), "s"(one) : "scc");
+    return r;
+}
+
 // ---------------------------------------------------------------------------------
 // k_scan: points (one or PT per lane, in registers) x MC rows (wave-uniform, staged in LDS)
 // ---------------------------------------------------------------------------------
@@ -189,9 +217,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const bool carried = DIRTY && mode == 1;
     const int car_n = carried ? ((ctl->mode != 0) ? ctl->car_n : 0) : 0;
     if (carried && car_n == 0) return;
-    const int j0 = blockIdx.x * (64 * PT);
+    // One point tile.  The clean scan runs one tile per workgroup.  The dirty scans walk the tiles with a grid stride:
+    // while k_dseed rules them out tile by tile the host launches a few workgroups only (a launch of one fat
+    // workgroup per tile that all return at once still has to find room beside a lookahead scan - measured: 200 us).
+    auto do_tile = [&](const int bx) {
+    const int j0 = bx * (64 * PT);
     if (j0 >= B) return;
-    if (DIRTY && rows.skip[blockIdx.x] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
+    if (DIRTY && rows.skip[bx] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
     const int d = ctl->d;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
@@ -265,6 +297,16 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
 #pragma unroll
         for (int i = 0; i < DP; ++i) p[t][i] = (valid[t] && i < d) ? xp[(size_t)i * n_pts] : 0.0;
     }
+    // fused distance terms (see cc_fma_term) are exact for this wave's points?
+    bool fuse_wave = POW2 && par.k >= 0x1p-64 && par.k <= 0x1p64;
+    if (POW2) {
+        bool tn = false;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int i = 0; i < DP; ++i) tn = tn || cc_is_tiny(p[t][i]);
+        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+    }
 
     // running best-two per kind and point: [kind][pt][rank]
     double bd[2][PT][2];
@@ -305,6 +347,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             if (tdq < CC_INF && sqrt(tdq) * (1.0 + 1e-9) < wave_tau) continue;  // nothing in this tile can matter
         }
         CC_WAVE_SYNC();
+        bool fuse_tile = false;
+        int rm_lo = 0, rm_hi = 0;  // lane m < CC_SCAN_TM: which dimensions of tile row m are scaled by 1/k
         {
             // the tile is one contiguous block of tm * d doubles per column: a straight copy, all loads of the
             // tile in flight before the first LDS store (LDS row stride = d; dimensions d..DP-1 are never read)
@@ -322,10 +366,32 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                 tc[q] = in ? gc[ge] : 0.0;
                 ts[q] = in ? gs[ge] : 1.0;
             }
+            bool tn = false;
 #pragma unroll
             for (int q = 0; q < NL; ++q) {
                 const int e = lane + q * 64;
                 if (e < CC_SCAN_TM * DP) { s_c_base[e] = tc[q]; s_s_base[e] = ts[q]; }
+                if (POW2) tn = tn || cc_is_tiny(tc[q]);
+            }
+            if (POW2) fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+            if (POW2 && !DIRTY) {
+                // When k is a power of two the distance operand of a dimension is 1 or 1/k: one bit.  The 64 * NL
+                // staged operands give NL ballot words = the tile's CC_SCAN_TM * DP bits in row order; lane m keeps
+                // the DP bits of row m, and the fused row loop builds its operands from them with scalar selects
+                // instead of reading them from LDS (the loop is bound by wave-uniform LDS reads otherwise).
+                unsigned long long rmask = 0ull;
+                const int off = (lane & (CC_SCAN_TM - 1)) * DP;
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    const unsigned long long w = __builtin_amdgcn_ballot_w64(ts[q] != 1.0);
+                    const int rel = off - 64 * q;
+                    const unsigned long long a = (rel >= 0 && rel < 64) ? (w >> (rel & 63)) : 0ull;
+                    const unsigned long long b = (rel < 0 && rel > -DP) ? (w << ((-rel) & 63)) : 0ull;
+                    rmask |= a | b;
+                }
+                if (DP < 64) rmask &= (1ull << (DP & 63)) - 1ull;
+                rm_lo = (int)(unsigned)(rmask & 0xFFFFFFFFull);
+                rm_hi = (int)(unsigned)(rmask >> 32);
             }
         }
         // kinds of the tile's rows as two wave-uniform bit masks (clean scan) / LDS columns (dirty scan)
@@ -361,23 +427,42 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             // update is pure selection (min / max and three selects).  Exact ties - the only place where the
             // list-order keys decide (hddstream.py:326/373: strict `<`, first in list order wins) - and the pdim
             // filter take the general path, which fetches the keys it needs.
+            auto clean_rows = [&](auto FUSEC) {
+            constexpr bool FUSE = decltype(FUSEC)::value;
             for (int m = 0; m < tm; ++m) {
                 double acc[PT];
-                const double* rc = s_c_base + m * DP;
-                const double* rs = s_s_base + m * DP;
-#pragma unroll
-                for (int i = 0; i < DP; ++i) {
-                    const double c = rc[i];
-                    const double sc = rs[i];
+                // (rows of an even DP start on 16-byte boundaries: ds_read_b128)
+                const double* rc = (DP % 2 == 0) ? (const double*)__builtin_assume_aligned(s_c_base + m * DP, 16) : s_c_base + m * DP;
+                const double* rs = (DP % 2 == 0) ? (const double*)__builtin_assume_aligned(s_s_base + m * DP, 16) : s_s_base + m * DP;
+                const unsigned mlo = FUSE ? (unsigned)__builtin_amdgcn_readlane(rm_lo, m) : 0u;
+                const unsigned mhi = (FUSE && DP > 32) ? (unsigned)__builtin_amdgcn_readlane(rm_hi, m) : 0u;
+                const double one = 1.0;
+                // centroid of the row, two dimensions per LDS read
+                typedef double cc_d2 __attribute__((ext_vector_type(2)));
+                static_assert(DP % 2 == 0, "padded dimensionalities are even");
+                const cc_d2* rc2 = reinterpret_cast<const cc_d2*>(rc);
+                auto dim_step = [&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    const cc_d2 cp = rc2[i >> 1];
+                    const double c = (i & 1) ? cp.y : cp.x;
+                    // fused: the operand comes from the row's bit mask (wave-uniform, a scalar select)
+                    double sc;
+                    if constexpr (FUSE) sc = cc_sel_scale<(i & 31)>(i < 32 ? mlo : mhi, inv_k, one);
+                    else sc = rs[i];
 #pragma unroll
                     for (int t = 0; t < PT; ++t) {
                         double x = p[t][i] - c;       // mc_functions.py:37
                         x = x * x;                    // :38
-                        x = POW2 ? x * sc : x / sc;   // :39
-                        // :41, left to right; the terms are >= +0, so 0.0 + x is x and the first one starts the sum
-                        acc[t] = (i == 0) ? x : acc[t] + x;
+                        // :39 + :41, left to right; the terms are >= +0, so 0.0 + x is x and the first one starts the sum
+                        if (FUSE) {
+                            acc[t] = (i == 0) ? x * sc : __builtin_fma(x, sc, acc[t]);  // see CC_TINY
+                        } else {
+                            x = POW2 ? x * sc : x / sc;
+                            acc[t] = (i == 0) ? x : acc[t] + x;
+                        }
                     }
-                }
+                };
+                cc_static_for<DP>(dim_step);
                 const int rowg = rt + m;
                 auto update = [&](auto KC) {
                     constexpr int K = decltype(KC)::value;
@@ -424,6 +509,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                 if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
                 else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
             }
+            };
+            if (POW2 && fuse_tile) clean_rows(std::true_type{});
+            else clean_rows(std::false_type{});
             continue;
         }
 
@@ -431,6 +519,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
         // independent accumulation chains hide each other's latency.  The clean scan mostly runs rows to the end,
         // where pairing only adds work, and takes one.
         constexpr bool RB2 = DIRTY;
+        auto dirty_rows = [&](auto FUSEC) {
+        constexpr bool FUSE = decltype(FUSEC)::value;
         for (int m = 0; m < tm; m += (RB2 ? 2 : 1)) {
             const int kindA = ((rowmask >> m) & 1u) ? __builtin_amdgcn_readfirstlane(s_kind_w[m]) : CC_KIND_DEAD;
             const int kindB = (RB2 && m + 1 < tm && ((rowmask >> (m + 1)) & 1u))
@@ -482,13 +572,19 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
                         for (int t = 0; t < PT; ++t) {
                             double x = p[t][i] - cA;  // mc_functions.py:37
                             x = x * x;                // :38
-                            x = POW2 ? x * sA : x / sA; // :39
-                            accA[t] = accA[t] + x;    // :41, left to right
+                            if (FUSE) accA[t] = __builtin_fma(x, sA, accA[t]);  // :39 + :41 in one rounding, see CC_TINY
+                            else {
+                                x = POW2 ? x * sA : x / sA; // :39
+                                accA[t] = accA[t] + x;    // :41, left to right
+                            }
                             if (RB2) {
                                 double y = p[t][i] - cB;
                                 y = y * y;
-                                y = POW2 ? y * sB : y / sB;
-                                accB[t] = accB[t] + y;
+                                if (FUSE) accB[t] = __builtin_fma(y, sB, accB[t]);
+                                else {
+                                    y = POW2 ? y * sB : y / sB;
+                                    accB[t] = accB[t] + y;
+                                }
                             }
                         }
                     }
@@ -539,6 +635,9 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             if (liveA) insert_row(m, kindA, accA, boundA);
             if (RB2 && liveB) insert_row(m + 1, kindB, accB, boundB);
         }
+        };
+        if (POW2 && fuse_tile) dirty_rows(std::true_type{});
+        else dirty_rows(std::false_type{});
     }
 
     if (!DIRTY) {
@@ -586,6 +685,13 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
         }
     }
+    };
+    if (!DIRTY) do_tile((int)blockIdx.x);
+    else
+        for (int bx = blockIdx.x; bx * (64 * PT) < B; bx += gridDim.x) {
+            do_tile(bx);
+            __syncthreads();  // the merge exchange of this tile shares its bytes with the next tile's rows
+        }
 }
 
 // ---------------------------------------------------------------------------------

@@ -5,7 +5,7 @@ import sys
 import pandas as pd
 
 d = sys.argv[1]
-f = glob.glob(d + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
 df = pd.read_csv(f)
 df["dur"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
 df["name"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.slice(0, 40)

@@ -1,5 +1,5 @@
 import pandas as pd, glob, sys
-f=glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')[0]
+f=(glob.glob(sys.argv[1]+'/*/*kernel_trace.csv')+glob.glob(sys.argv[1]+'/*kernel_trace.csv'))[0]
 df=pd.read_csv(f)
 df['name']=df['Kernel_Name'].str.replace(r'\(.*','',regex=True).str.replace('void ','').str.slice(0,28)
 df=df.sort_values('Start_Timestamp').reset_index(drop=True)
