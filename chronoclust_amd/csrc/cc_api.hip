@@ -116,6 +116,8 @@ struct cc_handle {
     int since_shrink = 1000;  // batches since the window was last shrunk
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     int force_dirty_wgs = 0;
+    bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
+    int la_pad = 0;         // bytes of unused dynamic LDS per workgroup of a lookahead scan (occupancy cap)
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -128,7 +130,7 @@ struct cc_handle {
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
     DevBuf<double> v_cf1, v_cf2, v_cen, v_pref, v_scl, v_w, v_dsq, v_tau;
     DevBuf<unsigned long long> v_tile_dsq;
-    DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt, v_skip, v_skip_car;
+    DevBuf<int> v_kind, v_key, v_next, v_upg, v_acc, v_tgt, v_skip, v_skip_car, v_unsafe;
     DevBuf<Cand> part, clean, dpart, dpart2, dseed;  // part: two copies (window parity), dpart2: carry-set scan
     size_t part_stride = 0;
     // carry set of the previous window (lookahead)
@@ -137,6 +139,9 @@ struct cc_handle {
     DevBuf<unsigned long long> c_tile_dsq;
     DevBuf<int> T0, T1, rk;
     DevBuf<CommitRec> rec;
+    // scan copy of the table for lookahead scans (see ScanCopy)
+    DevBuf<double> sh_cen[2], sh_scl[2], sh_cf1[2], sh_cf2[2], sh_w[2];
+    DevBuf<int> sh_kind[2], sh_key[2];
     DevBuf<int8_t> dpath;
 
     // offline results
@@ -265,7 +270,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
     h->v_dsq.ensure(w); h->v_tau.ensure(w); h->v_tile_dsq.ensure(w / 16 + 2);
     h->v_tgt.ensure(w);
-    h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2);
+    h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2); h->v_unsafe.ensure(w);
     h->part_stride = w * seg * 4;
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
@@ -283,11 +288,36 @@ Carry carry_view(cc_handle* h)
                  h->c_slot.p, h->c_c0.p, h->c_w0.p, h->c_kind0.p, h->c_dsq.p, h->c_tile_dsq.p};
 }
 
+// bring both scan copies in line with the table (rows [0, m_rows)); enqueued on the main stream
+void scan_copy_sync(cc_handle* h, ScanCopy (&out)[2])
+{
+    const size_t cap = h->tab.cap, d = (size_t)h->d, m = (size_t)h->hc.m_rows;
+    const bool filter = h->hc.filter != 0;
+    const TableStore& t = h->tab;
+    for (int q = 0; q < 2; ++q) {
+        h->sh_cen[q].ensure(cap * d); h->sh_scl[q].ensure(cap * d); h->sh_kind[q].ensure(cap); h->sh_key[q].ensure(cap);
+        if (filter) { h->sh_cf1[q].ensure(cap * d); h->sh_cf2[q].ensure(cap * d); h->sh_w[q].ensure(cap); }
+        if (m > 0) {
+            HIPCHK(hipMemcpyAsync(h->sh_cen[q].p, t.cen.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->sh_scl[q].p, t.scl.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->sh_kind[q].p, t.kind.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->sh_key[q].p, t.key.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
+            if (filter) {
+                HIPCHK(hipMemcpyAsync(h->sh_cf1[q].p, t.cf1.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(h->sh_cf2[q].p, t.cf2.p, m * d * 8, hipMemcpyDeviceToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(h->sh_w[q].p, t.w.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
+            }
+        }
+        out[q] = ScanCopy{h->sh_cen[q].p, h->sh_scl[q].p, h->sh_cf1[q].p, h->sh_cf2[q].p, h->sh_w[q].p, h->sh_kind[q].p,
+                          h->sh_key[q].p};
+    }
+}
+
 Versions versions_view(cc_handle* h)
 {
     return Versions{h->v_cf1.p, h->v_cf2.p, h->v_cen.p, h->v_pref.p, h->v_scl.p, h->v_w.p, h->v_kind.p,
                     h->v_key.p, h->v_next.p, h->v_upg.p, h->v_acc.p, h->v_tgt.p, h->v_dsq.p, h->v_tile_dsq.p,
-                    h->v_tau.p, h->v_skip.p, h->v_skip_car.p};
+                    h->v_tau.p, h->v_skip.p, h->v_skip_car.p, h->v_unsafe.p};
 }
 
 // ---- scan dispatch over the padded dimensionality ---------------------------------
@@ -310,8 +340,16 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;
+    // A lookahead scan shares the machine with the validation kernels of the previous window.  Four of its workgroups
+    // fill a CU's registers (4 x 120 of 512 per lane), and a validation kernel that needs more than the 32 left over
+    // only gets on when the scan has no workgroup left to dispatch; unused dynamic LDS limits the scan to three
+    // workgroups per CU, which leaves every SIMD a contiguous 152 registers.
+    size_t lds_pad = 0;
+    if (!DIRTY && mode == 1 && h->la_pad > 0) {
+        lds_pad = (size_t)h->la_pad;
+    }
 #define CC_LAUNCH_SCAN(F, P)                                                                                   \
-    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
+    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, lds_pad, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
                        part, round, mode, h->part_stride)
     if (filter) {
         if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
@@ -416,6 +454,10 @@ int cc_create(int device, cc_handle** out)
         // testing: CHRONOCLUST_HIP_DIRTY_WGS=n launches every dirty scan with n workgroups per segment (grid stride)
         const char* dw = getenv("CHRONOCLUST_HIP_DIRTY_WGS");
         h->force_dirty_wgs = dw ? atoi(dw) : 0;
+        const char* nd = getenv("CHRONOCLUST_HIP_NODIRTY");
+        h->allow_nodirty = !(nd && nd[0] == '0');
+        const char* lp = getenv("CHRONOCLUST_HIP_LA_PAD");
+        h->la_pad = lp ? atoi(lp) : 0;
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -557,6 +599,11 @@ int cc_online_run(cc_handle* h)
         // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
         // few workgroups per point tile then, the full split while they really run (set per batch below)
         int Sd = Sd_full;
+        // While k_dseed rules the dirty scans out for every tile they are not launched at all (beside a lookahead scan
+        // even a launch whose workgroups all return at once waits for registers until the scan has dispatched its last
+        // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
+        // if that stops a window at its first point, and the next batch launches them again.
+        bool nodirty = false;
         int dirty_wgs = h->force_dirty_wgs;  // > 0: the dirty scans are launched with this many workgroups per segment (grid stride over tiles)
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
@@ -613,6 +660,8 @@ int cc_online_run(cc_handle* h)
         for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
         push_ctl(h);
 
+        // no carry set yet: the commit record of an earlier call describes rows that may have moved since
+        HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
@@ -629,7 +678,7 @@ int cc_online_run(cc_handle* h)
         hipEvent_t evCommit = get_event(h, 2), evScan = nullptr;
         const size_t ev_base = 4;
         size_t ev_sync = ev_base;
-        ev_used = ev_base + 2 * (batch_max + 2);
+        ev_used = ev_base + 3 * (batch_max + 2);
 
         long long done = 0;
         int m_known = c.m_rows;
@@ -661,23 +710,35 @@ int cc_online_run(cc_handle* h)
             const int dblocks = (gw + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
             const int cblocks = (gw + 7) / 8;
             const int rblocks = std::min((gw + 7) / 8, 1024);
+            // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
+            // a batch, then kept up commit by commit
+            ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
+            if (la_on) scan_copy_sync(h, scopy);
+            Rows srows[2];
+            for (int q = 0; q < 2; ++q)
+                srows[q] = Rows{scopy[q].cen, scopy[q].scl, nullptr, scopy[q].cf1, scopy[q].cf2, scopy[q].w, scopy[q].kind,
+                                scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+            evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
+                    const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
                     if (timing) {
                         hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
                         HIPCHK(hipEventRecord(a, st));
-                        launch_scan<false>(h, st, gw, trows, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode);
                         HIPCHK(hipEventRecord(b, st));
                         timed.push_back({ev_used, 0.0});
                         ev_used += 2;
                     } else {
-                        launch_scan<false>(h, st, gw, trows, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode);
                     }
                 };
                 if (la_on) {
-                    // second stream: the snapshot scan of the window after this one, against the table as the
-                    // previous commit left it, while this window is validated on the first stream
+                    // first stream: this window's snapshot scan (enqueued one iteration ago on the second stream)
+                    if (evScan) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));
+                    // second stream: the snapshot scan of the window after this one, against the scan copy of its
+                    // parity (= the table as the previous commit left it), while this window is validated on the first
                     HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
                     timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
                     evScan = get_event(h, ev_sync++);
@@ -690,7 +751,13 @@ int cc_online_run(cc_handle* h)
                 }
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
                                    h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
-                                   h->dpath.p, S, Sd, 0);
+                                   h->dpath.p, S, Sd, 0, 0);
+                // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
+                // of the previous commit (before this window's commit overwrites the carry set), then, in k_commit_b,
+                // this window's own
+                const ScanCopy sc_now = scopy[seq_host & 1ull];
+                if (la_on)
+                    hipLaunchKernelGGL(k_apply_carry, dim3(rblocks), dim3(256), 0, sA, h->rec.p, car, sc_now, h->d, h->hc.filter);
                 for (int r = 1; r <= Rcur; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
@@ -698,16 +765,17 @@ int cc_online_run(cc_handle* h)
                                        h->ctl.p, h->X.p, tab, ver, car, told, r);
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, r);
-                    launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0, dirty_wgs);
-                    if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1, dirty_wgs);
+                    if (!nodirty) {
+                        launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0, dirty_wgs);
+                        if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1, dirty_wgs);
+                    }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
-                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r);
+                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r, nodirty ? 1 : 0);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                    h->rk.p, h->rec.p);
-                if (la_on) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));  // the lookahead scan reads the table
                 hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
-                                   h->lab_uid.p, h->lab_path.p, h->d);
+                                   h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
                 if (la_on) {
                     evCommit = get_event(h, ev_sync++);
                     HIPCHK(hipEventRecord(evCommit, sA));
@@ -731,7 +799,9 @@ int cc_online_run(cc_handle* h)
                 rounds_batch = Rcur;
                 unk_batch = h->hc.stat_trunc_unknown - unk_prev;
                 unk_prev = h->hc.stat_trunc_unknown;
-                if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
+                if (trunc > 0 && nodirty) {
+                    // points refused for want of the dirty scans: the next batch launches them again, nothing else changes
+                } else if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
                 else Rcur = std::max(1, std::min(Rcur, used));
             }
             {
@@ -754,7 +824,9 @@ int cc_online_run(cc_handle* h)
                 const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
                 const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
                 int want = h->hc.win_cfg;
-                if (trunc_batch * 4 >= wins && trunc_batch > 0 && rounds_batch < Rmax && unk_batch * 2 < trunc_batch) {
+                if (nodirty && trunc_batch > 0) {
+                    // (see above: windows stopped at points that needed the dirty scans)
+                } else if (trunc_batch * 4 >= wins && trunc_batch > 0 && rounds_batch < Rmax && unk_batch * 2 < trunc_batch) {
                     // windows stopped short because their decisions were still moving, with fewer validation rounds
                     // enqueued than allowed: more rounds (above) are the remedy, not a shorter window
                     h->clean_batches = 0;
@@ -780,6 +852,7 @@ int cc_online_run(cc_handle* h)
                 const bool quiet = tiles > 0 && dtiles * 16 < tiles;
                 Sd = quiet ? std::max(1, Sd_full / 8) : Sd_full;
                 dirty_wgs = h->force_dirty_wgs > 0 ? h->force_dirty_wgs : (quiet ? 16 : 0);
+                nodirty = h->allow_nodirty && tiles > 0 && dtiles == 0 && trunc_batch == 0;
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
                 if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {
                     h->hc.win_cfg = want;

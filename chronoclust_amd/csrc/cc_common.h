@@ -98,6 +98,10 @@ struct Versions {
     // so the dirty scan of the tile is not run and k_decide takes the seeds (k_dseed)
     int* skip;
     int* skip_car;
+    // per window point: 1 if some version row or carried row could matter to it beyond the seeds (k_dseed).  While no
+    // point is, the host stops launching the dirty scans; k_decide then refuses to decide such a point
+    // (CC_T_UNKNOWN: the window commits up to it and the host brings the dirty scans back)
+    int* unsafe;
 };
 
 // Read-only view the scan kernel walks (either the table or the version rows).

@@ -935,6 +935,10 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     if (!provable) tau = -CC_INF;
     tau_out = (tau == CC_INF) ? CC_INF : tau * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
     ver.tau[j] = tau_out;
+    // the same test as for the tile below, for this point alone
+    const bool ok_v = maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tau_out;
+    const bool ok_c = !la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tau_out);
+    ver.unsafe[j] = (ok_v && ok_c) ? 0 : 1;
     }
     // the tile as a whole: when even the largest displacement stays below every point's threshold, no row can matter
     // to any point of the tile and its dirty scan is not run at all (the same test k_scan makes per 16 rows)
@@ -961,7 +965,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const Cand* __restrict__ dpart, const Cand* __restrict__ dpart2,
                                                 const Cand* __restrict__ dseed,
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
-                                                int8_t* __restrict__ dpath, int S, int Sd, int round)
+                                                int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1007,8 +1011,9 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     if (round > 0) {
         Cand dummy = none;
         // a dirty scan that k_dseed ruled out for this point's tile was not run: the seeds are its whole result
-        const bool ran = ver.skip[j >> 6] == 0;
-        const bool ran_car = la_mode && ver.skip_car[j >> 6] == 0;
+        // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
+        const bool ran = nodirty == 0 && ver.skip[j >> 6] == 0;
+        const bool ran_car = nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
         if (gl == 0 && !(ran && (ran_car || !la_mode))) {
             dvp = dseed[(size_t)j * 4 + 0];
             dvo = dseed[(size_t)j * 4 + 2];
@@ -1094,6 +1099,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         T = M0 + j;
         path = 2;
     }
+    if (round > 0 && nodirty != 0 && ver.unsafe[j] != 0) T = CC_T_UNKNOWN;  // the seeds are not this point's whole story
     if (gl == 0) {
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
@@ -1323,6 +1329,21 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 // touched MC back into the table.
 // ---------------------------------------------------------------------------------
 
+// Scan copies of the table (lookahead).  Lookahead scans do not read the table but one of two copies of the columns a
+// scan needs, so that a commit never waits for a scan that is still reading.  The copy with the parity of window W
+// is read by the snapshot scan of W (which saw the table two commits earlier... one commit before W - 1's) and is
+// brought up to date during W's validation: first the rows the previous commit changed (its carry set,
+// k_apply_carry), then the rows W's own commit changes (k_commit_b).  It is next read by the scan of W + 2.
+struct ScanCopy {
+    double* cen;
+    double* scl;
+    double* cf1;  // cf1, cf2, w: read by the pdim filter only
+    double* cf2;
+    double* w;
+    int* kind;
+    int* key;
+};
+
 struct CommitRec {
     int n;        // validated prefix length
     int M0;       // table rows at window start
@@ -1348,12 +1369,13 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     __shared__ int tot;
     __shared__ int dirty_tiles;
     const int r = ctl->last_round;
+    const bool la_win = ctl->mode != 0;  // this window's snapshot scan ran ahead (read before thread 0 moves on)
     if (threadIdx.x == 0) dirty_tiles = 0;
     __syncthreads();
     // point tiles whose dirty scan ran in the last validation round (the host keeps windows short while most do)
     const int n_tiles = (r >= 1) ? (B + 63) / 64 : 0;
     for (int i = threadIdx.x; i < n_tiles; i += 1024)
-        if (ver.skip[i] == 0) atomicAdd(&dirty_tiles, 1);
+        if (ver.skip[i] == 0 || (la_win && ver.skip_car[i] == 0)) atomicAdd(&dirty_tiles, 1);
     const int* T = ((r - 1) & 1) ? Tbuf1 : Tbuf0;
     const int fcv = ctl->fc[r];
     const int n = fcv < B ? fcv : B;
@@ -1449,7 +1471,8 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
         ctl->window_seq = seq + 1ull;
-        if (ctl->la_on != 0 && !la_ok && next_b > 0) {
+        if ((ctl->la_on != 0 && !la_ok && next_b > 0) || n == 0) {
+            // (n == 0: the first point could not be decided without the dirty scans the host had stopped launching)
             // no usable lookahead scan and, in a lookahead batch, no in-place scan either: wait for the host
             ctl->stall_b = next_b;
             ctl->win_b = 0;
@@ -1470,7 +1493,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
 __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ rec, Table tab, Versions ver,
                                                   Carry car, const int* __restrict__ rk,
                                                   const int8_t* __restrict__ dpath, long long* __restrict__ lab_uid,
-                                                  int8_t* __restrict__ lab_path, int d)
+                                                  int8_t* __restrict__ lab_path, int d, ScanCopy sc, int filter)
 {
     CC_LATENCY_KERNEL();
     const int n = rec->n;
@@ -1518,6 +1541,10 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                 dq += df * df * ow;
             }
             tab.cf1[e] = n1; tab.cf2[e] = n2; tab.cen[e] = ncen; tab.pref[e] = npref; tab.scl[e] = nscl;
+            if (sc.cen) {
+                sc.cen[e] = ncen; sc.scl[e] = nscl;
+                if (filter) { sc.cf1[e] = n1; sc.cf2[e] = n2; }
+            }
         }
         if (carry) {
             for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
@@ -1534,6 +1561,11 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                 tab.id[row] = rec->oid0 + (rk[c] & 0xFFFF);
             }
             if (t >= M0) tab.uid[row] = rec->oid0 + (rk[c] & 0xFFFF);
+            if (sc.cen) {
+                sc.kind[row] = kind;
+                sc.key[row] = key;
+                if (filter) sc.w[row] = ver.w[j];
+            }
             if (carry) {
                 car.w[j] = ver.w[j];
                 car.kind[j] = kind;
@@ -1544,6 +1576,35 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                 atomicMax(&car.tile_dsq[j >> 4], (unsigned long long)__double_as_longlong(dq));
                 tab.carry_of[row] = (rec->next_seq << 20) | (unsigned long long)j;
             }
+        }
+    }
+}
+
+// the carry set of the previous commit -> the scan copy of the current window's parity; one 32-lane group per carried row
+__global__ __launch_bounds__(256) void k_apply_carry(const CommitRec* __restrict__ rec, Carry car, ScanCopy sc, int d,
+                                                     int filter)
+{
+    if (rec->carry == 0) return;
+    const int n = rec->n;
+    const int gl = threadIdx.x & 31;
+    const int groups = (gridDim.x * blockDim.x) >> 5;
+    for (int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; j < n; j += groups) {
+        const int kind = car.kind[j];
+        if (kind == CC_KIND_DEAD) continue;  // a later point holds the last version of this MC
+        const size_t row = (size_t)car.slot[j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i >= d) continue;
+            const size_t e = row * d + i, v = (size_t)j * d + i;
+            sc.cen[e] = car.cen[v];
+            sc.scl[e] = car.scl[v];
+            if (filter) { sc.cf1[e] = car.cf1[v]; sc.cf2[e] = car.cf2[v]; }
+        }
+        if (gl == 0) {
+            sc.kind[row] = kind;
+            sc.key[row] = car.key[j];
+            if (filter) sc.w[row] = car.w[j];
         }
     }
 }
