@@ -334,9 +334,8 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
-    // dirty scans: tile_wgs > 0 = that many workgroups walk the point tiles (grid stride) instead of one each
-    const int tiles = (win + 63) / 64;
-    const dim3 grid((DIRTY && tile_wgs > 0) ? std::min(tiles, tile_wgs) : tiles, S);
+    (void)tile_wgs;
+    const dim3 grid((win + 63) / 64, S);
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;

@@ -137,6 +137,9 @@ struct Ctl {
     int max_rounds;
     int last_round;      // last validation round that ran for the current window
     int fc[CC_MAX_ROUNDS + 2];  // fc[r]: first point whose decision changed in round r (>= win_b: converged)
+    // any_new[r]: some decision of round r creates a MC (k_decide); any_up[r]: some add replayed in round r promotes
+    // one (k_chain).  Plain flags; while both are clear k_commit_a has nothing to rank.
+    int any_new[CC_MAX_ROUNDS + 2], any_up[CC_MAX_ROUNDS + 2];
     // parameters (cc_params, see include/chronoclust_hip.h)
     double eps_sq, delta_sq, k, inv_k, beta_mu, mu, omicron;
     int pi;

@@ -180,7 +180,7 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
 template <int DP, bool FILTER, bool POW2, bool DIRTY, int NW>
-__global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
+__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : 1)) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
@@ -217,10 +217,8 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
     const bool carried = DIRTY && mode == 1;
     const int car_n = carried ? ((ctl->mode != 0) ? ctl->car_n : 0) : 0;
     if (carried && car_n == 0) return;
-    // One point tile.  The clean scan runs one tile per workgroup.  The dirty scans walk the tiles with a grid stride:
-    // while k_dseed rules them out tile by tile the host launches a few workgroups only (a launch of one fat
-    // workgroup per tile that all return at once still has to find room beside a lookahead scan - measured: 200 us).
-    auto do_tile = [&](const int bx) {
+    const int bx = (int)blockIdx.x;
+    {
     const int j0 = bx * (64 * PT);
     if (j0 >= B) return;
     if (DIRTY && rows.skip[bx] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
@@ -685,13 +683,7 @@ __global__ __launch_bounds__(64 * NW) void k_scan(const Ctl* __restrict__ ctl,
             o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
         }
     }
-    };
-    if (!DIRTY) do_tile((int)blockIdx.x);
-    else
-        for (int bx = blockIdx.x; bx * (64 * PT) < B; bx += gridDim.x) {
-            do_tile(bx);
-            __syncthreads();  // the merge exchange of this tile shares its bytes with the next tile's rows
-        }
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -847,9 +839,21 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         const unsigned long long cw = tab.cnt[slot];
         const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
         const int n_list = n_memb < CC_CHAIN_MEMB ? n_memb : CC_CHAIN_MEMB;
-        for (int i = 0; i < n_list; ++i) {
-            const int m = tab.memb[(size_t)slot * CC_CHAIN_MEMB + i];
-            v = (m < j && m > v) ? m : v;
+        if (n_list > 0) {
+            // the list is one 128-byte row: eight 16-byte loads in flight, entries past n_list are ignored
+            const int4* mrow = reinterpret_cast<const int4*>(tab.memb + (size_t)slot * CC_CHAIN_MEMB);
+            int4 mm[CC_CHAIN_MEMB / 4];
+#pragma unroll
+            for (int q = 0; q < CC_CHAIN_MEMB / 4; ++q) mm[q] = mrow[q];
+#pragma unroll
+            for (int q = 0; q < CC_CHAIN_MEMB / 4; ++q) {
+                const int e[4] = {mm[q].x, mm[q].y, mm[q].z, mm[q].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int m = e[c];
+                    v = (q * 4 + c < n_list && m < j && m > v) ? m : v;
+                }
+            }
         }
         if (n_memb > CC_CHAIN_MEMB)
             for (int steps = 0; ver.next[v] < j; ++steps) {
@@ -866,11 +870,23 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         if (kv == CC_KIND_DEAD) return;
         const double* vcen = (cr ? car.cen : ver.cen) + r * d;
         const double* vpref = (cr ? car.pref : ver.pref) + r * d;
+        // (one thread per point: the loads of eight dimensions are requested together, the sum stays left to right)
         double acc = 0.0;
-        for (int i = 0; i < d; ++i) {
-            double x = p[i] - vcen[i];
-            x = x * x;
-            acc = acc + cc_div_pref(x, vpref[i], par);
+        for (int i0 = 0; i0 < d; i0 += 8) {
+            double pv[8], cv[8], fv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = (i0 + q < d) ? i0 + q : d - 1;
+                pv[q] = p[i]; cv[q] = vcen[i]; fv[q] = vpref[i];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (i0 + q < d) {
+                    double x = pv[q] - cv[q];
+                    x = x * x;
+                    acc = acc + cc_div_pref(x, fv[q], par);
+                }
+            }
         }
         if (kv == 0 && filter) {
             int ne1 = 0;
@@ -1098,6 +1114,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     if (T == -1) {  // hddstream.py:434-462: new outlier MC, provisional id = rows-at-window-start + j
         T = M0 + j;
         path = 2;
+        if (gl == 0) ctl->any_new[round] = 1;
     }
     if (round > 0 && nodirty != 0 && ver.unsafe[j] != 0) T = CC_T_UNKNOWN;  // the seeds are not this point's whole story
     if (gl == 0) {
@@ -1279,6 +1296,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 // hddstream.py:416-430: promotion is only examined after an add to an existing outlier MC
                 if (bkind == CC_KIND_OUTLIER && !creates && w1 >= par.beta_mu && g.gt1 <= par.pi) {
                     bkind = CC_KIND_PCORE; bkey = pk_base + cur; bupg = cur;
+                    if (gl == 0) ctl->any_up[round] = 1;
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1391,6 +1409,10 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     // every thread ranks a contiguous run of points (packed counts: low 16 bits creations, high 16 bits
     // promotions; B <= 32768).
     __shared__ unsigned char sflag[32768];
+    // (steady state: nothing was created or promoted in this window - nothing to rank, k_commit_b never reads rk)
+    const bool events = ctl->any_new[r - 1] != 0 || ctl->any_up[r] != 0;
+    if (threadIdx.x == 0) tot = 0;
+    if (events) {
     for (int j = tid; j < B; j += 1024)
         sflag[j] = (j < n) ? (unsigned char)(((T[j] == M0 + j) ? 1 : 0) | ((ver.upg[j] == j) ? 2 : 0)) : (unsigned char)0;
     __syncthreads();
@@ -1424,6 +1446,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
             const int f = (int)sflag[j];
             run += (f & 1) | ((f & 2) << 15);
         }
+    }
     }
     __syncthreads();
     const int tot_new = tot & 0xFFFF, tot_up = tot >> 16;
@@ -1484,6 +1507,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->last_round = 0;
         ctl->fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) ctl->fc[i] = CC_IDX_INF;
+        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) { ctl->any_new[i] = 0; ctl->any_up[i] = 0; }
     }
 }
 
