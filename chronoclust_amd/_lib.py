@@ -53,6 +53,9 @@ SYMBOLS = {
     "cc_decay_downgrade": (C.c_int, [C.c_void_p, C.c_double]),
     "cc_points_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32]),
     "cc_online_run": (C.c_int, [C.c_void_p]),
+    "cc_col_minmax": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
+    "cc_points_upload_scaled": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
+    "cc_points_download": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "cc_labels_download": (C.c_int, [C.c_void_p, _i64p, _i8p]),
     "cc_online": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _i64p, _i8p]),
     "cc_count": (C.c_int, [C.c_void_p, C.c_int]),
@@ -154,6 +157,32 @@ class Handle(object):
             raise ValueError("points must be a 2-d array")
         self._check(self._lib.cc_points_upload(self._h, _ptr(x), x.shape[0], x.shape[1]))
         self._n = x.shape[0]
+
+    def col_minmax(self, x):
+        """Per-column (min, max) of x, NaN ignored, reduced on the device."""
+        x = _f64(x)
+        mn = np.empty(x.shape[1], dtype=np.float64)
+        mx = np.empty(x.shape[1], dtype=np.float64)
+        self._check(self._lib.cc_col_minmax(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(mn), _ptr(mx)))
+        return mn, mx
+
+    def points_upload_scaled(self, x, scale, min_):
+        """points_upload of x * scale + min_ (MinMaxScaler.transform), scaled on the device."""
+        x, scale, min_ = _f64(x), _f64(scale), _f64(min_)
+        if x.ndim != 2 or scale.shape != (x.shape[1],) or min_.shape != (x.shape[1],):
+            raise ValueError("points must be [n, d], scale and min_ [d]")
+        self._check(self._lib.cc_points_upload_scaled(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(scale), _ptr(min_)))
+        self._n = x.shape[0]
+
+    def points_download(self, d, scale=None, min_=None):
+        """The resident points; with scale / min_, (X - min_) / scale (MinMaxScaler.inverse_transform)."""
+        out = np.empty((self._n, d), dtype=np.float64)
+        if scale is None:
+            self._check(self._lib.cc_points_download(self._h, _ptr(out), None, None))
+        else:
+            scale, min_ = _f64(scale), _f64(min_)
+            self._check(self._lib.cc_points_download(self._h, _ptr(out), _ptr(scale), _ptr(min_)))
+        return out
 
     def online_run(self):
         self._check(self._lib.cc_online_run(self._h))

@@ -17,7 +17,7 @@ import pandas as pd
 
 from .clustering.hddstream import HDDStream
 from .objects.cluster import Cluster
-from .scaling.scaler import Scaler
+from .scaling.scaler import Scaler, read_timepoint
 from .tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
 
 HDDSTREAM_OBJ = 'hddstream'
@@ -73,19 +73,21 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
     scaler = None
     if normalise_data:
         logger.info("Setting up scaler")
-        scaler = Scaler(data)
+        scaler = Scaler(data, handle=hddstream._h)  # column min / max reduced on the device, files parsed once
 
     for timepoint, data_file in enumerate(data):
         if restoring and hddstream.last_data_timestamp >= timepoint:
             continue  # already processed before the checkpoint (app.py:165-166)
         logger.info("Processing dataset {}".format(timepoint))
-        raw = pd.read_csv(data_file, header=0, sep=',').to_numpy()
-        dataset = raw
+        raw = scaler.parsed.pop(data_file, None) if scaler is not None else None
+        if raw is None:
+            raw = read_timepoint(data_file)
         if normalise_data:
+            # MinMaxScaler.transform runs on the device as part of the upload (cc_points_upload_scaled)
             logger.info("Scaling dataset {}".format(timepoint))
-            dataset = scaler.scale_data(raw)
-
-        hddstream.online_microcluster_maintenance(dataset, timepoint)
+            hddstream.online_microcluster_maintenance(raw, timepoint, device_scaling=(scaler.scale_, scaler.min_))
+        else:
+            hddstream.online_microcluster_maintenance(raw, timepoint)
         pcore_by_id = {mc.id[0]: mc for mc in hddstream.pcore_MC}
 
         for found in hddstream.final_clusters:
@@ -102,7 +104,7 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
 
         write_result_file(gating, result_filename, timepoint, tracker_by_association, scaler=scaler)
         write_datapoints_details(dataset_attributes, tracker_by_lineage.child_clusters, hddstream,
-                                 raw, dataset, f'{output_directory}/cluster_points_D{timepoint}.csv', scaler)
+                                 raw, f'{output_directory}/cluster_points_D{timepoint}.csv', scaler)
 
         tracker_by_lineage.transfer_child_to_parent()
         tracker_by_association.transfer_current_to_previous()
@@ -138,13 +140,13 @@ def write_result_file(gating, result_filename, timepoint, tracker_by_association
     append_to_file(result_filename, rows)
 
 
-def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, scaled, cluster_points_filename, scaler):
+def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, cluster_points_filename, scaler):
     """id, cluster_id, <features> for every point of the timepoint, in input order (app.py:263-360).
 
     The reference walks per-microcluster `points` dicts; here the per-point microcluster labels are one int64
     array (creation number of the MC holding each row), joined to the lineage ids by lookup."""
     write_file_header(cluster_points_filename, ['id', 'cluster_id'] + dataset_attributes)
-    n = scaled.shape[0]
+    n = raw.shape[0]
     pcore = hddstream.table(0)
     uid_of_pcore = {int(i): int(u) for i, u in zip(pcore["id"], pcore["uid"])}
     label_of_uid = {}
@@ -156,7 +158,8 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, scale
     cluster_ids = names[inverse] if n else np.empty(0, dtype=object)
 
     if scaler:
-        values = scaler.reverse_scaling(scaled)
+        # the reference writes inverse_transform(transform(raw)), not raw: (X - min_) / scale_ on the device
+        values = hddstream.resident_points(scaler.scale_, scaler.min_)
     else:
         values = raw
     columns = {'id': np.arange(n, dtype=np.int64), 'cluster_id': cluster_ids}
@@ -211,6 +214,13 @@ def append_to_file(filename, content):
 
 
 def get_dataset_attributes(dataset_file):
+    if str(dataset_file).endswith(".npy"):
+        # binary side input: column names from `<file>.columns` (one name per line) if present
+        names_file = str(dataset_file) + ".columns"
+        if os.path.exists(names_file):
+            with open(names_file) as f:
+                return [line.strip() for line in f if line.strip()]
+        return ["m%d" % i for i in range(np.load(dataset_file, mmap_mode="r").shape[1])]
     return pd.read_csv(dataset_file, sep=',', header=None).iloc[0].values.tolist()
 
 

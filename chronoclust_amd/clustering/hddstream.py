@@ -75,7 +75,10 @@ class HDDStream(object):
 
     # ---- the timestep ---------------------------------------------------------------------------
 
-    def online_microcluster_maintenance(self, input_dataset, input_dataset_daystamp, reset_param=True):
+    def online_microcluster_maintenance(self, input_dataset, input_dataset_daystamp, reset_param=True,
+                                        device_scaling=None):
+        """device_scaling=(scale_, min_): `input_dataset` holds raw values and MinMaxScaler.transform
+        (X * scale_ + min_) is applied on the device during the upload (scaling/scaler.py:39-41)."""
         X = np.ascontiguousarray(np.asarray(input_dataset, dtype=np.float64))
         if X.ndim != 2:
             raise ValueError("input_dataset must be 2-d [N, d]")
@@ -100,8 +103,13 @@ class HDDStream(object):
             self._h.decay_downgrade(2 ** (-self.lambbda * interval))  # hddstream.py:283
 
         log.info("Starting online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
-        self._X = X
-        if X.shape[0] > 0:
+        self._X = X if device_scaling is None else None  # scaled values are fetched from the device on demand
+        self._n_points = X.shape[0]
+        if X.shape[0] > 0 and device_scaling is not None:
+            self._h.points_upload_scaled(X, device_scaling[0], device_scaling[1])
+            self._h.online_run()
+            self.labels_uid, self.labels_path = self._h.labels_download()
+        elif X.shape[0] > 0:
             self.labels_uid, self.labels_path = self._h.online(X)
         else:
             self.labels_uid, self.labels_path = np.empty(0, np.int64), np.empty(0, np.int8)
@@ -160,7 +168,16 @@ class HDDStream(object):
     def outlier_MC_last_id(self):
         return self._h.counters()[1]
 
+    def resident_points(self, scale=None, min_=None):
+        """The points of the last timepoint as the device holds them; with scale / min_ the inverse transform
+        (X - min_) / scale_ is applied on the device first (scaling/scaler.py:43-44)."""
+        if not getattr(self, "_n_points", 0):
+            return np.empty((0, self.dataset_dimensionality or 0))
+        return self._h.points_download(self.dataset_dimensionality, scale, min_)
+
     def _points_of(self, uid):
+        if self.labels_uid is not None and self._X is None and getattr(self, "_n_points", 0):
+            self._X = self.resident_points()
         if self.labels_uid is None or self._X is None:
             return {}
         if self._uid_rows is None:

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <type_traits>
+#include <limits>
 #include <vector>
 
 #include "../../include/chronoclust_hip.h"
@@ -125,6 +126,7 @@ struct cc_handle {
     DevBuf<long long> lab_uid;
     DevBuf<int8_t> lab_path;
     DevBuf<int> badflag;
+    DevBuf<double> scr, scr2;  // scaler scratch
 
     // window buffers
     int win_alloc = 0, seg_alloc = 0, d_alloc = 0;
@@ -555,32 +557,102 @@ int cc_set_counters(cc_handle* h, int64_t pcore_last_id, int64_t outlier_last_id
     });
 }
 
+static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn);
+
 int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d)
 {
     if (!h || (!x && n > 0) || n < 0) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() { return upload_points(h, x, n, d, nullptr, nullptr); });
+}
+
+// MinMax scaling on the device (scaling/scaler.py:27-47).  cc_col_minmax: per-column min / max of a host buffer,
+// NaN ignored (what MinMaxScaler.partial_fit takes from one file); cc_points_upload_scaled: cc_points_upload of
+// x * scale + min_; cc_points_download_unscaled: (resident points - min_) / scale back to the host.
+int cc_col_minmax(cc_handle* h, const double* x, int64_t n, int32_t d, double* out_min, double* out_max)
+{
+    if (!h || !x || n <= 0 || d <= 0 || d > CC_MAX_DIM || !out_min || !out_max) return CC_ERR_BAD_ARG;
     return guarded(h, [&]() {
-        int rc = set_dim(h, d);
-        if (rc != CC_OK) return rc;
-        h->X.ensure((size_t)n * d);
-        h->Xt.ensure((size_t)n * d);
-        h->lab_uid.ensure((size_t)n);
-        h->lab_path.ensure((size_t)n);
-        h->n_points = n;
-        if (n == 0) return (int)CC_OK;
-        HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
-        const long long tot = (long long)n * d;
-        int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
-        hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
-                           h->Xt.p, (long long)n, (int)d);
-        int bad = 0;
-        HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
+        h->scr.ensure((size_t)n * d);
+        const int chunks = (int)std::min<long long>(1024, (n + 255) / 256);
+        h->scr2.ensure((size_t)2 * chunks * d);
+        HIPCHK(hipMemcpyAsync(h->scr.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_col_minmax, dim3(chunks), dim3(256), 0, h->stream, h->scr.p, (long long)n, (int)d, h->scr2.p,
+                           chunks);
+        std::vector<double> part((size_t)2 * chunks * d);
+        HIPCHK(hipMemcpyAsync(part.data(), h->scr2.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        if (bad) {
-            h->n_points = 0;
-            return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
+        for (int c = 0; c < d; ++c) {
+            double mn = std::numeric_limits<double>::infinity(), mx = -mn;
+            for (int b = 0; b < chunks; ++b) {
+                mn = std::fmin(mn, part[(size_t)b * d + c]);
+                mx = std::fmax(mx, part[(size_t)(chunks + b) * d + c]);
+            }
+            out_min[c] = mn;
+            out_max[c] = mx;
         }
+        return (int)CC_OK;
+    });
+}
+
+static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn)
+{
+    int rc = set_dim(h, d);
+    if (rc != CC_OK) return rc;
+    h->X.ensure((size_t)n * d);
+    h->Xt.ensure((size_t)n * d);
+    h->lab_uid.ensure((size_t)n);
+    h->lab_path.ensure((size_t)n);
+    h->n_points = n;
+    if (n == 0) return (int)CC_OK;
+    HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
+    const long long tot = (long long)n * d;
+    if (scale) {
+        h->scr2.ensure((size_t)2 * d);
+        HIPCHK(hipMemcpyAsync(h->scr2.p, scale, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->scr2.p + d, mn, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_scale_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p, tot, (int)d,
+                           h->scr2.p, h->scr2.p + d);
+    }
+    int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
+    hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
+                       h->Xt.p, (long long)n, (int)d);
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (bad) {
+        h->n_points = 0;
+        return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
+    }
+    return (int)CC_OK;
+}
+
+int cc_points_upload_scaled(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* min_)
+{
+    if (!h || (!x && n > 0) || n < 0 || !scale || !min_) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() { return upload_points(h, x, n, d, scale, min_); });
+}
+
+int cc_points_download(cc_handle* h, double* out, const double* scale, const double* min_)
+{
+    if (!h || !out || ((scale == nullptr) != (min_ == nullptr))) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        const long long tot = h->n_points * (long long)h->d;
+        if (tot == 0) return (int)CC_OK;
+        const int d = h->d;
+        if (!scale) {
+            HIPCHK(hipMemcpyAsync(out, h->X.p, (size_t)tot * 8, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            h->scr.ensure((size_t)tot);
+            h->scr2.ensure((size_t)2 * d);
+            HIPCHK(hipMemcpyAsync(h->scr2.p, scale, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->scr2.p + d, min_, (size_t)d * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_unscale_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p, h->scr.p,
+                               tot, d, h->scr2.p, h->scr2.p + d);
+            HIPCHK(hipMemcpyAsync(out, h->scr.p, (size_t)tot * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
         return (int)CC_OK;
     });
 }

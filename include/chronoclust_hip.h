@@ -162,6 +162,21 @@ int cc_clusters_total_members(cc_handle* h);
 int cc_clusters_export(cc_handle* h, int64_t* members, int32_t* offsets, double* w, double* cf1, double* cf2,
                        double* cen, double* pref);
 
+/* MinMax scaling on the device (scaling/scaler.py:27-47, i.e. scikit-learn's
+ * MinMaxScaler.partial_fit / transform / inverse_transform, feature range [0, 1]):
+ *   cc_col_minmax              : per-column minimum / maximum of x[n, d], NaN ignored
+ *                                (np.nanmin / np.nanmax); the caller folds the files of
+ *                                all timepoints and forms scale_ = 1 / range
+ *                                (range < 10 eps -> 1), min_ = 0 - data_min * scale_
+ *   cc_points_upload_scaled    : cc_points_upload of x * scale_ + min_ (two roundings,
+ *                                as numpy evaluates transform), scaled on the device
+ *   cc_points_download         : the resident points back to the host; with scale_ / min_
+ *                                given, (X - min_) / scale_ (inverse_transform), else as held */
+int cc_col_minmax(cc_handle* h, const double* x, int64_t n, int32_t d, double* out_min, double* out_max);
+int cc_points_upload_scaled(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale,
+                            const double* min_);
+int cc_points_download(cc_handle* h, double* out, const double* scale, const double* min_);
+
 /* TrackByHistoricalAssociation.track_cluster_history (cluster_tracker.py:127-141):
  * for every current pcore (cur_cen/cur_pref [mc,d]) the index of the previous
  * pcore (prev_cen [mp,d], given in iteration order) with the smallest

@@ -184,3 +184,32 @@ def test_restore_program_continues_exactly(tmp_path):
     for t in range(5):
         exp_text = gzip.decompress(rec["t%d_points_csv" % t].tobytes())
         assert open(os.path.join(out, "cluster_points_D%d.csv" % t), "rb").read() == exp_text
+
+
+@pytest.mark.parametrize("name", ["d5_norm", "d20"])
+def test_binary_side_input_gives_the_same_files(name, tmp_path):
+    """`.npy` timepoints (no text parse) against the same values read from CSV: result.csv and the
+    per-point files must be byte-identical (d5_norm runs with normalise_data=True: device-side scaler)."""
+    from chronoclust_amd import app
+    sc = scenarios.BLOB_SCENARIOS[name]
+    Xs = scenarios.make_blob_timepoints(sc)  # what pd.read_csv returns for the scenario's CSV files
+    outs = []
+    for kind in ("csv", "npy"):
+        files = []
+        for t, X in enumerate(Xs):
+            fn = os.path.join(str(tmp_path), "tp%d.%s" % (t, kind))
+            if kind == "csv":
+                pd.DataFrame(scenarios.make_blob_timepoints(sc, raw=True)[t],
+                             columns=["m%d" % i for i in range(sc["d"])]).to_csv(fn, index=False)
+            else:
+                np.save(fn, X)
+            files.append(fn)
+        out = os.path.join(str(tmp_path), "out_" + kind)
+        os.makedirs(out)
+        try:
+            app.run(data=files, output_directory=out, normalise_data=sc.get("normalise", False), **sc["params"])
+        finally:
+            _reset_logging()
+        outs.append(out)
+    for fn in ["result.csv"] + ["cluster_points_D%d.csv" % t for t in range(len(Xs))]:
+        assert open(os.path.join(outs[0], fn), "rb").read() == open(os.path.join(outs[1], fn), "rb").read(), fn

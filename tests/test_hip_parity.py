@@ -225,3 +225,34 @@ def test_offline_intermediates_against_oracle():
         for key in ("core", "pdim", "nn", "nw"):
             np.testing.assert_array_equal(info[key], o.offline_dump[key], err_msg="%s t=%d" % (key, t))
         assert info["nn"].max() > 1  # the eps-neighbourhoods are not all singletons
+
+
+@pytest.mark.parametrize("n,d", [(1, 1), (7, 3), (1000, 20), (100003, 14), (5000, 64)])
+def test_device_scaler_matches_the_restated_minmaxscaler(n, d):
+    """cc_col_minmax / cc_points_upload_scaled / cc_points_download against chronoclust_amd.scaling.scaler.Scaler's
+    numpy arithmetic (itself checked bit for bit against scikit-learn in tests/test_host_logic.py)."""
+    from chronoclust_amd import _lib
+    from chronoclust_amd.scaling.scaler import Scaler
+    rng = np.random.default_rng(n + d)
+    X = rng.normal(3.0, 50.0, (n, d)) * rng.uniform(1e-3, 1e3, d)
+    if d > 2:
+        X[:, 1] = 7.25          # zero range: scale_ stays 1
+    if n > 5:
+        X[3, 0] = X[:, 0].max() + 1.0
+    hd = _lib.Handle(0)
+    mn, mx = hd.col_minmax(X)
+    np.testing.assert_array_equal(mn, X.min(axis=0))
+    np.testing.assert_array_equal(mx, X.max(axis=0))
+    Xn = X.copy()
+    if n > 5:
+        Xn[2, d - 1] = np.nan    # ignored by the fit, like np.nanmin / np.nanmax
+        mn2, mx2 = hd.col_minmax(Xn)
+        np.testing.assert_array_equal(mn2, np.nanmin(Xn, axis=0))
+        np.testing.assert_array_equal(mx2, np.nanmax(Xn, axis=0))
+    ref = Scaler()
+    ref.fit_scaler(X)
+    hd.points_upload_scaled(X, ref.scale_, ref.min_)
+    scaled = hd.points_download(d)
+    assert np.array_equal(scaled, ref.scale_data(X))
+    back = hd.points_download(d, ref.scale_, ref.min_)
+    assert np.array_equal(back, ref.reverse_scaling(ref.scale_data(X)))
