@@ -821,106 +821,155 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     const double K = par.k >= 1.0 ? par.k : 1.0 / par.k;  // worst-case ratio of a dimension's weight before / after
 
     const unsigned long long wseq = ctl->window_seq;
-    // the live version of MC `slot` when point j arrives (-1: untouched so far, -2: not found in 16 steps,
+    // Four lookups per point - best and second-best snapshot candidate of either kind -, each a chain of dependent
+    // loads (validation stamp -> member list -> version row -> its centroid).  One thread per point: the four chains
+    // advance in lock step, so that every step's loads are in flight together.
+    Cand cq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cq[q] = clean[(size_t)j * 4 + q];
+    double d2v[2] = {CC_INF, CC_INF};
+    bool have1[2];
+    bool look[4];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd) {
+        if (cq[kd * 2 + 1].slot >= 0) d2v[kd] = cq[kd * 2 + 1].dist;
+        have1[kd] = cq[kd * 2].slot >= 0;  // no snapshot candidate of this kind: cap stays +inf
+        look[kd * 2] = have1[kd];
+        look[kd * 2 + 1] = have1[kd] && cq[kd * 2 + 1].slot >= 0;
+    }
+    // step 1: validation stamp, member count, carry mark of the four MCs
+    unsigned long long tcq[4], cwq[4], coq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const size_t sl = (size_t)(look[q] ? cq[q].slot : 0);
+        tcq[q] = look[q] ? tab.touch[(size_t)(round & 1) * tab.cap + sl] : 0ull;
+        cwq[q] = look[q] ? tab.cnt[sl] : 0ull;
+        coq[q] = (look[q] && la_mode) ? tab.carry_of[sl] : 0ull;
+    }
+    // the live version of the MC when point j arrives (-1: untouched so far, -2: not found,
     // >= CC_CAR_BASE: the carried row - the previous window changed the MC after this window's snapshot scan)
-    auto live_version = [&](int slot) -> int {
-        const unsigned long long tc = tab.touch[(size_t)(round & 1) * tab.cap + slot];
-        const int head = 0xFFFFF - (int)(tc & 0xFFFFFull);
-        if ((tc >> 20) != stamp || head >= j) {
-            if (la_mode) {
-                const unsigned long long co = tab.carry_of[slot];
-                if ((co >> 20) == wseq) return CC_CAR_BASE + (int)(co & 0xFFFFFull);
-            }
-            return -1;
+    int lv[4], n_memb[4];
+    bool walk[4];
+    int max_list = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int head = 0xFFFFF - (int)(tcq[q] & 0xFFFFFull);
+        lv[q] = -1;
+        walk[q] = false;
+        n_memb[q] = 0;
+        if (!look[q]) continue;
+        if ((tcq[q] >> 20) != stamp || head >= j) {
+            if (la_mode && (coq[q] >> 20) == wseq) lv[q] = CC_CAR_BASE + (int)(coq[q] & 0xFFFFFull);
+        } else {
+            // the latest claimant before j: the largest listed member of the MC's chain below j (k_decide listed up
+            // to CC_CHAIN_MEMB of them), then along the chain for the members the list does not hold
+            lv[q] = head;
+            walk[q] = true;
+            n_memb[q] = ((cwq[q] >> 24) == stamp) ? (int)(cwq[q] & 0xFFFFFFull) : 0;
+            const int n_list = n_memb[q] < CC_CHAIN_MEMB ? n_memb[q] : CC_CHAIN_MEMB;
+            max_list = n_list > max_list ? n_list : max_list;
         }
-        // the latest claimant before j: the largest listed member of the MC's chain below j (k_decide listed up to
-        // CC_CHAIN_MEMB of them, one 128-byte read), then along the chain for the members the list does not hold
-        int v = head;
-        const unsigned long long cw = tab.cnt[slot];
-        const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
-        const int n_list = n_memb < CC_CHAIN_MEMB ? n_memb : CC_CHAIN_MEMB;
-        if (n_list > 0) {
-            // the list is one 128-byte row: eight 16-byte loads in flight, entries past n_list are ignored
-            const int4* mrow = reinterpret_cast<const int4*>(tab.memb + (size_t)slot * CC_CHAIN_MEMB);
-            int4 mm[CC_CHAIN_MEMB / 4];
+    }
+    // step 2: the member lists, four entries of each list per pass
+    for (int pos = 0; pos * 4 < max_list; ++pos) {
+        int4 mm[4];
 #pragma unroll
-            for (int q = 0; q < CC_CHAIN_MEMB / 4; ++q) mm[q] = mrow[q];
+        for (int q = 0; q < 4; ++q) {
+            const bool on = walk[q] && pos * 4 < n_memb[q];
+            mm[q] = on ? reinterpret_cast<const int4*>(tab.memb + (size_t)cq[q].slot * CC_CHAIN_MEMB)[pos] : make_int4(0, 0, 0, 0);
+        }
 #pragma unroll
-            for (int q = 0; q < CC_CHAIN_MEMB / 4; ++q) {
-                const int e[4] = {mm[q].x, mm[q].y, mm[q].z, mm[q].w};
+        for (int q = 0; q < 4; ++q) {
+            const int n_list = n_memb[q] < CC_CHAIN_MEMB ? n_memb[q] : CC_CHAIN_MEMB;
+            const int e[4] = {mm[q].x, mm[q].y, mm[q].z, mm[q].w};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int m = e[c];
-                    v = (q * 4 + c < n_list && m < j && m > v) ? m : v;
-                }
+            for (int c = 0; c < 4; ++c) {
+                const int m = e[c];
+                if (walk[q] && pos * 4 + c < n_list && m < j && m > lv[q]) lv[q] = m;
             }
         }
-        if (n_memb > CC_CHAIN_MEMB)
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (walk[q] && n_memb[q] > CC_CHAIN_MEMB) {
+            int v = lv[q];
             for (int steps = 0; ver.next[v] < j; ++steps) {
                 v = ver.next[v];
-                if (steps >= 64) return -2;
+                if (steps >= 64) { v = -2; break; }
             }
-        return v;
-    };
-    // exact distance of point j to version row v; enters the first-candidate slot of the version's kind
-    auto seed_version = [&](int v) {
-        const bool cr = v >= CC_CAR_BASE;
-        const size_t r = (size_t)(cr ? v - CC_CAR_BASE : v);
-        const int kv = cr ? car.kind[r] : ver.kind[r];
-        if (kv == CC_KIND_DEAD) return;
-        const double* vcen = (cr ? car.cen : ver.cen) + r * d;
-        const double* vpref = (cr ? car.pref : ver.pref) + r * d;
-        // (one thread per point: the loads of eight dimensions are requested together, the sum stays left to right)
-        double acc = 0.0;
-        for (int i0 = 0; i0 < d; i0 += 8) {
-            double pv[8], cv[8], fv[8];
+            lv[q] = v;
+        }
+    // what the lookups mean for the caps (hddstream.py:326/373 via the candidate lists)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int i = (i0 + q < d) ? i0 + q : d - 1;
-                pv[q] = p[i]; cv[q] = vcen[i]; fv[q] = vpref[i];
+    for (int kd = 0; kd < 2; ++kd) {
+        if (!have1[kd]) continue;
+        const int v1 = lv[kd * 2];
+        if (v1 == -1) cap[kd] = cq[kd * 2].dist;  // c1 is clean at j: a live version has to beat c1 itself
+        else {
+            cap[kd] = d2v[kd];
+            if (v1 < 0) provable = false;
+        }
+        if (look[kd * 2 + 1] && lv[kd * 2 + 1] == -2) provable = false;
+    }
+    // step 3: kind and key of the (up to four) version rows; step 4: their exact distances to point j, four
+    // dimensions of all rows per pass, every sum left to right
+    bool sd[4];
+    int kvq[4], keyq[4];
+    const double* vcen[4];
+    const double* vpref[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sd[q] = look[q] && lv[q] >= 0;
+        const bool cr = sd[q] && lv[q] >= CC_CAR_BASE;
+        const size_t r = sd[q] ? (size_t)(cr ? lv[q] - CC_CAR_BASE : lv[q]) : 0;
+        kvq[q] = sd[q] ? (cr ? car.kind[r] : ver.kind[r]) : CC_KIND_DEAD;
+        keyq[q] = sd[q] ? (cr ? car.key[r] : ver.key[r]) : 0;
+        vcen[q] = (cr ? car.cen : ver.cen) + r * d;
+        vpref[q] = (cr ? car.pref : ver.pref) + r * d;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sd[q] = sd[q] && kvq[q] != CC_KIND_DEAD;
+    double accq[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i0 = 0; i0 < d; i0 += 4) {
+        double pv[4], cv[4][4], fv[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = (i0 + c < d) ? i0 + c : d - 1;
+            pv[c] = p[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cv[q][c] = sd[q] ? vcen[q][i] : 0.0;
+                fv[q][c] = sd[q] ? vpref[q][i] : 1.0;
             }
+        }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if (i0 + q < d) {
-                    double x = pv[q] - cv[q];
+        for (int c = 0; c < 4; ++c) {
+            if (i0 + c < d) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    double x = pv[c] - cv[q][c];
                     x = x * x;
-                    acc = acc + cc_div_pref(x, fv[q], par);
+                    accq[q] = accq[q] + cc_div_pref(x, fv[q][c], par);
                 }
             }
         }
-        if (kv == 0 && filter) {
+    }
+    // the seeds enter the first-candidate slot of their version's kind, in lookup order
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!sd[q]) continue;
+        if (kvq[q] == 0 && filter) {
+            const bool cr = lv[q] >= CC_CAR_BASE;
+            const size_t r = (size_t)(cr ? lv[q] - CC_CAR_BASE : lv[q]);
             int ne1 = 0;
             cc_tentative_radius((cr ? car.cf1 : ver.cf1) + r * d, (cr ? car.cf2 : ver.cf2) + r * d,
                                 cr ? car.w[r] : ver.w[r], p, d, par, nullptr, &ne1);
-            if (ne1 > par.pi) return;
+            if (ne1 > par.pi) continue;
         }
-        const int key = cr ? car.key[r] : ver.key[r];
-        if (kv == 0) {
-            if (cand_less(acc, key, first0.dist, first0.key)) first0 = Cand{acc, key, v};
+        if (kvq[q] == 0) {
+            if (cand_less(accq[q], keyq[q], first0.dist, first0.key)) first0 = Cand{accq[q], keyq[q], lv[q]};
         } else {
-            if (cand_less(acc, key, first1.dist, first1.key)) first1 = Cand{acc, key, v};
-        }
-    };
-
-    double d2v[2] = {CC_INF, CC_INF};
-    bool have1[2] = {false, false};
-    for (int kd = 0; kd < 2; ++kd) {
-        const Cand c1 = clean[(size_t)j * 4 + kd * 2];
-        const Cand c2 = clean[(size_t)j * 4 + kd * 2 + 1];
-        if (c2.slot >= 0) d2v[kd] = c2.dist;
-        if (c1.slot < 0) continue;  // no snapshot candidate of this kind: cap stays +inf
-        have1[kd] = true;
-        const int v1 = live_version(c1.slot);
-        if (v1 == -1) cap[kd] = c1.dist;  // c1 is clean at j: a live version has to beat c1 itself
-        else {
-            cap[kd] = d2v[kd];
-            if (v1 >= 0) seed_version(v1);
-            else provable = false;
-        }
-        if (c2.slot >= 0) {
-            const int v2 = live_version(c2.slot);
-            if (v2 >= 0) seed_version(v2);
-            else if (v2 == -2) provable = false;
+            if (cand_less(accq[q], keyq[q], first1.dist, first1.key)) first1 = Cand{accq[q], keyq[q], lv[q]};
         }
     }
     seed[(size_t)j * 4 + 0] = first0;
