@@ -163,10 +163,20 @@ def main():
                            "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
                            "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
                            "fp64_valu": {"algorithmic_top_s": 4.0 * pair_dims / secs / 1e12,
+                                         "instr_per_pair_dim": 3.0,
+                                         "issued_top_s": 3.0 * pair_dims / secs / 1e12,
                                          "peak_top_s": FP64_VALU_PEAK_TOPS,
-                                         "frac": 4.0 * pair_dims / secs / 1e12 / FP64_VALU_PEAK_TOPS,
-                                         "note": "4 non-FMA fp64 ops per (point, microcluster, dim): sub, mul, "
-                                                 "mul, add in the reference's order; every pair runs all dims"},
+                                         "frac": 3.0 * pair_dims / secs / 1e12 / FP64_VALU_PEAK_TOPS,
+                                         "note": "per (point, microcluster, dim) the reference does sub, mul, div-by-pref, "
+                                                 "add (4 flops, left to right); k = 4 is a power of two, so the kernel "
+                                                 "issues 3 fp64 instructions for them (v_add, v_mul, v_fma: one rounding "
+                                                 "of x2 * 2^e + acc is the same double, guarded against subnormal "
+                                                 "products); frac = those instructions / the 39.3 T fp64 VALU "
+                                                 "instruction-lanes per second of the chip at 2.4 GHz, over ALL timed "
+                                                 "launches (short start-up windows, co-running lookahead scans); the "
+                                                 "11-instruction best-two update per (point, microcluster) is not "
+                                                 "counted.  PMC (SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE) for a full "
+                                                 "24 576-point launch running alone: DESIGN.md section 8"},
                            "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead "
                                           "scans (second stream, beside the validation kernels of the previous window, "
                                           "including the few that go unused) and in-place scans (short windows of the "

@@ -256,3 +256,32 @@ def test_device_scaler_matches_the_restated_minmaxscaler(n, d):
     assert np.array_equal(scaled, ref.scale_data(X))
     back = hd.points_download(d, ref.scale_, ref.min_)
     assert np.array_equal(back, ref.reverse_scaling(ref.scale_data(X)))
+
+
+@pytest.mark.parametrize("lookahead,wps,window", [(0, 4, 1024), (3, 4, 1024), (2, 2, 512), (0, 16, 2048)])
+def test_quiet_stream_then_new_populations(lookahead, wps, window):
+    """A long stretch in which no live version can matter to any point (the host stops launching the dirty scans and
+    k_decide vouches for every point), then new populations appear in the middle of a batch: points that need the
+    dirty scans are refused, the window commits up to them (possibly nothing: the device idles the batch) and the
+    host brings the scans back.  Twice within one timepoint, then again after a decay."""
+    from oracle import oracle as O
+    d, g = 8, 30
+    rng = np.random.default_rng(77)
+    centres = rng.uniform(0.1, 0.9, (g + 6, d))
+
+    def stretch(n, which, sigma=0.01):
+        lab = rng.choice(which, n)
+        return np.clip(centres[lab] + rng.normal(0.0, sigma, (n, d)), 0.0, 1.0)
+
+    X0 = np.concatenate([stretch(26000, np.arange(g)),                       # quiet: 30 established populations
+                         stretch(1500, np.arange(g, g + 3)),                  # three new ones, nothing else
+                         stretch(9000, np.arange(g + 3)),                     # quiet again
+                         stretch(2500, np.arange(g + 6))])                    # three more, mixed with the old
+    X1 = np.concatenate([stretch(12000, np.arange(g + 6)), stretch(800, np.arange(3), sigma=0.2)])
+    n = len(X0)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.06))
+    h, o = _hdd(cfg, window=window, windows_per_sync=wps, lookahead=lookahead), O.OracleHDDStream(cfg)
+    for t, X in enumerate((X0, X1)):
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)

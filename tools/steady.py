@@ -16,7 +16,8 @@ if __name__ == "__main__":
     cfg = bench.blob_config(n)
     h = _lib.Handle(0)
     h.set_tuning(window=int(os.environ.get("WIN", "0")), segments=int(os.environ.get("SEG", "0")),
-                 lookahead=int(os.environ.get("LA", "2")), time_kernels=1)
+                 lookahead=int(os.environ.get("LA", "2")), time_kernels=1,
+                 windows_per_sync=int(os.environ.get("WPS", "0")))
     bench.set_params(h, cfg, n, d)
     h.points_upload(X)
     h.online_run()
