@@ -691,6 +691,7 @@ int cc_online_run(cc_handle* h)
         const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
         const int start_small = 256;
+        const int fast_below = 4096;  // below this size a clean batch quadruples the window (and batches are two windows)
         // (a new timepoint begins with whatever changed since the last one - decayed weights, new populations -, which
         // takes a few validation rounds per window: not with the largest window the previous one ended on)
         if (h->adapt_win > 0) c.win_cfg = std::min(win, std::min(h->adapt_win, early0));
@@ -883,6 +884,8 @@ int cc_online_run(cc_handle* h)
                 //    early) the speculated remainder is wasted: aim at the average committed length; grow back
                 //    by doubling while nothing is truncated.
                 const long long grew = (long long)h->hc.m_rows - rows_prev, pts = h->hc.cursor - cursor_prev;
+                // while MCs are being created every window needs its chains replayed two or three times: all the rounds
+                if (pts > 0 && grew * 50 > pts) Rcur = Rmax;
                 const long long wins = h->hc.stat_windows - windows_prev;
                 rows_prev = h->hc.m_rows;
                 cursor_prev = h->hc.cursor;
@@ -912,9 +915,9 @@ int cc_online_run(cc_handle* h)
                     // shrink; grow by doubling after one clean batch, after two if a shrink is recent
                     ++h->since_shrink;
                     if (trunc_batch == 0) ++h->clean_batches;
-                    const int need = (h->since_shrink > 8 || want < 1024) ? 1 : 2;
+                    const int need = (h->since_shrink > 8 || want < fast_below) ? 1 : 2;
                     if (trunc_batch == 0 && h->clean_batches >= need)
-                        want = std::min(target, std::max(want, 64) * (want < 1024 ? 4 : 2));  // small windows: fast start
+                        want = std::min(target, std::max(want, 64) * (want < fast_below ? 4 : 2));  // small windows: fast start
                 }
                 want = std::min(want, target);
                 h->adapt_win = want;
@@ -937,7 +940,7 @@ int cc_online_run(cc_handle* h)
                 // settle quickly at the start of a call and whenever windows are being truncated
                 batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
                                                                                   : h->tun.windows_per_sync;
-                if (want < 1024 && trunc_batch == 0) batch_windows = 2;
+                if (want < fast_below && trunc_batch == 0) batch_windows = 2;
                 first_batch = false;
             }
         }

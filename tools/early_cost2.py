@@ -14,7 +14,7 @@ if __name__ == "__main__":
     for early in [int(x) for x in os.environ.get("EARLY", "4096,6144,8192,12288,16384").split(",")]:
         for m in (40_000, 160_000, 1_000_000):
             h = _lib.Handle(0)
-            h.set_tuning(early_window=early, rounds=int(os.environ.get("ROUNDS", "0")))
+            h.set_tuning(early_window=early, rounds=int(os.environ.get("ROUNDS", "0")), window=int(os.environ.get("WIN", "0")))
             best = None
             for rep in range(2):
                 h.reset()
