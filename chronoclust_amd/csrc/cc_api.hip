@@ -116,9 +116,7 @@ struct cc_handle {
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
-    int force_dirty_wgs = 0;
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
-    int la_pad = 0;         // bytes of unused dynamic LDS per workgroup of a lookahead scan (occupancy cap)
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -332,25 +330,16 @@ struct ScanWaves {
 
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                    int mode, int tile_wgs)
+                    int mode)
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
-    (void)tile_wgs;
     const dim3 grid((win + 63) / 64, S);
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;
-    // A lookahead scan shares the machine with the validation kernels of the previous window.  Four of its workgroups
-    // fill a CU's registers (4 x 120 of 512 per lane), and a validation kernel that needs more than the 32 left over
-    // only gets on when the scan has no workgroup left to dispatch; unused dynamic LDS limits the scan to three
-    // workgroups per CU, which leaves every SIMD a contiguous 152 registers.
-    size_t lds_pad = 0;
-    if (!DIRTY && mode == 1 && h->la_pad > 0) {
-        lds_pad = (size_t)h->la_pad;
-    }
 #define CC_LAUNCH_SCAN(F, P)                                                                                   \
-    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, lds_pad, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
+    hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
                        part, round, mode, h->part_stride)
     if (filter) {
         if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
@@ -367,16 +356,16 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 // dirty scan: mode 0 = version rows, 1 = carry set.
 template <bool DIRTY>
 void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                 int mode, int tile_wgs = 0)
+                 int mode)
 {
     const int d = h->d;
-    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
-    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode, tile_wgs);
+    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
 }
 
 int scan_waves_for_dim(int) { return 4; }
@@ -452,13 +441,8 @@ int cc_create(int device, cc_handle** out)
         h->tun.time_kernels = 0;
         const char* tr = getenv("CHRONOCLUST_HIP_TRACE");
         h->trace = tr && tr[0] == '1';
-        // testing: CHRONOCLUST_HIP_DIRTY_WGS=n launches every dirty scan with n workgroups per segment (grid stride)
-        const char* dw = getenv("CHRONOCLUST_HIP_DIRTY_WGS");
-        h->force_dirty_wgs = dw ? atoi(dw) : 0;
         const char* nd = getenv("CHRONOCLUST_HIP_NODIRTY");
         h->allow_nodirty = !(nd && nd[0] == '0');
-        const char* lp = getenv("CHRONOCLUST_HIP_LA_PAD");
-        h->la_pad = lp ? atoi(lp) : 0;
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -675,7 +659,6 @@ int cc_online_run(cc_handle* h)
         // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
         // if that stops a window at its first point, and the next batch launches them again.
         bool nodirty = false;
-        int dirty_wgs = h->force_dirty_wgs;  // > 0: the dirty scans are launched with this many workgroups per segment (grid stride over tiles)
         memset(&h->stats, 0, sizeof(h->stats));
         if (N == 0) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
@@ -838,8 +821,8 @@ int cc_online_run(cc_handle* h)
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, r);
                     if (!nodirty) {
-                        launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0, dirty_wgs);
-                        if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1, dirty_wgs);
+                        launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
+                        if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
                                        h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r, nodirty ? 1 : 0);
@@ -925,7 +908,6 @@ int cc_online_run(cc_handle* h)
                 // overlapping MCs) the scan of a window that then starts elsewhere is wasted
                 const bool quiet = tiles > 0 && dtiles * 16 < tiles;
                 Sd = quiet ? std::max(1, Sd_full / 8) : Sd_full;
-                dirty_wgs = h->force_dirty_wgs > 0 ? h->force_dirty_wgs : (quiet ? 16 : 0);
                 nodirty = h->allow_nodirty && tiles > 0 && dtiles == 0 && trunc_batch == 0;
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
                 if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {

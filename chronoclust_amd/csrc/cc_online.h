@@ -425,8 +425,11 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : 1)) void k_scan(const Ctl*
             // update is pure selection (min / max and three selects).  Exact ties - the only place where the
             // list-order keys decide (hddstream.py:326/373: strict `<`, first in list order wins) - and the pdim
             // filter take the general path, which fetches the keys it needs.
-            auto clean_rows = [&](auto FUSEC) {
+            // KSEL: 0 / 1 = every row of the tile is a pcore / outlier MC (no kind test per row, the running pair of that
+            // kind stays in its registers), -1 = mixed tile
+            auto clean_rows = [&](auto FUSEC, auto KSELC) {
             constexpr bool FUSE = decltype(FUSEC)::value;
+            constexpr int KSEL = decltype(KSELC)::value;
             for (int m = 0; m < tm; ++m) {
                 double acc[PT];
                 // (rows of an even DP start on 16-byte boundaries: ds_read_b128)
@@ -504,12 +507,20 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : 1)) void k_scan(const Ctl*
                         s0 = first ? rowg : s0;
                     }
                 };
-                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
-                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+                if constexpr (KSEL == 0) update(std::integral_constant<int, 0>{});
+                else if constexpr (KSEL == 1) update(std::integral_constant<int, 1>{});
+                else {
+                    if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+                    else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+                }
             }
             };
-            if (POW2 && fuse_tile) clean_rows(std::true_type{});
-            else clean_rows(std::false_type{});
+            const unsigned full = (tm >= 32) ? 0xFFFFFFFFu : ((1u << tm) - 1u);
+            if (POW2 && fuse_tile) {
+                if (pmask == full) clean_rows(std::true_type{}, std::integral_constant<int, 0>{});
+                else if (omask == full) clean_rows(std::true_type{}, std::integral_constant<int, 1>{});
+                else clean_rows(std::true_type{}, std::integral_constant<int, -1>{});
+            } else clean_rows(std::false_type{}, std::integral_constant<int, -1>{});
             continue;
         }
 

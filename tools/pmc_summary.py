@@ -8,7 +8,7 @@ import pandas as pd
 
 
 def per_launch(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     df = pd.read_csv(f)
     df = df[df["Counter_Name"] == counter]
     df = df[df["Kernel_Name"].str.contains("k_scan") & df["Kernel_Name"].str.contains("false, 4>")]
