@@ -180,7 +180,7 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
 template <int DP, bool FILTER, bool POW2, bool DIRTY, int NW>
-__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : 1)) void k_scan(const Ctl* __restrict__ ctl,
+__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
