@@ -51,6 +51,7 @@ struct Table {
 // Candidate slots >= CC_CAR_BASE refer to carried rows (index = slot - CC_CAR_BASE), below to version rows.
 #define CC_CAR_BASE (1 << 24)
 #define CC_CHAIN_MEMB 32
+#define CC_CHAIN_AHEAD 4  // k_chain: points of a chain requested ahead of the step that absorbs them
 
 // Lookahead.  While window W is validated, the snapshot scan of window W + 1 already runs - against the table as
 // it is before W's commit.  What that scan could not see is exactly the set of rows W's commit changes or adds:

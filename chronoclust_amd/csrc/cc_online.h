@@ -753,7 +753,10 @@ __device__ inline GroupAdd cc_group_add_regs(const double (&b1)[2], const double
     row[gl + 32] = term[1];
     CC_WAVE_SYNC();
     double r2 = 0.0;
-    for (int i = 0; i < d; ++i) r2 = r2 + row[i];  // mc_functions.py:54, left to right
+    // mc_functions.py:54, left to right; entries d..63 of the row hold +0.0 (x + 0.0 == x), so the loop runs over
+    // whole groups of eight (four 16-byte LDS reads in flight) without a one-by-one remainder
+    const int d8 = (d + 7) & ~7;
+    for (int i = 0; i < d8; ++i) r2 = r2 + row[i];
     g.r2 = r2;
     return g;
 }
@@ -1299,21 +1302,15 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
             }
         }
     }
-    int cur = j;
-    double px[2] = {0.0, 0.0};  // this lane's two dimensions of point `cur`
-    if (valid_chain) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int i = gl + 32 * h;
-            if (i < d) px[h] = X[(cursor + cur) * d + i];
-        }
-    }
-    while (true) {
+    // The chain is walked in batches of CC_CHAIN_AHEAD members: the members of a batch are located first and their
+    // points requested together (the rows of one MC's points are scattered over the window: with one point in
+    // flight per step a long chain ran at the memory latency, 2.5 us per step); the steps themselves stay strictly
+    // sequential.  mem[q] = q-th member of the batch, mem[CC_CHAIN_AHEAD] = first member of the next one.
+    constexpr int NB = CC_CHAIN_AHEAD;
+    // the member after `after` of a chain that is not listed: scan of the claims, 128 per block, in registers
+    auto find_next = [&](const int after) -> int {
         int nx = CC_IDX_INF;
-        ++step;
-        if (listed) nx = (step < n_memb) ? __shfl(sorted_memb, step, 32) : CC_IDX_INF;
-        else
-        for (int base = (cur + 1) & ~127; base <= last_j && cur < last_j; base += 128) {
+        for (int base = (after + 1) & ~127; base <= last_j && after < last_j; base += 128) {
             const int i = base + gl * 4;
             // the 128 claims of a block stay in registers while the chain moves inside it; the following block is
             // requested as soon as a block is entered, so its latency hides behind the chain steps
@@ -1324,8 +1321,8 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 if (have_nb) vn = T4[((base + 128) >> 2) + gl];
             }
             const int4 v = vb;
-            const unsigned mm = ((i > cur && i < B && v.x == t) ? 1u : 0u) | ((i + 1 > cur && i + 1 < B && v.y == t) ? 2u : 0u) |
-                                ((i + 2 > cur && i + 2 < B && v.z == t) ? 4u : 0u) | ((i + 3 > cur && i + 3 < B && v.w == t) ? 8u : 0u);
+            const unsigned mm = ((i > after && i < B && v.x == t) ? 1u : 0u) | ((i + 1 > after && i + 1 < B && v.y == t) ? 2u : 0u) |
+                                ((i + 2 > after && i + 2 < B && v.z == t) ? 4u : 0u) | ((i + 3 > after && i + 3 < B && v.w == t) ? 8u : 0u);
             const unsigned b = cc_group_ballot(mm != 0u);
             if (b) {
                 const int l = __builtin_ctz(b);
@@ -1334,70 +1331,93 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 break;
             }
         }
-        // the next point of the chain is fetched while this one is being absorbed
-        double pn[2] = {0.0, 0.0};
-        if (valid_chain && nx != CC_IDX_INF) {
+        return nx;
+    };
+    int first = j;  // first member of the next batch
+    while (first != CC_IDX_INF) {
+        int mem[NB + 1];
+        mem[0] = first;
+#pragma unroll
+        for (int q = 1; q <= NB; ++q) {
+            int m = CC_IDX_INF;
+            if (mem[q - 1] != CC_IDX_INF) {
+                if (listed) m = (step + q < n_memb) ? __shfl(sorted_memb, (step + q) & 31, 32) : CC_IDX_INF;
+                else m = find_next(mem[q - 1]);
+            }
+            mem[q] = m;
+        }
+        step += NB;
+        double pxb[NB][2];  // this lane's two dimensions of the batch's points
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int i = gl + 32 * h;
-                if (i < d) pn[h] = X[(cursor + nx) * d + i];
+                pxb[q][h] = (valid_chain && mem[q] != CC_IDX_INF && i < d) ? X[(cursor + mem[q]) * d + i] : 0.0;
             }
-        }
-        if (!valid_chain) {
-            if (gl == 0) {
-                ver.tgt[cur] = t; ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
-            }
-        } else {
-            const double w1 = bw + 1.0;  // microcluster.py:147
-            const GroupAdd g = cc_group_add_regs(bc1, bc2, bw, px, d, par);
-            const bool creates = isnew && cur == j;
-            const bool ok = creates || (g.r2 <= par.eps_sq);
-            if (ok) {
-                // hddstream.py:416-430: promotion is only examined after an add to an existing outlier MC
-                if (bkind == CC_KIND_OUTLIER && !creates && w1 >= par.beta_mu && g.gt1 <= par.pi) {
-                    bkind = CC_KIND_PCORE; bkey = pk_base + cur; bupg = cur;
-                    if (gl == 0) ctl->any_up[round] = 1;
+        // All of the batch's points have to be in before its first step anyway.  Waiting here, once, keeps the steps
+        // free of vector-memory waits: gfx9 counts loads and stores in one in-order counter, so a wait for a point
+        // inside the loop is also a wait for every version row stored before it (2 us per step, measured).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            if (mem[q] == CC_IDX_INF) break;
+            const int cur = mem[q];
+            const int nx = mem[q + 1];
+            const double px[2] = {pxb[q][0], pxb[q][1]};
+            if (!valid_chain) {
+                if (gl == 0) {
+                    ver.tgt[cur] = t; ver.kind[cur] = CC_KIND_DEAD; ver.next[cur] = cur; ver.acc[cur] = 0; ver.upg[cur] = -1;
                 }
+            } else {
+                const double w1 = bw + 1.0;  // microcluster.py:147
+                const GroupAdd g = cc_group_add_regs(bc1, bc2, bw, px, d, par);
+                const bool creates = isnew && cur == j;
+                const bool ok = creates || (g.r2 <= par.eps_sq);
+                if (ok) {
+                    // hddstream.py:416-430: promotion is only examined after an add to an existing outlier MC
+                    if (bkind == CC_KIND_OUTLIER && !creates && w1 >= par.beta_mu && g.gt1 <= par.pi) {
+                        bkind = CC_KIND_PCORE; bkey = pk_base + cur; bupg = cur;
+                        if (gl == 0) ctl->any_up[round] = 1;
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        bc1[h] = g.c1[h]; bc2[h] = g.c2[h];
+                        bce[h] = g.c1[h] / w1;  // mc_functions.py:31-33
+                        bpr[h] = g.pr[h];
+                    }
+                    bw = w1;
+                }
+                // the version row of `cur` = the MC's state right after `cur` (unchanged if the radius test failed)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    bc1[h] = g.c1[h]; bc2[h] = g.c2[h];
-                    bce[h] = g.c1[h] / w1;  // mc_functions.py:31-33
-                    bpr[h] = g.pr[h];
+                    const int i = gl + 32 * h;
+                    if (i < d) {
+                        ver.cf1[(size_t)cur * d + i] = bc1[h]; ver.cf2[(size_t)cur * d + i] = bc2[h];
+                        ver.cen[(size_t)cur * d + i] = bce[h]; ver.pref[(size_t)cur * d + i] = bpr[h];
+                        ver.scl[(size_t)cur * d + i] = par.pow2 ? (bpr[h] == 1.0 ? 1.0 : par.inv_k) : bpr[h];
+                    }
                 }
-                bw = w1;
-            }
-            // the version row of `cur` = the MC's state right after `cur` (unchanged if the radius test failed)
+                // squared displacement from the window-start centroid in the window-start metric (any summation order:
+                // it only feeds a conservative bound); +inf when no bound exists (new MC, promoted inside the window)
+                double dq = 0.0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = gl + 32 * h;
-                if (i < d) {
-                    ver.cf1[(size_t)cur * d + i] = bc1[h]; ver.cf2[(size_t)cur * d + i] = bc2[h];
-                    ver.cen[(size_t)cur * d + i] = bce[h]; ver.pref[(size_t)cur * d + i] = bpr[h];
-                    ver.scl[(size_t)cur * d + i] = par.pow2 ? (bpr[h] == 1.0 ? 1.0 : par.inv_k) : bpr[h];
+                for (int h = 0; h < 2; ++h) {
+                    const double df = bce[h] - c0[h];
+                    dq += df * df * w0[h];
                 }
-            }
-            // squared displacement from the window-start centroid in the window-start metric (any summation order:
-            // it only feeds a conservative bound); +inf when no bound exists (new MC, promoted inside the window)
-            double dq = 0.0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double df = bce[h] - c0[h];
-                dq += df * df * w0[h];
-            }
-            for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
-            if (isnew || bkind != kind0 || !(dq >= 0.0)) dq = CC_INF;
-            if (gl == 0) {
-                ver.w[cur] = bw;
-                ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
-                ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
-                ver.dsq[cur] = dq;
-                atomicMax(&ver.tile_dsq[cur >> 4], (unsigned long long)__double_as_longlong(dq));
+                for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
+                if (isnew || bkind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+                if (gl == 0) {
+                    ver.w[cur] = bw;
+                    ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
+                    ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
+                    ver.dsq[cur] = dq;
+                    atomicMax(&ver.tile_dsq[cur >> 4], (unsigned long long)__double_as_longlong(dq));
+                }
             }
         }
-        if (nx == CC_IDX_INF) break;
-        cur = nx;
-        px[0] = pn[0];
-        px[1] = pn[1];
+        first = mem[NB];
     }
 }
 
