@@ -710,6 +710,7 @@ __device__ __forceinline__ unsigned cc_group_ballot(bool p)
 
 struct GroupAdd {
     double c1[2], c2[2], pr[2];  // this lane's two dimensions of (base + point): CF1, CF2, preferred-dimension entry
+    double cen[2];               // ... and CF1 / W, the centroid (mc_functions.py:31-33; the same quotient the variance uses)
     double r2;                   // projected radius^2 of the enlarged MC (all lanes)
     int gt1, ne1;                // count(pref' > 1), count(pref' != 1)
 };
@@ -728,13 +729,17 @@ __device__ inline GroupAdd cc_group_add_regs(const double (&b1)[2], const double
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int i = gl + 32 * h;
-        g.c1[h] = 0.0; g.c2[h] = 0.0; g.pr[h] = 1.0;
+        g.c1[h] = 0.0; g.c2[h] = 0.0; g.pr[h] = 1.0; g.cen[h] = 0.0;
         term[h] = 0.0; gt[h] = false; ne[h] = false;
         if (i < d) {
             const double x = px[h];
             g.c1[h] = b1[h] + x;
             g.c2[h] = b2[h] + x * x;
-            const double var = cc_sqvar(g.c1[h], g.c2[h], w1);
+            // mc_functions.py:14-22 (cc_sqvar), keeping the quotient CF1 / W
+            const double qa = g.c2[h] / w1;
+            const double qb = g.c1[h] / w1;
+            g.cen[h] = qb;
+            const double var = qa - qb * qb;
             const double pr = (var <= c.delta_sq) ? c.k : 1.0;
             g.pr[h] = pr;
             term[h] = cc_div_pref(var, pr, c);
@@ -1383,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         bc1[h] = g.c1[h]; bc2[h] = g.c2[h];
-                        bce[h] = g.c1[h] / w1;  // mc_functions.py:31-33
+                        bce[h] = g.cen[h];  // mc_functions.py:31-33: CF1 / W, the quotient the variance was formed from
                         bpr[h] = g.pr[h];
                     }
                     bw = w1;
