@@ -708,6 +708,29 @@ __device__ __forceinline__ unsigned cc_group_ballot(bool p)
     return (unsigned)(b >> (threadIdx.x & 32));
 }
 
+// Sum over the 32 lanes of a group whose order does not matter (it feeds conservative bounds only), result valid in
+// lanes 0..15 of the group: four DPP steps inside the rows of 16 lanes, then the other row's total (the shuffle
+// butterfly goes through the LDS crossbar five times, one latency each)
+template <int CTRL>
+__device__ __forceinline__ double cc_dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double cc_group_sum_any_order(double x)
+{
+    x += cc_dpp_f64<0xB1>(x);   // quad_perm [1,0,3,2]
+    x += cc_dpp_f64<0x4E>(x);   // quad_perm [2,3,0,1]
+    x += cc_dpp_f64<0x141>(x);  // row_half_mirror
+    x += cc_dpp_f64<0x140>(x);  // row_mirror: every lane of a row of 16 holds the row's sum
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const double r16 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    const double r48 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return x + ((threadIdx.x & 32) ? r48 : r16);
+}
+
 struct GroupAdd {
     double c1[2], c2[2], pr[2];  // this lane's two dimensions of (base + point): CF1, CF2, preferred-dimension entry
     double cen[2];               // ... and CF1 / W, the centroid (mc_functions.py:31-33; the same quotient the variance uses)
@@ -1411,7 +1434,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                     const double df = bce[h] - c0[h];
                     dq += df * df * w0[h];
                 }
-                for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
+                dq = cc_group_sum_any_order(dq);  // (valid in the lane that stores it)
                 if (isnew || bkind != kind0 || !(dq >= 0.0)) dq = CC_INF;
                 if (gl == 0) {
                     ver.w[cur] = bw;
