@@ -63,7 +63,7 @@ struct TableStore {
     DevBuf<int> kind, key;
     DevBuf<long long> id, uid;
     DevBuf<unsigned long long> touch, last, carry_of, cnt;
-    DevBuf<int> memb;
+    DevBuf<int> memb, clen;
     size_t cap = 0;
     int d = 0;
     void alloc(size_t rows, int dim)
@@ -71,11 +71,11 @@ struct TableStore {
         cf1.ensure(rows * dim); cf2.ensure(rows * dim); cen.ensure(rows * dim); pref.ensure(rows * dim);
         scl.ensure(rows * dim);
         w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(2 * rows); last.ensure(2 * rows);
-        carry_of.ensure(rows); cnt.ensure(rows); memb.ensure(rows * CC_CHAIN_MEMB);
+        carry_of.ensure(rows); cnt.ensure(rows); memb.ensure(rows * CC_CHAIN_MEMB); clen.ensure(rows);
         cap = rows;
         d = dim;
     }
-    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, carry_of.p, cnt.p, memb.p, cap}; }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, carry_of.p, cnt.p, memb.p, clen.p, cap}; }
     void swap(TableStore& o)
     {
         std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
@@ -87,6 +87,7 @@ struct TableStore {
         std::swap(last.p, o.last.p); std::swap(last.n, o.last.n);
         std::swap(carry_of.p, o.carry_of.p); std::swap(carry_of.n, o.carry_of.n);
         std::swap(cnt.p, o.cnt.p); std::swap(cnt.n, o.cnt.n); std::swap(memb.p, o.memb.p); std::swap(memb.n, o.memb.n);
+        std::swap(clen.p, o.clen.p); std::swap(clen.n, o.clen.n);
         std::swap(cap, o.cap); std::swap(d, o.d);
     }
 };
@@ -245,6 +246,7 @@ void ensure_table(cc_handle* h, size_t rows)
     // the carry marks of the last commit are live state: the next window may be a lookahead window
     if (m > 0) HIPCHK(hipMemcpyAsync(nt.carry_of.p, h->tab.carry_of.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(nt.cnt.p, 0, want * 8, h->stream));
+    HIPCHK(hipMemsetAsync(nt.clen.p, 0, want * 4, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->tab.swap(nt);
 }
@@ -819,7 +821,7 @@ int cc_online_run(cc_handle* h)
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), 0, sA,
                                        h->ctl.p, h->X.p, tab, ver, car, told, r);
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                       h->clean.p, h->dseed.p, r);
+                                       h->clean.p, h->dseed.p, told, r);
                     if (!nodirty) {
                         launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
@@ -906,8 +908,9 @@ int cc_online_run(cc_handle* h)
                 h->adapt_win = want;
                 // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few
                 // overlapping MCs) the scan of a window that then starts elsewhere is wasted
-                const bool quiet = tiles > 0 && dtiles * 16 < tiles;
-                Sd = quiet ? std::max(1, Sd_full / 8) : Sd_full;
+                // (the dirty scans keep their full split: when only a few tiles need them those tiles are long - every
+                // version row before them -, and when none does they are not launched at all)
+                Sd = Sd_full;
                 nodirty = h->allow_nodirty && tiles > 0 && dtiles == 0 && trunc_batch == 0;
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
                 if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {

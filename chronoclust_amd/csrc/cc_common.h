@@ -45,6 +45,7 @@ struct Table {
     // that heads the chain sorts them (k_chain); longer chains are found by scanning the claims.
     unsigned long long* cnt;  // [cap]
     int* memb;                // [cap, CC_CHAIN_MEMB]
+    int* clen;                // [cap] members of the MC's chain as k_chain walked it (valid while `touch` carries the round's stamp)
     size_t cap;                 // rows allocated (offset of the second copy)
 };
 

@@ -826,7 +826,7 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 
 __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
-                                              Cand* __restrict__ seed, int round)
+                                              Cand* __restrict__ seed, const int* __restrict__ T, int round)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -934,10 +934,34 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         if (walk[q] && n_memb[q] > CC_CHAIN_MEMB) {
+            // More members than the list holds (the counter stops there; k_chain left the chain's length in clen).
+            // Members far apart: along the chain from the latest listed member before j, one dependent load per member.  Close
+            // together (a long chain): backwards through the claims (T, the ones k_chain replayed) from j - 1, 32
+            // independent loads per pass; neighbouring threads read overlapping ranges.
+            const int clen = tab.clen[cq[q].slot];
+            const int gap = B / (clen > 0 ? clen : 1);
             int v = lv[q];
-            for (int steps = 0; ver.next[v] < j; ++steps) {
-                v = ver.next[v];
-                if (steps >= 64) { v = -2; break; }
+            if (gap > 64) {
+                bool found = false;
+                for (int steps = 0; steps < 64; ++steps) {
+                    const int nxv = ver.next[v];
+                    if (nxv >= j) { found = true; break; }
+                    v = nxv;
+                }
+                if (!found) v = -2;
+            } else {
+                const int want = cq[q].slot;
+                int hit = -1;
+                for (int hi = j - 1, scanned = 0; hit < 0 && scanned < 2048; hi -= 32, scanned += 32) {
+                    int tv[32];
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) tv[c] = (hi - c > v) ? T[hi - c] : CC_T_UNKNOWN;
+#pragma unroll
+                    for (int c = 31; c >= 0; --c)
+                        if (tv[c] == want) hit = hi - c;  // (ends on the smallest c = the largest index)
+                    if (hit < 0 && hi - 32 <= v) hit = v;  // nothing between v and j: v is the latest
+                }
+                v = hit >= 0 ? hit : -2;
             }
             lv[q] = v;
         }
@@ -1362,6 +1386,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         return nx;
     };
     int first = j;  // first member of the next batch
+    int walked = 0;
     while (first != CC_IDX_INF) {
         int mem[NB + 1];
         mem[0] = first;
@@ -1390,6 +1415,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             if (mem[q] == CC_IDX_INF) break;
+            ++walked;
             const int cur = mem[q];
             const int nx = mem[q + 1];
             const double px[2] = {pxb[q][0], pxb[q][1]};
@@ -1447,6 +1473,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         }
         first = mem[NB];
     }
+    if (gl == 0 && !isnew) tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it
 }
 
 // ---------------------------------------------------------------------------------

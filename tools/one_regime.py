@@ -12,6 +12,7 @@ if __name__ == "__main__":
     X = bench.make_blobs(7, n, d, g)
     cfg = bench.blob_config(n)
     h = _lib.Handle(0)
+    h.set_tuning(lookahead=int(os.environ.get("LA", "0")), window=int(os.environ.get("WIN", "0")))
     bench.set_params(h, cfg, n, d)
     h.points_upload(X)
     for rep in range(int(os.environ.get("REPS", 2))):
