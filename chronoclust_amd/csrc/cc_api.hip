@@ -689,6 +689,7 @@ int cc_online_run(cc_handle* h)
         c.stat_windows = c.stat_rounds = c.stat_truncated = 0;
         c.stat_lookahead = 0;
         c.stat_tiles = c.stat_dirty_tiles = 0;
+        c.stat_unprovable = c.stat_unsafe = 0;
         c.stat_trunc_unknown = 0;
         c.stat_table_rows = 0;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
@@ -920,8 +921,9 @@ int cc_online_run(cc_handle* h)
                     push_ctl(h);
                 }
                 if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld lookahead %lld dirty tiles %lld / %lld | next window %d rounds %d\n",
-                            done, h->hc.m_rows, wins, pts, trunc_batch, (long long)h->hc.stat_lookahead, dtiles, tiles, want, Rcur);
+                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
+                            done, h->hc.m_rows, wins, pts, trunc_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
+                            (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, want, Rcur);
                 // settle quickly at the start of a call and whenever windows are being truncated
                 batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
                                                                                   : h->tun.windows_per_sync;

@@ -167,6 +167,7 @@ struct Ctl {
     long long round_hist[CC_MAX_ROUNDS + 2];  // windows by the validation round they ended in
     long long stat_lookahead;  // windows whose snapshot scan ran ahead (mode 1)
     long long stat_trunc_unknown;  // truncated windows that stopped at a point whose decision could not be made (the rest: one more round needed)
+    long long stat_unprovable, stat_unsafe;  // points whose live versions k_dseed could not locate / that needed the dirty scans
     long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
 };
 

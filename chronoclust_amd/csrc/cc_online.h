@@ -824,7 +824,7 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 // seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
 // ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+__global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
                                               Cand* __restrict__ seed, const int* __restrict__ T, int round)
 {
@@ -851,6 +851,7 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
         maxd_car = __longlong_as_double((long long)mc);
     }
     double tau_out = CC_INF;  // lanes past the window do not constrain the tile
+    bool flag_unprov = false, flag_unsafe = false;
     if (j < B) {
     const Par par = cc_load_par(ctl);
     const int d = par.d;
@@ -939,31 +940,40 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
             // together (a long chain): backwards through the claims (T, the ones k_chain replayed) from j - 1, 32
             // independent loads per pass; neighbouring threads read overlapping ranges.
             const int clen = tab.clen[cq[q].slot];
-            const int gap = B / (clen > 0 ? clen : 1);
+            const int n = clen > CC_CHAIN_MEMB ? clen : CC_CHAIN_MEMB + 1;
+            const int gap = B / n;  // members of this chain lie about this many claims apart
+            // The listed members are mostly the chain's earliest (k_decide's workgroups start in point order), so
+            // the walk from the latest listed one takes up to n - 32 dependent steps, a backward read about gap / 32
+            // passes: whichever is expected to be shorter goes first, the other one is the fallback.
+            const bool scan_first = (n - CC_CHAIN_MEMB) > gap / 8;  // (a pass of 32 loads costs about four steps)
             int v = lv[q];
-            if (gap > 64) {
-                bool found = false;
-                for (int steps = 0; steps < 64; ++steps) {
-                    const int nxv = ver.next[v];
-                    if (nxv >= j) { found = true; break; }
-                    v = nxv;
-                }
-                if (!found) v = -2;
-            } else {
-                const int want = cq[q].slot;
-                int hit = -1;
-                for (int hi = j - 1, scanned = 0; hit < 0 && scanned < 2048; hi -= 32, scanned += 32) {
-                    int tv[32];
+            int res = -2;
+            for (int attempt = 0; attempt < 2 && res == -2; ++attempt) {
+                if ((attempt == 0) == scan_first) {
+                    const int want = cq[q].slot;
+                    // (members are spread like arrivals: a distance of 16 gaps is exceeded once in 10^7 lookups)
+                    const int budget = min(16384, 16 * gap + 64);
+                    for (int hi = j - 1, scanned = 0; res == -2 && scanned < budget; hi -= 32, scanned += 32) {
+                        int tv[32];
 #pragma unroll
-                    for (int c = 0; c < 32; ++c) tv[c] = (hi - c > v) ? T[hi - c] : CC_T_UNKNOWN;
+                        for (int c = 0; c < 32; ++c) tv[c] = (hi - c > v) ? T[hi - c] : CC_T_UNKNOWN;
+                        int hit = -1;
 #pragma unroll
-                    for (int c = 31; c >= 0; --c)
-                        if (tv[c] == want) hit = hi - c;  // (ends on the smallest c = the largest index)
-                    if (hit < 0 && hi - 32 <= v) hit = v;  // nothing between v and j: v is the latest
+                        for (int c = 31; c >= 0; --c)
+                            if (tv[c] == want) hit = hi - c;  // (ends on the smallest c = the largest index)
+                        if (hit < 0 && hi - 32 <= v) hit = v;  // nothing between v and j: v is the latest
+                        if (hit >= 0) res = hit;
+                    }
+                } else {
+                    int w = v;
+                    for (int steps = 0; steps < 64; ++steps) {
+                        const int nxv = ver.next[w];
+                        if (nxv >= j) { res = w; break; }
+                        w = nxv;
+                    }
                 }
-                v = hit >= 0 ? hit : -2;
             }
-            lv[q] = v;
+            lv[q] = res;
         }
     // what the lookups mean for the caps (hddstream.py:326/373 via the candidate lists)
 #pragma unroll
@@ -1070,6 +1080,14 @@ __global__ __launch_bounds__(64) void k_dseed(const Ctl* __restrict__ ctl, const
     const bool ok_v = maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tau_out;
     const bool ok_c = !la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tau_out);
     ver.unsafe[j] = (ok_v && ok_c) ? 0 : 1;
+    flag_unprov = !provable;
+    flag_unsafe = !(ok_v && ok_c);
+    }
+    {
+        // statistics for the host's trace line (one atomic per wave and only when something is flagged)
+        const unsigned long long b1 = __builtin_amdgcn_ballot_w64(flag_unprov), b2 = __builtin_amdgcn_ballot_w64(flag_unsafe);
+        if (threadIdx.x == 0 && b1) atomicAdd((unsigned long long*)&ctl->stat_unprovable, (unsigned long long)__builtin_popcountll(b1));
+        if (threadIdx.x == 0 && b2) atomicAdd((unsigned long long*)&ctl->stat_unsafe, (unsigned long long)__builtin_popcountll(b2));
     }
     // the tile as a whole: when even the largest displacement stays below every point's threshold, no row can matter
     // to any point of the tile and its dirty scan is not run at all (the same test k_scan makes per 16 rows)
