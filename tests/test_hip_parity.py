@@ -285,3 +285,20 @@ def test_quiet_stream_then_new_populations(lookahead, wps, window):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
         _check_against_oracle(h, o)
+
+
+@pytest.mark.parametrize("g,window,lookahead", [(8, 16384, 0), (3, 8192, 3), (40, 24576, 0), (150, 24576, 2)])
+def test_long_chains(g, window, lookahead):
+    """Few microclusters and large windows: every MC absorbs hundreds to thousands of points per window, so the chains
+    k_chain replays are far longer than the 32-entry member lists, and k_dseed finds live versions by reading the
+    claims backwards (very long chains) or by walking the chain (chains a little over the list)."""
+    from oracle import oracle as O
+    n, d = 70000, 6
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.08))
+    h, o = _hdd(cfg, window=window, lookahead=lookahead), O.OracleHDDStream(cfg)
+    for t in range(2):
+        X = scenarios.make_blobs(5100 + t, n, d, g, 0.015)
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+    assert h.stats()["windows"] * 32 * g < n  # on average the chains were longer than the member lists
