@@ -921,8 +921,8 @@ int cc_online_run(cc_handle* h)
                     push_ctl(h);
                 }
                 if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
-                            done, h->hc.m_rows, wins, pts, trunc_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
+                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
+                            done, h->hc.m_rows, wins, pts, trunc_batch, unk_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
                             (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, want, Rcur);
                 // settle quickly at the start of a call and whenever windows are being truncated
                 batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
