@@ -58,6 +58,27 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
+// page-locked host buffer for device -> host copies that sit on the step's critical path
+struct PinBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    void* ensure(size_t bytes)
+    {
+        if (bytes > n) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            n = 0;
+            HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+            n = bytes;
+        }
+        return p;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    PinBuf() = default;
+    PinBuf(const PinBuf&) = delete;
+    PinBuf& operator=(const PinBuf&) = delete;
+};
+
 struct TableStore {
     DevBuf<double> cf1, cf2, cen, pref, scl, w;
     DevBuf<int> kind, key;
@@ -162,6 +183,7 @@ struct cc_handle {
     DevBuf<int> flags;
 
     std::vector<hipEvent_t> ev_pool;
+    PinBuf pin_adj;  // offline phase: weighted-reachability bitmask
 };
 
 namespace {
@@ -1176,12 +1198,12 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                            h->adjw.p, words, mp, d, p.ups_eps_sq);
         std::vector<int8_t> core(mp);
         std::vector<int> pdim(mp), nn(mp);
-        std::vector<unsigned long long> adjw((size_t)mp * words);
+        unsigned long long* const adjw = static_cast<unsigned long long*>(h->pin_adj.ensure((size_t)mp * words * 8));
         h->pcore_ids_host.resize(mp);
         HIPCHK(hipMemcpyAsync(core.data(), h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(pdim.data(), h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(adjw.data(), h->adjw.p, (size_t)mp * words * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(adjw, h->adjw.p, (size_t)mp * words * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->pcore_ids_host.data(), h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
