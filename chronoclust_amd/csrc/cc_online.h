@@ -20,16 +20,23 @@
 //                        labels by prefix sums in point order) and opens the next window
 //
 // Everything before the frontier is exactly what the sequential loop would have
-// produced; a window always commits at least its first point.
+// produced; a window always commits at least its first point (the one exception:
+// while the host does not launch the dirty scans - k_dseed ruled them out for every
+// point of the last batch - k_decide refuses points that would need them, and a
+// window whose first point is refused commits nothing and idles the batch).
 //
 // Lookahead: the snapshot scan of the next window may run on a second stream while
 // this window is validated, against the table one commit earlier.  What it cannot
 // see - the rows this window's commit changes - is kept as the "carry set" (struct
 // Carry) and enters the next window's validation like version rows that precede its
 // first point (k_dseed, k_scan<DIRTY=true, mode 1>, k_decide, k_chain, k_commit_b).
+// Lookahead scans read one of two scan copies of the table (struct ScanCopy), kept
+// up to date by k_apply_carry and k_commit_b, so that a commit never waits for them.
 //
-// Arithmetic: IEEE double, no contraction (-ffp-contract=off), sums over dimensions
-// left to right as in utilities/mc_functions.py under numba.
+// Arithmetic: IEEE double, no contraction by the compiler (-ffp-contract=off), sums
+// over dimensions left to right as in utilities/mc_functions.py under numba; the one
+// hand-written fusion (distance terms of the scans when k is a power of two) is
+// exact, see CC_TINY.
 #pragma once
 #include <type_traits>
 
@@ -819,7 +826,8 @@ __device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
 // k_dseed: per window point and kind, the cap and the first candidate of the dirty scan (one thread per point).
 // A live version only matters to point j if it beats what j already has.  If j's best snapshot candidate c1 is
 // still untouched when j arrives, that is c1 itself (cap = d1).  If c1 was touched, the live version of c1's MC
-// is itself a candidate: find it (short walk along the chain), take its exact distance as the first candidate;
+// is itself a candidate: find it (member list, then walk or backward read of the claims), take its exact distance
+// as the first candidate;
 // everything else has to beat that.  Loose fallback: the snapshot's second-best distance d2.
 // seed[j*4 + kd*2] = first candidate (slot -1: none), seed[j*4 + kd*2 + 1].dist = cap.
 // ---------------------------------------------------------------------------------
