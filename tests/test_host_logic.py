@@ -54,3 +54,24 @@ def test_letters_run_past_z():
     t = TrackByLineage()
     got = [t.get_new_letter() for _ in range(26 * 2 + 2)]
     assert got[25:28] == ["Z", "AA", "BB"] and got[51:54] == ["ZZ", "AAA", "BBB"]
+
+
+def test_binary_side_input_readers(tmp_path):
+    """`.npy` timepoints (SURVEY 8f item 3): values as stored, column names from `<file>.columns` or m0.. by default;
+    CSV files keep the reference's reader (header row, pd.read_csv)."""
+    import numpy as np
+    import pandas as pd
+    from chronoclust_amd import app
+    from chronoclust_amd.scaling.scaler import read_timepoint
+    X = np.random.default_rng(0).random((7, 3))
+    npy = str(tmp_path / "tp0.npy")
+    np.save(npy, X)
+    assert np.array_equal(read_timepoint(npy), X)
+    assert app.get_dataset_attributes(npy) == ["m0", "m1", "m2"]
+    with open(npy + ".columns", "w") as f:
+        f.write("CD4\nCD8\nLy6C\n")
+    assert app.get_dataset_attributes(npy) == ["CD4", "CD8", "Ly6C"]
+    csv = str(tmp_path / "tp0.csv")
+    pd.DataFrame(X, columns=["a", "b", "c"]).to_csv(csv, index=False)
+    assert app.get_dataset_attributes(csv) == ["a", "b", "c"]
+    assert np.allclose(read_timepoint(csv), X, rtol=0, atol=1e-15)
