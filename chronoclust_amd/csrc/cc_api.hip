@@ -139,6 +139,7 @@ struct cc_handle {
     int since_shrink = 1000;  // batches since the window was last shrunk
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
+    bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -467,6 +468,8 @@ int cc_create(int device, cc_handle** out)
         h->trace = tr && tr[0] == '1';
         const char* nd = getenv("CHRONOCLUST_HIP_NODIRTY");
         h->allow_nodirty = !(nd && nd[0] == '0');
+        const char* cl = getenv("CHRONOCLUST_HIP_CLAIMS");
+        h->allow_claims = !(cl && cl[0] == '0');
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -790,6 +793,9 @@ int cc_online_run(cc_handle* h)
             const int dblocks = (gw + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
             const int cblocks = (gw + 7) / 8;
             const int rblocks = std::min((gw + 7) / 8, 1024);
+            // few MCs: the claims of a window are gathered per MC by k_claims (rows beyond scan_rows, e.g. rows created
+            // during the batch, keep k_decide's atomics)
+            const int scan_rows = (h->allow_claims && h->hc.m_rows > 0 && h->hc.m_rows <= 1024) ? h->hc.m_rows : 0;
             // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
             // a batch, then kept up commit by commit
             ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
@@ -831,7 +837,9 @@ int cc_online_run(cc_handle* h)
                 }
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
                                    h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
-                                   h->dpath.p, S, Sd, 0, 0);
+                                   h->dpath.p, S, Sd, 0, 0, scan_rows);
+                if (scan_rows > 0)
+                    hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
                 // of the previous commit (before this window's commit overwrites the carry set), then, in k_commit_b,
                 // this window's own
@@ -850,7 +858,9 @@ int cc_online_run(cc_handle* h)
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
-                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r, nodirty ? 1 : 0);
+                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r, nodirty ? 1 : 0, scan_rows);
+                    if (scan_rows > 0)
+                        hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                    h->rk.p, h->rec.p);

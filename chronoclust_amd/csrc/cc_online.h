@@ -1122,7 +1122,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const Cand* __restrict__ dpart, const Cand* __restrict__ dpart2,
                                                 const Cand* __restrict__ dseed,
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
-                                                int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty)
+                                                int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
+                                                int scan_rows)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1263,7 +1264,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
         if ((j & 15) == 0) ver.tile_dsq[j >> 4] = 0ull;  // the next k_chain takes maxima into it
-        if (T != CC_T_UNKNOWN) {
+        // (claims on the first scan_rows table rows are gathered by k_claims instead, without atomics)
+        if (T != CC_T_UNKNOWN && !(T < M0 && T < scan_rows)) {
             // first / last point of this window that targets T, for the round that replays these claims
             // (provisional ids of new MCs index the free rows behind the table)
             const unsigned long long sn = (stamp + 1ull) << 20;
@@ -1285,6 +1287,54 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             }
             if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)T * CC_CHAIN_MEMB + pos] = j;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_claims: first / last claimant, number of claimants and (up to CC_CHAIN_MEMB) members of the chains of the first
+// scan_rows table rows, one workgroup per MC reading the claims once.  With few MCs the per-point atomics of
+// k_decide pile up on a handful of addresses (68 us per call at 50 MCs, measured); the host launches this kernel
+// instead while the table is small.  Same stamps and formats as k_decide writes.
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Table tab, const int* __restrict__ T,
+                                                int round, int scan_rows)
+{
+    CC_LATENCY_KERNEL();
+    const int B = ctl->win_b;
+    if (B == 0) return;
+    if (round > 0 && ctl->fc[round - 1] >= B) return;  // k_decide of this round did not run either
+    const int M0 = ctl->m_rows;
+    const int m = blockIdx.x;
+    if (m >= M0 || m >= scan_rows) return;
+    __shared__ int s_pos, s_first, s_last;
+    if (threadIdx.x == 0) { s_pos = 0; s_first = CC_IDX_INF; s_last = -1; }
+    __syncthreads();
+    int lmin = CC_IDX_INF, lmax = -1;
+    const int4* T4 = reinterpret_cast<const int4*>(T);  // (the buffer is padded to whole 128-entry blocks)
+    for (int base = (int)threadIdx.x * 4; base < B; base += 256 * 4) {
+        const int4 v = T4[base >> 2];
+        const int e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = base + c;
+            if (j < B && e[c] == m) {
+                lmin = j < lmin ? j : lmin;
+                lmax = j > lmax ? j : lmax;
+                const int pos = atomicAdd(&s_pos, 1);
+                if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+            }
+        }
+    }
+    if (lmax >= 0) { atomicMin(&s_first, lmin); atomicMax(&s_last, lmax); }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_pos > 0) {
+        const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+        const unsigned long long sn = (stamp + 1ull) << 20;
+        const size_t wr = (size_t)((round + 1) & 1) * tab.cap + (size_t)m;  // the copy the next round reads
+        tab.touch[wr] = sn | (unsigned long long)(0xFFFFF - s_first);
+        tab.last[wr] = sn | (unsigned long long)s_last;
+        tab.cnt[m] = ((stamp + 1ull) << 24) | (unsigned long long)s_pos;
     }
 }
 
