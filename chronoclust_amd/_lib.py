@@ -65,6 +65,7 @@ SYMBOLS = {
     "cc_export": (C.c_int, [C.c_void_p, C.c_int, _i64p, _i64p, _dp, _dp, _dp, _dp, _dp]),
     "cc_inject_mc": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, _dp, _dp, _dp, _dp, C.c_double, C.c_int64,
                                C.c_int64]),
+    "cc_inject_bulk": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, _dp, _i64p, _i64p]),
     "cc_offline": (C.c_int, [C.c_void_p, _i32p, _i8p, _i32p, _i32p, _i32p]),
     "cc_num_core": (C.c_int, [C.c_void_p]),
     "cc_cluster_size": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -224,6 +225,20 @@ class Handle(object):
         cf1, cf2, cen, pref = _f64(cf1), _f64(cf2), _f64(cen), _f64(pref)
         self._check(self._lib.cc_inject_mc(self._h, kind, len(cf1), _ptr(cf1), _ptr(cf2), _ptr(cen), _ptr(pref),
                                            float(w), int(id), int(uid)))
+
+    def inject_bulk(self, kind, cf1, cf2, cen, pref, w, id, uid):
+        """Appends len(w) microclusters to a list with one upload per column (cc_inject_bulk)."""
+        cf1, cf2, cen, pref, w = _f64(cf1), _f64(cf2), _f64(cen), _f64(pref), _f64(w)
+        id = np.ascontiguousarray(id, dtype=np.int64)
+        uid = np.ascontiguousarray(uid, dtype=np.int64)
+        n = w.shape[0]
+        if n == 0:
+            return
+        if cf1.shape != (n, cf1.shape[1]) or any(a.shape != cf1.shape for a in (cf2, cen, pref)) or \
+                id.shape != (n,) or uid.shape != (n,):
+            raise ValueError("inject_bulk: cf1/cf2/cen/pref must be [n, d], w/id/uid [n]")
+        self._check(self._lib.cc_inject_bulk(self._h, kind, cf1.shape[1], n, _ptr(cf1), _ptr(cf2), _ptr(cen),
+                                             _ptr(pref), _ptr(w), _ptr(id, _i64p), _ptr(uid, _i64p)))
 
     def offline_arrays(self, dumps=False):
         """cc_offline + cc_clusters_export: (members, offsets, w, cf1, cf2, cen, pref), info - all clusters as arrays."""

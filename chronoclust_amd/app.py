@@ -67,7 +67,9 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
         for _, gate in gating_df.iterrows():
             centroid = tuple(gate[dataset_attributes].values)
             gating[int(gate['Day'])][centroid] = gate['PopName']
-    if not (restoring and os.path.exists(result_filename)):
+    if restoring and os.path.exists(result_filename):
+        drop_rows_after(result_filename, hddstream.last_data_timestamp)
+    else:
         write_file_header(result_filename, result_file_header)
 
     scaler = None
@@ -169,29 +171,55 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, clust
 
 
 def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by_lineage):
-    """State after a completed timepoint (app.py:402-433): microcluster tables + counters as arrays, the two
-    trackers pickled (they only hold small Cluster records here)."""
+    """State after a completed timepoint (app.py:402-433): ONE bundle holding the microcluster tables + counters
+    as arrays and the two trackers pickled (they only hold small Cluster records here), written to a temporary
+    file and moved into place with os.replace, so that a crash leaves either the previous image or the new one,
+    never the clustering of one timepoint beside the trackers of another."""
+    import io
     import pickle
     d = "{}/program_images".format(output_dir)
     os.makedirs(d, exist_ok=True)
-    np.savez(os.path.join(d, HDDSTREAM_OBJ + '.npz'), **hddstream.get_state())
-    with open(os.path.join(d, TRACKER_HISTORICAL_ASSOC), 'wb') as f:
-        pickle.dump(tracker_by_association, f)
-    with open(os.path.join(d, TRACKER_LINEAGE), 'wb') as f:
-        pickle.dump(tracker_by_lineage, f)
+    state = hddstream.get_state()
+    state[TRACKER_HISTORICAL_ASSOC] = np.frombuffer(pickle.dumps(tracker_by_association), dtype=np.uint8)
+    state[TRACKER_LINEAGE] = np.frombuffer(pickle.dumps(tracker_by_lineage), dtype=np.uint8)
+    state["image_timepoint"] = np.int64(hddstream.last_data_timestamp)
+    buf = io.BytesIO()
+    np.savez(buf, **state)
+    final = os.path.join(d, HDDSTREAM_OBJ + '.npz')
+    tmp = final + '.tmp'
+    with open(tmp, 'wb') as f:
+        f.write(buf.getvalue())
+        f.flush()
+        os.fsync(f.fileno())
+    os.replace(tmp, final)
 
 
 def restore_program_state(program_state_dir, hddstream):
     """Loads what save_program_state wrote into `hddstream`; returns the two trackers (app.py:436-465)."""
     import pickle
     with np.load(os.path.join(program_state_dir, HDDSTREAM_OBJ + '.npz')) as z:
-        hddstream.set_state({k: z[k] for k in z.files})
-    with open(os.path.join(program_state_dir, TRACKER_HISTORICAL_ASSOC), 'rb') as f:
-        tracker_by_association = pickle.load(f)
-    with open(os.path.join(program_state_dir, TRACKER_LINEAGE), 'rb') as f:
-        tracker_by_lineage = pickle.load(f)
+        state = {k: z[k] for k in z.files}
+    if int(state["image_timepoint"]) != int(state["last_data_timestamp"]):
+        raise ValueError("program image is inconsistent: trackers of timepoint {} beside microclusters of {}".format(
+            int(state["image_timepoint"]), int(state["last_data_timestamp"])))
+    tracker_by_association = pickle.loads(state.pop(TRACKER_HISTORICAL_ASSOC).tobytes())
+    tracker_by_lineage = pickle.loads(state.pop(TRACKER_LINEAGE).tobytes())
+    hddstream.set_state(state)
     tracker_by_association._handle = hddstream._h
     return tracker_by_association, tracker_by_lineage
+
+
+def drop_rows_after(result_filename, last_timepoint):
+    """A run that stopped between writing timepoint t's rows and saving t's image resumes at t: rows of
+    timepoints the image does not cover are dropped before result.csv is appended to again."""
+    with open(result_filename, newline='') as f:
+        rows = list(csv.reader(f))
+    keep = rows[:1] + [r for r in rows[1:] if r and int(r[0]) <= last_timepoint]
+    if len(keep) != len(rows):
+        tmp = result_filename + '.tmp'
+        with open(tmp, 'w') as f:
+            csv.writer(f).writerows(keep)
+        os.replace(tmp, result_filename)
 
 
 def setup_logger(log_dir):

@@ -215,9 +215,9 @@ class HDDStream(object):
         self._h.set_params(self.epsilon_squared, self.delta_squared, self.k, self.beta, 0.0, 0.0, self.upsilon,
                            self.upsilon ** 2, self.delta, max(d, 1))
         for kind, name in ((_lib.PCORE, "pcore"), (_lib.OUTLIER, "outlier")):
-            ids = state["%s_id" % name]
-            for i in range(len(ids)):
-                self._h.inject(kind, state["%s_cf1" % name][i], state["%s_cf2" % name][i], state["%s_cen" % name][i],
-                               state["%s_pref" % name][i], state["%s_w" % name][i], ids[i], state["%s_uid" % name][i])
+            if len(state["%s_id" % name]):  # the whole list in one upload (cc_inject_bulk)
+                self._h.inject_bulk(kind, state["%s_cf1" % name].reshape(-1, d), state["%s_cf2" % name].reshape(-1, d),
+                                    state["%s_cen" % name].reshape(-1, d), state["%s_pref" % name].reshape(-1, d),
+                                    state["%s_w" % name], state["%s_id" % name], state["%s_uid" % name])
         self._h.set_counters(state["pcore_MC_last_id"], state["outlier_MC_last_id"])
         self._invalidate()

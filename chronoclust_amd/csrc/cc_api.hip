@@ -1098,6 +1098,47 @@ int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const dou
     });
 }
 
+int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* cf1, const double* cf2,
+                   const double* cen, const double* pref, const double* w, const int64_t* id, const int64_t* uid)
+{
+    if (!h || n < 0) return CC_ERR_BAD_ARG;
+    if (n == 0) return CC_OK;
+    if (!cf1 || !cf2 || !cen || !pref || !w || !id || !uid) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        int rc = set_dim(h, d);
+        if (rc != CC_OK) return rc;
+        ensure_table(h, (size_t)h->hc.m_rows + (size_t)n);
+        const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d, nn = (size_t)n;
+        for (size_t i = 0; i < nn * dd; ++i)
+            if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) { h->tainted = true; break; }
+        const int knd = kind == CC_PCORE ? CC_KIND_PCORE : CC_KIND_OUTLIER;
+        int& nkeys = kind == CC_PCORE ? h->hc.n_pkeys : h->hc.n_okeys;
+        std::vector<int> kinds(nn, knd), keys(nn);
+        for (size_t i = 0; i < nn; ++i) keys[i] = nkeys + (int)i;
+        static_assert(sizeof(long long) == sizeof(int64_t), "int64");
+        HIPCHK(hipMemcpyAsync(h->tab.cf1.p + r * dd, cf1, nn * dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.cf2.p + r * dd, cf2, nn * dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.cen.p + r * dd, cen, nn * dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.pref.p + r * dd, pref, nn * dd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.w.p + r, w, nn * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.kind.p + r, kinds.data(), nn * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.key.p + r, keys.data(), nn * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.id.p + r, id, nn * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->tab.uid.p + r, uid, nn * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        nkeys += n;
+        h->hc.m_rows += n;
+        for (size_t i = 0; i < nn; ++i) {
+            if (kind == CC_PCORE && id[i] >= h->hc.pcore_last_id) h->hc.pcore_last_id = id[i] + 1;
+            if (uid[i] >= h->hc.outlier_last_id) h->hc.outlier_last_id = uid[i] + 1;
+        }
+        refresh_ctl_params(h);
+        push_ctl(h);
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return (int)CC_OK;
+    });
+}
+
 int cc_decay_downgrade(cc_handle* h, double factor)
 {
     if (!h) return CC_ERR_BAD_ARG;

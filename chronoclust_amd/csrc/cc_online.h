@@ -1594,8 +1594,8 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         if (threadIdx.x == 0) rec->n = 0;
         return;
     }
-    __shared__ int wsum[16];
-    __shared__ int tot;
+    __shared__ unsigned wsum[16];
+    __shared__ unsigned tot;
     __shared__ int dirty_tiles;
     const int r = ctl->last_round;
     const bool la_win = ctl->mode != 0;  // this window's snapshot scan ran ahead (read before thread 0 moves on)
@@ -1617,50 +1617,51 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const int win_cfg = ctl->win_cfg;
 
     // Per point: bit 0 "creates a MC", bit 1 "its add promoted the MC"; read with coalesced loads into LDS, then
-    // every thread ranks a contiguous run of points (packed counts: low 16 bits creations, high 16 bits
-    // promotions; B <= 32768).
+    // every thread ranks a contiguous run of points (packed counts, unsigned: low 16 bits creations, high 16 bits
+    // promotions; B <= 32768, and a point either creates or promotes, so creations <= 32768 < 2^16 never carry
+    // into the promotions and promotions <= 32768 fit the upper 16 bits).
     __shared__ unsigned char sflag[32768];
     // (steady state: nothing was created or promoted in this window - nothing to rank, k_commit_b never reads rk)
     const bool events = ctl->any_new[r - 1] != 0 || ctl->any_up[r] != 0;
-    if (threadIdx.x == 0) tot = 0;
+    if (threadIdx.x == 0) tot = 0u;
     if (events) {
     for (int j = tid; j < B; j += 1024)
         sflag[j] = (j < n) ? (unsigned char)(((T[j] == M0 + j) ? 1 : 0) | ((ver.upg[j] == j) ? 2 : 0)) : (unsigned char)0;
     __syncthreads();
     const int per = (B + 1023) >> 10;  // points per thread
-    int mine = 0;
+    unsigned mine = 0u;
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
-        const int f = (j < B) ? (int)sflag[j] : 0;
-        mine += (f & 1) | ((f & 2) << 15);
+        const unsigned f = (j < B) ? (unsigned)sflag[j] : 0u;
+        mine += (f & 1u) | ((f & 2u) << 15);
     }
     // inclusive wave scan of the per-thread sums
-    int v = mine;
+    unsigned v = mine;
     const int lane = tid & 63, wid = tid >> 6;
     for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
+        const unsigned o = __shfl_up(v, off);
         if (lane >= off) v += o;
     }
     if (lane == 63) wsum[wid] = v;
     __syncthreads();
     if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 16; ++i) { const int x = wsum[i]; wsum[i] = run; run += x; }
+        unsigned run = 0u;
+        for (int i = 0; i < 16; ++i) { const unsigned x = wsum[i]; wsum[i] = run; run += x; }
         tot = run;
     }
     __syncthreads();
-    int run = v - mine + wsum[wid];
+    unsigned run = v - mine + wsum[wid];
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
         if (j < B) {
-            rk[j] = run;
-            const int f = (int)sflag[j];
-            run += (f & 1) | ((f & 2) << 15);
+            rk[j] = (int)run;  // exclusive prefix: at most 32767 promotions before j, fits 31 bits
+            const unsigned f = (unsigned)sflag[j];
+            run += (f & 1u) | ((f & 2u) << 15);
         }
     }
     }
     __syncthreads();
-    const int tot_new = tot & 0xFFFF, tot_up = tot >> 16;
+    const int tot_new = (int)(tot & 0xFFFFu), tot_up = (int)(tot >> 16);
     // Lookahead: the snapshot scan of the next window is already under way (or done) if the host enqueues such
     // scans; it is usable when this window committed in full, so that the next one starts where that scan assumed.
     const unsigned long long seq = ctl->window_seq;

@@ -143,6 +143,11 @@ int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w,
 int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const double* cf2, const double* cen,
                  const double* pref, double w, int64_t id, int64_t uid);
 
+/* Appends n microclusters to a list in one upload (checkpoint restore of a whole table: what unpickling the
+ * reference's pcore_MC / outlier_MC lists does, app.py:436-465).  cf1/cf2/cen/pref are [n, d]; w, id, uid [n]. */
+int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* cf1, const double* cf2,
+                   const double* cen, const double* pref, const double* w, const int64_t* id, const int64_t* uid);
+
 /* HDDStream.offline_clustering (hddstream.py:464-510) + PreDeCon.run
  * (clustering/predecon.py:49-267): core flags, eps-neighbourhoods, subspace
  * preference vectors and weighted reachability on the device; the ordered

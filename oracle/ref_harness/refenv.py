@@ -2,8 +2,8 @@
 
 Only usable in the build container (the reference does not travel to the GPU
 box).  Used by ``tests/golden/make_golden.py`` to produce the committed golden
-vectors and by ``tests/test_oracle_vs_reference.py`` (skipped when the
-reference is absent).
+vectors (the oracle is then checked against those vectors by
+``tests/test_oracle_golden.py``, which needs no reference).
 
 Two adjustments make the import faithful to the numba-compiled original:
 
@@ -13,6 +13,13 @@ Two adjustments make the import faithful to the numba-compiled original:
   (numpy itself sums pairwise for n >= 8).  The reference files are not
   touched: the module-level name ``np`` of the two modules is rebound to a
   proxy object after import.
+
+Known deviation from a real numba run: ``np.linalg.norm`` in
+``predeconmc_functions.calculate_euclidean_dist`` evaluates as numpy's
+sqrt(dot) here, while numba lowers it to BLAS nrm2.  The oracle and the HIP
+kernel use sqrt of the left-to-right sum; eps-neighbourhood membership exactly
+on the ``<= upsilon * epsilon`` boundary can therefore differ from a numba run
+by one ulp ("known unpinned spot").  No golden hits it.
 """
 import os
 import sys

@@ -186,6 +186,48 @@ def test_restore_program_continues_exactly(tmp_path):
         assert open(os.path.join(out, "cluster_points_D%d.csv" % t), "rb").read() == exp_text
 
 
+def test_restore_after_crash_between_result_rows_and_image(tmp_path):
+    """A crash after timepoint 3's rows were appended to result.csv but before its image was saved: the resumed run
+    re-processes timepoint 3 from the image of timepoint 2 and must not leave its rows in result.csv twice."""
+    from chronoclust_amd import app
+    import chronoclust_amd.app as A
+    c1 = os.path.join(GOLDEN, "c1")
+    data = [os.path.join(c1, "synthetic_d%d.csv.gz" % t) for t in range(5)]
+    gating = os.path.join(c1, "gating_centroids.csv")
+    out = str(tmp_path)
+
+    class Crash(Exception):
+        pass
+
+    orig = A.save_program_state
+
+    def crash_before_saving_t3(h, o, ta, tl):
+        if h.last_data_timestamp == 3:
+            raise Crash()
+        orig(h, o, ta, tl)
+    try:
+        A.save_program_state = crash_before_saving_t3
+        try:
+            app.run(data=data, output_directory=out, gating_centroid_file=gating, **scenarios.C1_PARAMS)
+        except Crash:
+            pass
+        finally:
+            A.save_program_state = orig
+        _reset_logging()
+        rows_before = open(os.path.join(out, "result.csv")).read()
+        assert "\n3," in rows_before  # timepoint 3's rows are there, its image is not
+        assert not os.path.exists(os.path.join(out, "program_images", "hddstream.npz.tmp"))
+        app.run(data=data, output_directory=out, gating_centroid_file=gating, restore_program=True,
+                **scenarios.C1_PARAMS)
+    finally:
+        _reset_logging()
+    with open(os.path.join(c1, "expected_result.csv"), newline="") as f:
+        exp = f.read()
+    with open(os.path.join(out, "result.csv"), newline="") as f:
+        got = f.read()
+    assert got.replace("\r\n", "\n") == exp.replace("\r\n", "\n")
+
+
 @pytest.mark.parametrize("name", ["d5_norm", "d20"])
 def test_binary_side_input_gives_the_same_files(name, tmp_path):
     """`.npy` timepoints (no text parse) against the same values read from CSV: result.csv and the

@@ -75,3 +75,21 @@ def test_binary_side_input_readers(tmp_path):
     pd.DataFrame(X, columns=["a", "b", "c"]).to_csv(csv, index=False)
     assert app.get_dataset_attributes(csv) == ["a", "b", "c"]
     assert np.allclose(read_timepoint(csv), X, rtol=0, atol=1e-15)
+
+
+def test_drop_rows_after_keeps_header_and_earlier_timepoints(tmp_path):
+    """restore_program: rows of timepoints the saved image does not cover are removed before appending again
+    (chronoclust_amd/app.py:drop_rows_after); quoting of lineage ids with commas survives the rewrite."""
+    import csv
+    from chronoclust_amd.app import append_to_file, drop_rows_after, write_file_header
+    fn = str(tmp_path / "result.csv")
+    write_file_header(fn, ["timepoint", "cumulative_size", "tracking_by_lineage"])
+    append_to_file(fn, [[0, "10.0", "A"], [1, "12.5", "(A,B)"], [2, "3.0", "(A,B)|1"], [2, "4.0", "C"]])
+    before = open(fn, newline="").read()
+    drop_rows_after(fn, 2)
+    assert open(fn, newline="").read() == before
+    drop_rows_after(fn, 1)
+    with open(fn, newline="") as f:
+        rows = list(csv.reader(f))
+    assert rows == [["timepoint", "cumulative_size", "tracking_by_lineage"], ["0", "10.0", "A"], ["1", "12.5", "(A,B)"]]
+    assert open(fn, newline="").read() == before[:before.index("2,3.0")]

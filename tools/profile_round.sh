@@ -4,7 +4,8 @@
 set -o pipefail
 OUT=${1:-gpurun_out/final}
 mkdir -p $OUT
-cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}" || exit 1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
