@@ -1,0 +1,117 @@
+"""The per-timepoint pipeline of chronoclust/app.py:157-216 without file I/O: HDDStream, cluster records,
+TrackByLineage, TrackByHistoricalAssociation.  Shared by the full-size GPU tests (test infrastructure)."""
+from decimal import ROUND_HALF_UP, Decimal
+
+import numpy as np
+
+
+class _RecordingHandle(object):
+    """Forwards to a _lib.Handle and keeps the inputs / outputs of every cc_assoc_argmin call."""
+
+    def __init__(self, handle, log):
+        self._handle, self._log = handle, log
+
+    def assoc_argmin(self, cur_cen, cur_pref, prev_cen):
+        idx, dist = self._handle.assoc_argmin(cur_cen, cur_pref, prev_cen)
+        self._log.append(dict(cur_cen=np.array(cur_cen), cur_pref=np.array(cur_pref), prev_cen=np.array(prev_cen),
+                              idx=np.array(idx), dist=np.array(dist)))
+        return idx, dist
+
+
+def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None):
+    """Returns one dict per timepoint: labels_uid, pcore / outlier tables, `rows` = what write_result_file would
+    write per cluster (weight, pcore ids, preferred dimensions, lineage id, association string; app.py:229-260),
+    merge-ordered members of every cluster, and the recorded association argmin calls."""
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    from chronoclust_amd.objects.cluster import Cluster
+    from chronoclust_amd.tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
+    h = HDDStream(cfg, device=device, tuning=tuning)
+    assoc_log = []
+    lineage = TrackByLineage()
+    assoc = TrackByHistoricalAssociation(handle=_RecordingHandle(h._h, assoc_log))
+    out = []
+    for t, X in enumerate(Xs):
+        before = {kind: {k: v.copy() for k, v in h.table(kind).items() if k in ("uid", "w")} for kind in (0, 1)} \
+            if t > 0 else None
+        h.online_microcluster_maintenance(X, t)
+        pcore_by_id = {mc.id[0]: mc for mc in h.pcore_MC}
+        for found in h.final_clusters:
+            w = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)  # app.py:184
+            cl = Cluster(list(found.id), found.cluster_centroids, w, found.preferred_dimension_vector)
+            cl.add_pcore_objects(pcore_by_id)
+            lineage.add_new_child_cluster(cl)
+        lineage.calculate_ids()
+        assoc.set_current_clusters(lineage.child_clusters)
+        n_calls = len(assoc_log)
+        assoc.track_cluster_history()
+        rows = [(str(cl.cumulative_weight), cl.get_pcore_ids_as_str(), cl.get_preferred_dimensions_as_str(), cl.id,
+                 cl.get_historical_associates_as_str()) for cl in assoc.current_clusters]
+        rec = dict(labels_uid=h.labels_uid.copy(), pcore=h.table(0), outlier=h.table(1), rows=rows,
+                   members=[c.members_in_merge_order for c in h.final_clusters],
+                   counters=(h.pcore_MC_last_id, h.outlier_MC_last_id), stats=h.stats(),
+                   assoc_calls=assoc_log[n_calls:], before=before)
+        out.append(rec)
+        if on_timepoint is not None:
+            on_timepoint(t, h, rec)
+        lineage.transfer_child_to_parent()
+        assoc.transfer_current_to_previous()
+    return out
+
+
+def check_weights(rec, n_points, decay_factor=None):
+    """Every point adds weight 1.0 to exactly one microcluster, after the decay of the timestep boundary
+    (hddstream.py:283-286: w * 2^(-lambda * interval)), one add at a time (microcluster.py:147)."""
+    uid = np.concatenate([rec["pcore"]["uid"], rec["outlier"]["uid"]])
+    w = np.concatenate([rec["pcore"]["w"], rec["outlier"]["w"]])
+    assert len(np.unique(uid)) == len(uid)
+    u, counts = np.unique(rec["labels_uid"], return_counts=True)
+    assert counts.sum() == n_points
+    cnt = dict(zip(u.tolist(), counts.tolist()))
+    start = {}
+    if rec["before"] is not None:
+        for kind in (0, 1):
+            for a, b in zip(rec["before"][kind]["uid"].tolist(), rec["before"][kind]["w"].tolist()):
+                start[a] = b * decay_factor
+    w0 = np.array([start.get(x, 0.0) for x in uid.tolist()])
+    c = np.array([cnt.get(x, 0) for x in uid.tolist()])
+    # labels may also name microclusters that no longer exist?  No: deletion happens before the online loop.
+    assert set(cnt) <= set(uid.tolist())
+    exp = w0.copy()
+    for step in range(int(c.max()) if len(c) else 0):
+        exp = np.where(step < c, exp + 1.0, exp)
+    assert np.array_equal(exp, w)
+    # a microcluster that exists now and did not before was created by one of this timepoint's points
+    assert all(cnt.get(x, 0) >= 1 for x in uid.tolist() if x not in start)
+
+
+def check_cf_ordered_sums(X, rec, rng, samples=12):
+    """CF1 / CF2 of microclusters created in this timepoint = their points added one by one in arrival order."""
+    pc = rec["pcore"]
+    old = set() if rec["before"] is None else \
+        set(rec["before"][0]["uid"].tolist()) | set(rec["before"][1]["uid"].tolist())
+    fresh = [i for i, u in enumerate(pc["uid"].tolist()) if u not in old]
+    if not fresh:
+        return 0
+    d = X.shape[1]
+    picks = rng.choice(fresh, min(samples, len(fresh)), replace=False)
+    for pos in picks:
+        rows = np.nonzero(rec["labels_uid"] == pc["uid"][pos])[0]
+        cf1, cf2 = np.zeros(d), np.zeros(d)
+        for r in rows:
+            cf1 = cf1 + X[r]
+            cf2 = cf2 + X[r] * X[r]
+        assert np.array_equal(cf1, pc["cf1"][pos]) and np.array_equal(cf2, pc["cf2"][pos])
+        assert np.array_equal(cf1 / len(rows), pc["cen"][pos])
+    return len(picks)
+
+
+def same_results(a, b):
+    assert len(a) == len(b)
+    for t, (ra, rb) in enumerate(zip(a, b)):
+        assert np.array_equal(ra["labels_uid"], rb["labels_uid"]), t
+        for kind in ("pcore", "outlier"):
+            for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+                assert np.array_equal(ra[kind][key], rb[kind][key]), (t, kind, key)
+        assert ra["members"] == rb["members"], t
+        assert ra["rows"] == rb["rows"], t
+        assert ra["counters"] == rb["counters"], t
