@@ -11,7 +11,7 @@ PCORE, OUTLIER = 0, 1
 MAX_DIM = 64
 
 _ERRORS = {-1: "no HIP device / HIP runtime error", -2: "bad argument", -3: "non-finite input", -4: "out of memory",
-           -5: "internal error"}
+           -5: "internal error", -6: "exchange between ranks failed"}
 
 
 class ChronoclustHipError(RuntimeError):
@@ -34,7 +34,8 @@ class CcStats(C.Structure):
     _fields_ = [("points", C.c_int64), ("windows", C.c_int64), ("rounds", C.c_int64), ("truncated", C.c_int64),
                 ("scan_launches", C.c_int64), ("scan_ms", C.c_double), ("scan_pair_dims", C.c_double),
                 ("run_ms", C.c_double), ("rows", C.c_int64), ("table_rows_scanned", C.c_int64),
-                ("lookahead_windows", C.c_int64), ("reserved", C.c_int64 * 5)]
+                ("lookahead_windows", C.c_int64), ("sharded_windows", C.c_int64), ("comm_launches", C.c_int64),
+                ("comm_ms", C.c_double), ("reserved", C.c_int64 * 2)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -74,7 +75,16 @@ SYMBOLS = {
     "cc_clusters_export": (C.c_int, [C.c_void_p, _i64p, _i32p, _dp, _dp, _dp, _dp, _dp]),
     "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
     "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
+    "cc_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "cc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "cc_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "cc_comm_destroy": (C.c_int, [C.c_void_p]),
+    "cc_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
+    "cc_shard_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
+    "cc_set_shard_thresholds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
 }
+
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -103,6 +113,34 @@ def _f64(a):
 
 def _ptr(a, typ=_dp):
     return None if a is None else a.ctypes.data_as(typ)
+
+
+def comm_unique_id():
+    """The 128-byte RCCL id rank 0 hands to the other ranks of a stream group (cc_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().cc_comm_unique_id(buf)
+    if rc != 0:
+        raise ChronoclustHipError("cc_comm_unique_id failed (%s): is librccl available?" % _ERRORS.get(rc, rc))
+    return buf.raw
+
+
+def comm_init_local(handles):
+    """Makes the Handles of this process one group (rank = position): the in-process transport of the exact
+    multi-GPU path.  Each handle must then be driven by its own host thread; collective calls block until every
+    member has made them."""
+    arr = (C.c_void_p * len(handles))(*[h._h for h in handles])
+    rc = load().cc_comm_init_local(arr, len(handles))
+    if rc != 0:
+        raise ChronoclustHipError("cc_comm_init_local failed: %s" % _ERRORS.get(rc, rc))
+
+
+def shard_rows(n, world, rank, unit=1):
+    """[lo, hi) of n rows for `rank` of `world` in units of `unit` rows (cc_shard_rows; no GPU needed)."""
+    lo, hi = C.c_int32(), C.c_int32()
+    rc = load().cc_shard_rows(int(n), int(world), int(rank), int(unit), C.byref(lo), C.byref(hi))
+    if rc != 0:
+        raise ValueError("cc_shard_rows(%r, %r, %r, %r): %s" % (n, world, rank, unit, _ERRORS.get(rc, rc)))
+    return lo.value, hi.value
 
 
 class Handle(object):
@@ -278,6 +316,23 @@ class Handle(object):
         self._check(self._lib.cc_assoc_argmin(self._h, _ptr(cc), _ptr(cp), mc, _ptr(pc), mp, d, _ptr(idx, _i32p),
                                               _ptr(dist)))
         return idx, dist
+
+    def comm_init_rccl(self, unique_id, rank, world):
+        """Joins the RCCL communicator of a stream group (collective over the `world` processes)."""
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % COMM_ID_BYTES)
+        self._check(self._lib.cc_comm_init_rccl(self._h, bytes(unique_id), int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.cc_comm_destroy(self._h))
+
+    def comm_info(self):
+        r, w, t = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.cc_comm_info(self._h, C.byref(r), C.byref(w), C.byref(t)))
+        return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "local"}[t.value])
+
+    def set_shard_thresholds(self, min_row_dims=-1, offline_min_rows=-1):
+        self._check(self._lib.cc_set_shard_thresholds(self._h, int(min_row_dims), int(offline_min_rows)))
 
     def stats(self):
         s = CcStats()

@@ -17,6 +17,7 @@
 #include "cc_common.h"
 #include "cc_online.h"
 #include "cc_offline.h"
+#include "cc_comm.h"
 
 namespace {
 
@@ -185,6 +186,16 @@ struct cc_handle {
 
     std::vector<hipEvent_t> ev_pool;
     PinBuf pin_adj;  // offline phase: weighted-reachability bitmask
+
+    // exact multi-GPU path: this handle is rank comm.rank of comm.world replicas of one stream
+    cc::Comm comm;
+    // a snapshot scan is split over the ranks when the table holds at least this many (row, dim) entries
+    // (below that a window's scan is shorter than the all-gather that would follow it)
+    long long shard_min_row_dims = 400000;
+    int offline_shard_min_rows = 8192;  // the pair matrices of the offline phase / association tracker likewise
+    DevBuf<Cand> gsend, gpart;  // one merged record per window point (two parities) / the gathered records of all ranks
+    size_t gsend_stride = 0, gpart_stride = 0;
+    DevBuf<int> g_i32;          // gather scratch of the offline phase
 };
 
 namespace {
@@ -204,7 +215,10 @@ int guarded(cc_handle* h, F&& f)
     } catch (const HipErr& e) {
         char buf[512];
         snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
+        if (h && h->comm.local) h->comm.local->abandon();  // peers of an in-process group must not wait for this rank
         return fail(h, e.e == hipErrorOutOfMemory ? CC_ERR_OOM : CC_ERR_NO_DEVICE, buf);
+    } catch (const cc::CommErr& e) {
+        return fail(h, CC_ERR_COMM, "exchange between ranks failed: " + e.what);
     } catch (const std::bad_alloc&) {
         return fail(h, CC_ERR_OOM, "host allocation failed");
     }
@@ -355,7 +369,7 @@ struct ScanWaves {
 
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                    int mode)
+                    int mode, int shard_rank, int shard_world)
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
@@ -365,7 +379,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
     const bool filter = DIRTY || h->hc.filter != 0;
 #define CC_LAUNCH_SCAN(F, P)                                                                                   \
     hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
-                       part, round, mode, h->part_stride)
+                       part, round, mode, h->part_stride, shard_rank, shard_world)
     if (filter) {
         if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
         else CC_LAUNCH_SCAN(true, false);
@@ -381,16 +395,18 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 // dirty scan: mode 0 = version rows, 1 = carry set.
 template <bool DIRTY>
 void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                 int mode)
+                 int mode, int shard_rank = 0, int shard_world = 1)
 {
     const int d = h->d;
-    if (d <= 4) launch_scan_dp<4, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 8) launch_scan_dp<8, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 16) launch_scan_dp<16, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 20) launch_scan_dp<20, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 32) launch_scan_dp<32, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else if (d <= 40) launch_scan_dp<40, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
-    else launch_scan_dp<64, DIRTY>(h, st, win, rows, clean, part, S, round, mode);
+#define CC_SCAN_DP(DP) launch_scan_dp<DP, DIRTY>(h, st, win, rows, clean, part, S, round, mode, shard_rank, shard_world)
+    if (d <= 4) CC_SCAN_DP(4);
+    else if (d <= 8) CC_SCAN_DP(8);
+    else if (d <= 16) CC_SCAN_DP(16);
+    else if (d <= 20) CC_SCAN_DP(20);
+    else if (d <= 32) CC_SCAN_DP(32);
+    else if (d <= 40) CC_SCAN_DP(40);
+    else CC_SCAN_DP(64);
+#undef CC_SCAN_DP
 }
 
 int scan_waves_for_dim(int) { return 4; }
@@ -486,6 +502,9 @@ void cc_destroy(cc_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    h->comm.destroy();
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
         (void)hipStreamDestroy(h->stream);
@@ -691,6 +710,19 @@ int cc_online_run(cc_handle* h)
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
         refresh_ctl_params(h);
         ensure_window_buffers(h, win, std::max(S, Sd_full));
+        // Exact multi-GPU path: while the table is large enough, every rank scans its share of the table rows and
+        // the ranks all-gather one merged candidate record per window point; the rest of the window runs replicated.
+        // All ranks take the same decision: it depends on the row count only, which is the same everywhere.
+        const int world = h->comm.world, myrank = h->comm.rank;
+        // (a communicator of one rank takes the same path: that is how the RCCL calls are exercised on one GPU)
+        const bool grouped = h->comm.active();
+        auto want_shard = [&](int m_rows) { return grouped && (long long)m_rows * h->d >= h->shard_min_row_dims; };
+        if (grouped) {
+            h->gsend_stride = (size_t)h->win_alloc * 4;
+            h->gpart_stride = (size_t)world * h->win_alloc * 4;
+            h->gsend.ensure(2 * h->gsend_stride);
+            h->gpart.ensure(2 * h->gpart_stride);
+        }
         // every window of a batch may create one MC per point: rows for the largest batch that can be enqueued
         const size_t batch_max = (size_t)std::max(2, h->tun.windows_per_sync);
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * batch_max + 1);
@@ -752,7 +784,11 @@ int cc_online_run(cc_handle* h)
         HIPCHK(hipEventRecord(ev0, h->stream));
         size_t ev_used = 2;
         std::vector<std::pair<size_t, double>> timed;  // (event index, pair-dims covered)
+        std::vector<size_t> timed_comm;                // event index of every timed merge + all-gather
         const bool timing = h->tun.time_kernels != 0;
+        bool shard_on = want_shard(c.m_rows);
+        double pair_rows_eff = 0.0, pair_rows_prev = 0.0;  // (window points x table rows) this rank's scans covered
+        long long sharded_windows = 0;
 
         const Versions ver = versions_view(h);
         const Carry car = carry_view(h);
@@ -809,17 +845,38 @@ int cc_online_run(cc_handle* h)
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
                     const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
+                    const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
                     if (timing) {
                         hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
                         HIPCHK(hipEventRecord(a, st));
-                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
                         HIPCHK(hipEventRecord(b, st));
                         timed.push_back({ev_used, 0.0});
                         ev_used += 2;
                     } else {
-                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode);
+                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
+                    }
+                    if (shard_on) {
+                        // the rank's S partials per point -> one record per point -> the records of all ranks, in rank
+                        // order, in the gathered buffer of the window's parity (what k_decide round 0 reads)
+                        const int q = (mode == 1) ? (round & 1) : (int)(seq_host & 1ull);
+                        if (timing) HIPCHK(hipEventRecord(get_event(h, ev_used), st));
+                        hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
+                                           h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode);
+                        h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
+                                           (size_t)gw * 4 * sizeof(Cand), st);
+                        if (timing) {
+                            HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
+                            timed_comm.push_back(ev_used);
+                            ev_used += 2;
+                        }
                     }
                 };
+                // where k_decide round 0 finds the snapshot candidates of a point
+                const Cand* const dec_part = shard_on ? h->gpart.p : h->part.p;
+                const size_t dec_stride = shard_on ? h->gpart_stride : h->part_stride;
+                const int dec_S = shard_on ? world : S, dec_inner = shard_on ? 1 : S;
+                const size_t dec_outer = shard_on ? (size_t)gw * 4 : 0;
                 if (la_on) {
                     // first stream: this window's snapshot scan (enqueued one iteration ago on the second stream)
                     if (evScan) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));
@@ -835,9 +892,9 @@ int cc_online_run(cc_handle* h)
                 } else {
                     timed_scan(sA, 0, 0);
                 }
-                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
-                                   h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
-                                   h->dpath.p, S, Sd, 0, 0, scan_rows);
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
+                                   dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
+                                   h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
@@ -857,8 +914,9 @@ int cc_online_run(cc_handle* h)
                         launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
                     }
-                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, h->part.p,
-                                       h->part_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, S, Sd, r, nodirty ? 1 : 0, scan_rows);
+                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
+                                       dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
+                                       dec_inner, dec_outer);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
@@ -877,6 +935,8 @@ int cc_online_run(cc_handle* h)
             seq_host = h->hc.window_seq;
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
+            pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_on ? (double)world : 1.0);
+            pair_rows_prev = h->hc.stat_pair_rows;
             {
                 int used = 1;
                 for (int r = 1; r <= CC_MAX_ROUNDS; ++r) {
@@ -946,7 +1006,12 @@ int cc_online_run(cc_handle* h)
                 Sd = Sd_full;
                 nodirty = h->allow_nodirty && tiles > 0 && dtiles == 0 && trunc_batch == 0;
                 const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
-                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0) && done < N) {
+                // (a pending lookahead scan was made for the old split of the table rows: restart when the split changes)
+                const bool shard_next = want_shard(h->hc.m_rows);
+                if (shard_on) sharded_windows += wins;
+                const bool shard_flip = shard_next != shard_on;
+                shard_on = shard_next;
+                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0 || shard_flip) && done < N) {
                     h->hc.win_cfg = want;
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
                     set_lookahead(want_la);
@@ -973,7 +1038,8 @@ int cc_online_run(cc_handle* h)
         h->stats.rounds = h->hc.stat_rounds;
         h->stats.truncated = h->hc.stat_truncated;
         h->stats.rows = h->hc.m_rows;
-        h->stats.scan_pair_dims = h->hc.stat_pair_rows * (double)h->d;
+        h->stats.scan_pair_dims = pair_rows_eff * (double)h->d;
+        h->stats.sharded_windows = sharded_windows;
         h->stats.table_rows_scanned = h->hc.stat_table_rows;
         h->stats.lookahead_windows = h->hc.stat_lookahead;
         if (timing) {
@@ -985,6 +1051,14 @@ int cc_online_run(cc_handle* h)
             }
             h->stats.scan_launches = (int64_t)timed.size();
             h->stats.scan_ms = tot;
+            double ctot = 0.0;
+            for (size_t i : timed_comm) {
+                float e = 0.f;
+                HIPCHK(hipEventElapsedTime(&e, h->ev_pool[i], h->ev_pool[i + 1]));
+                ctot += e;
+            }
+            h->stats.comm_launches = (int64_t)timed_comm.size();
+            h->stats.comm_ms = ctot;
         }
         return (int)CC_OK;
     });
@@ -1229,9 +1303,18 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         if (mp == 0) return (int)CC_OK;
         const size_t md = (size_t)mp * d;
         const int words = (mp + 63) / 64;
+        // Multi-GPU: a rank evaluates a block of p rows (whole 64-row blocks) of the M x M pair matrices and the ranks
+        // all-gather what the ordered expansion needs of them: subspace preference vectors, neighbour counts, the
+        // weighted-reachability bitmask.  The eps-neighbour bitmask stays local (a row is only read by its owner).
+        const int world = h->comm.world, rank = h->comm.rank;
+        const bool shard = h->comm.active() && mp >= h->offline_shard_min_rows;
+        const int share = shard ? cc_shard_share(mp, world, 64) : words * 64;  // p rows per rank
+        const size_t rows_pad = shard ? (size_t)share * world : (size_t)mp;     // buffers hold every rank's block
+        int p_lo = 0, p_hi = mp;
+        if (shard) cc_shard_range(mp, world, rank, 64, &p_lo, &p_hi);
         h->pv_cf1.ensure(md); h->pv_cf2.ensure(md); h->pv_cen.ensure(md); h->pv_pref.ensure(md); h->pv_w.ensure(mp);
-        h->pv_id.ensure(mp); h->prow.ensure(mp); h->wvec.ensure(md); h->nn.ensure(mp); h->pdim.ensure(mp);
-        h->core.ensure(mp); h->adj.ensure((size_t)mp * words); h->adjw.ensure((size_t)mp * words);
+        h->pv_id.ensure(mp); h->prow.ensure(mp); h->wvec.ensure(rows_pad * d); h->nn.ensure(rows_pad); h->pdim.ensure(mp);
+        h->core.ensure(mp); h->adj.ensure(rows_pad * words); h->adjw.ensure(rows_pad * words);
         HIPCHK(hipMemcpyAsync(h->prow.p, rl.pcore.data(), (size_t)mp * 4, hipMemcpyHostToDevice, h->stream));
         PcoreView pv{h->pv_cf1.p, h->pv_cf2.p, h->pv_cen.p, h->pv_pref.p, h->pv_w.p, h->pv_id.p};
         const Ctl& c = h->hc;
@@ -1240,13 +1323,25 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                            pv, h->prow.p, mp, d);
         hipLaunchKernelGGL(k_core_flags, dim3((mp + 255) / 256), dim3(256), 0, h->stream, pv, mp, d, p.eps_sq, p.mu,
                            p.pi, p.k, c.inv_k, c.pow2, h->core.p);
-        hipLaunchKernelGGL(k_eps_neighbours, dim3(words, words), dim3(256), (size_t)2 * 64 * (d + 1) * sizeof(double),
-                           h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words);
-        hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, h->stream, pv.cen,
-                           h->adj.p, words, mp, d, p.delta, p.k, h->wvec.p, h->nn.p);
+        const int my_rows = p_hi - p_lo;
+        if (my_rows > 0) {
+            hipLaunchKernelGGL(k_eps_neighbours, dim3(words, (my_rows + 63) / 64), dim3(256),
+                               (size_t)2 * 64 * (d + 1) * sizeof(double), h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words,
+                               p_lo);
+            hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)(((size_t)my_rows * d + 255) / 256)), dim3(256), 0, h->stream,
+                               pv.cen, h->adj.p, words, mp, d, p.delta, p.k, h->wvec.p, h->nn.p, p_lo, p_hi);
+        }
+        if (shard) {
+            // in place: rank r's block sits at r * share rows of the same buffer on every rank
+            h->comm.all_gather(h->wvec.p + (size_t)rank * share * d, h->wvec.p, (size_t)share * d * 8, h->stream);
+            h->comm.all_gather(h->nn.p + (size_t)rank * share, h->nn.p, (size_t)share * 4, h->stream);
+        }
         hipLaunchKernelGGL(k_pdim, dim3((mp + 255) / 256), dim3(256), 0, h->stream, h->wvec.p, mp, d, h->pdim.p);
-        hipLaunchKernelGGL(k_weighted_reach, dim3(words, mp), dim3(64), 0, h->stream, pv.cen, h->wvec.p, h->adj.p,
-                           h->adjw.p, words, mp, d, p.ups_eps_sq);
+        if (my_rows > 0)
+            hipLaunchKernelGGL(k_weighted_reach, dim3(words, my_rows), dim3(64), 0, h->stream, pv.cen, h->wvec.p, h->adj.p,
+                               h->adjw.p, words, mp, d, p.ups_eps_sq, p_lo);
+        if (shard)
+            h->comm.all_gather(h->adjw.p + (size_t)rank * share * words, h->adjw.p, (size_t)share * words * 8, h->stream);
         std::vector<int8_t> core(mp);
         std::vector<int> pdim(mp), nn(mp);
         unsigned long long* const adjw = static_cast<unsigned long long*>(h->pin_adj.ensure((size_t)mp * words * 8));
@@ -1398,21 +1493,125 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
     return guarded(h, [&]() {
         if (mc == 0) return (int)CC_OK;
         const size_t cd = (size_t)mc * d, pd = (size_t)mp * d;
-        h->a_cur_cen.ensure(cd); h->a_cur_pref.ensure(cd); h->a_prev_cen.ensure(pd); h->a_idx.ensure(mc);
-        h->a_dist.ensure(mc);
+        // multi-GPU: a rank takes a block of current pcores; indices and distances are all-gathered
+        const int world = h->comm.world, rank = h->comm.rank;
+        const bool shard = h->comm.active() && mc >= h->offline_shard_min_rows;
+        const int share = shard ? cc_shard_share(mc, world, 1) : mc;
+        int c_lo = 0, c_hi = mc;
+        if (shard) cc_shard_range(mc, world, rank, 1, &c_lo, &c_hi);
+        h->a_cur_cen.ensure(cd); h->a_cur_pref.ensure(cd); h->a_prev_cen.ensure(pd);
+        h->a_idx.ensure(shard ? (size_t)share * world : (size_t)mc);
+        h->a_dist.ensure(shard ? (size_t)share * world : (size_t)mc);
         HIPCHK(hipMemcpyAsync(h->a_cur_cen.p, cur_cen, cd * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->a_cur_pref.p, cur_pref, cd * 8, hipMemcpyHostToDevice, h->stream));
         if (pd) HIPCHK(hipMemcpyAsync(h->a_prev_cen.p, prev_cen, pd * 8, hipMemcpyHostToDevice, h->stream));
         const double k = h->have_par ? h->par.k : 1.0;
         const int pow2 = is_pow2(k) ? 1 : 0;
-        hipLaunchKernelGGL(k_assoc_argmin, dim3(mc), dim3(64), 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,
-                           h->a_prev_cen.p, mc, mp, d, k, pow2 ? 1.0 / k : 0.0, pow2, h->a_idx.p, h->a_dist.p);
+        if (c_hi > c_lo)
+            hipLaunchKernelGGL(k_assoc_argmin, dim3(c_hi - c_lo), dim3(64), 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,
+                               h->a_prev_cen.p, mc, mp, d, k, pow2 ? 1.0 / k : 0.0, pow2, h->a_idx.p, h->a_dist.p, c_lo);
+        if (shard) {
+            h->comm.all_gather(h->a_idx.p + (size_t)rank * share, h->a_idx.p, (size_t)share * 4, h->stream);
+            h->comm.all_gather(h->a_dist.p + (size_t)rank * share, h->a_dist.p, (size_t)share * 8, h->stream);
+        }
         HIPCHK(hipMemcpyAsync(out_idx, h->a_idx.p, (size_t)mc * 4, hipMemcpyDeviceToHost, h->stream));
         if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, h->a_dist.p, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
         return (int)CC_OK;
     });
+}
+
+// ---- exact multi-GPU path: communicator set-up -------------------------------------------------------
+
+int cc_comm_unique_id(void* out_id)
+{
+    if (!out_id) return CC_ERR_BAD_ARG;
+    cc::RcclApi& api = cc::RcclApi::get();
+    if (!api.ok()) return CC_ERR_COMM;
+    ncclUniqueId id;
+    if (api.GetUniqueId(&id) != ncclSuccess) return CC_ERR_COMM;
+    static_assert(sizeof(id) == CC_COMM_ID_BYTES, "ncclUniqueId size");
+    memcpy(out_id, &id, sizeof(id));
+    return CC_OK;
+}
+
+int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world)
+{
+    if (!h || !id_bytes || world < 1 || rank < 0 || rank >= world) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        if (h->comm.active()) return fail(h, CC_ERR_BAD_ARG, "the handle already belongs to a group");
+        cc::RcclApi& api = cc::RcclApi::get();
+        if (!api.ok()) return fail(h, CC_ERR_COMM, std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "missing symbol"));
+        ncclUniqueId id;
+        memcpy(&id, id_bytes, sizeof(id));
+        ncclComm_t comm = nullptr;
+        const ncclResult_t r = api.CommInitRank(&comm, world, id, rank);  // (the handle's device is current)
+        if (r != ncclSuccess) return fail(h, CC_ERR_COMM, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
+        h->comm.nccl = comm;
+        h->comm.rank = rank;
+        h->comm.world = world;
+        return (int)CC_OK;
+    });
+}
+
+int cc_comm_init_local(cc_handle** handles, int world)
+{
+    if (!handles || world < 1) return CC_ERR_BAD_ARG;
+    for (int r = 0; r < world; ++r)
+        if (!handles[r] || handles[r]->comm.active()) return CC_ERR_BAD_ARG;
+    auto grp = std::make_shared<cc::LocalGroup>(world);
+    for (int r = 0; r < world; ++r) {
+        cc_handle* h = handles[r];
+        int rc = guarded(h, [&]() {
+            HIPCHK(hipEventCreateWithFlags(&h->comm.ev_ready, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&h->comm.ev_done, hipEventDisableTiming));
+            return (int)CC_OK;
+        });
+        if (rc != CC_OK) return rc;
+        h->comm.local = grp;
+        h->comm.rank = r;
+        h->comm.world = world;
+    }
+    return CC_OK;
+}
+
+int cc_comm_destroy(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream2);
+        h->comm.destroy();
+        return (int)CC_OK;
+    });
+}
+
+int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (rank) *rank = h->comm.rank;
+    if (world) *world = h->comm.world;
+    if (transport) *transport = h->comm.nccl ? 1 : (h->comm.local ? 2 : 0);
+    return CC_OK;
+}
+
+int cc_shard_rows(int32_t n, int32_t world, int32_t rank, int32_t unit, int32_t* lo, int32_t* hi)
+{
+    if (n < 0 || world < 1 || rank < 0 || rank >= world || unit < 1 || !lo || !hi) return CC_ERR_BAD_ARG;
+    int a = 0, b = 0;
+    cc_shard_range(n, world, rank, unit, &a, &b);
+    *lo = a;
+    *hi = b;
+    return CC_OK;
+}
+
+int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (min_row_dims >= 0) h->shard_min_row_dims = min_row_dims;
+    if (offline_min_rows >= 0) h->offline_shard_min_rows = offline_min_rows;
+    return CC_OK;
 }
 
 int cc_get_stats(cc_handle* h, cc_stats* out)

@@ -1,0 +1,171 @@
+// cc_comm.h — the exchange step of the exact multi-GPU path: every rank holds the whole
+// microcluster table, scans its own share of the table rows and all-gathers one 64-byte candidate record per
+// window point; everything after that runs replicated and bit-identically on every rank.
+//
+// Two transports behind one call:
+//   RCCL   one process per GPU; ncclAllGather over xGMI on the stream of the scan that produced the records.
+//          librccl is opened with dlopen when a communicator is first asked for, so single-GPU users of the
+//          library never load it (and the library has no link-time dependency on it).
+//   LOCAL  several handles of ONE process (one host thread each) that form a group: the same all-gather done
+//          with stream-ordered device copies between the handles' buffers.  This is how the sharded path is
+//          verified on a machine with a single GPU (two handles on GPU 0, each scanning half of the rows).
+// There is no reference counterpart: the reference is a single Python thread.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace cc {
+
+struct CommErr {
+    std::string what;
+};
+
+// ---- RCCL through dlopen ---------------------------------------------------------------------------------
+
+struct RcclApi {
+    void* dl = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+
+    static RcclApi& get()
+    {
+        static RcclApi api;
+        static std::once_flag once;
+        std::call_once(once, [&]() {
+            // the soname first: a copy that is already mapped (e.g. the one PyTorch ships) is reused
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) {
+                api.dl = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (api.dl) break;
+            }
+            if (!api.dl) return;
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.dl, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.dl, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.dl, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.dl, "ncclAllGather");
+            api.AllReduce = (decltype(api.AllReduce))dlsym(api.dl, "ncclAllReduce");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.dl, "ncclGetErrorString");
+        });
+        return api;
+    }
+    bool ok() const { return dl && GetUniqueId && CommInitRank && CommDestroy && AllGather && AllReduce && GetErrorString; }
+};
+
+// ---- in-process group ------------------------------------------------------------------------------------
+
+// One rendezvous object shared by the handles of a group.  A collective is two host barriers: after the first
+// every rank has published its send buffer and the event that marks it ready; after the second every rank has
+// enqueued its copies, so nobody overwrites a send buffer that a peer still has to read.
+struct LocalGroup {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    bool broken = false;
+    std::vector<const void*> send;
+    std::vector<hipEvent_t> ready, done;  // owned by the ranks that record them
+
+    explicit LocalGroup(int w) : world(w), send(w, nullptr), ready(w, nullptr), done(w, nullptr) {}
+
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) throw CommErr{"in-process group was abandoned by a member"};
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&]() { return generation != gen || broken; });
+            if (generation == gen) throw CommErr{"in-process group was abandoned by a member"};
+        }
+    }
+    void abandon()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
+struct Comm {
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    std::shared_ptr<LocalGroup> local;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;  // LOCAL: this rank's two events
+
+    bool active() const { return world > 1 || nccl != nullptr; }
+
+    void check(ncclResult_t r, const char* what)
+    {
+        if (r != ncclSuccess) throw CommErr{std::string(what) + ": " + RcclApi::get().GetErrorString(r)};
+    }
+
+    // recv[p * bytes .. (p + 1) * bytes) = rank p's send[0 .. bytes), for every p, ordered on `st`
+    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t st)
+    {
+        if (nccl) {
+            check(RcclApi::get().AllGather(send, recv, bytes, ncclInt8, nccl, st), "ncclAllGather");
+            return;
+        }
+        if (!local) {
+            if (recv != send && hipMemcpyAsync(recv, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess)
+                throw CommErr{"copy failed"};
+            return;
+        }
+        LocalGroup& g = *local;
+        auto chk = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess) {
+                g.abandon();
+                throw CommErr{std::string(what) + ": " + hipGetErrorString(e)};
+            }
+        };
+        chk(hipEventRecord(ev_ready, st), "hipEventRecord");
+        g.send[rank] = send;
+        g.ready[rank] = ev_ready;
+        g.done[rank] = ev_done;
+        g.barrier();
+        for (int p = 0; p < world; ++p) {
+            if (p != rank) chk(hipStreamWaitEvent(st, g.ready[p], 0), "hipStreamWaitEvent");
+            char* dst = (char*)recv + (size_t)p * bytes;
+            if ((const void*)dst != g.send[p])  // (in place: a rank's own block is already where it belongs)
+                chk(hipMemcpyAsync(dst, g.send[p], bytes, hipMemcpyDeviceToDevice, st), "hipMemcpyAsync");
+        }
+        chk(hipEventRecord(ev_done, st), "hipEventRecord");
+        g.barrier();
+        for (int p = 0; p < world; ++p)
+            if (p != rank) chk(hipStreamWaitEvent(st, g.done[p], 0), "hipStreamWaitEvent");
+        g.barrier();  // the events may be re-recorded only after every peer has enqueued its waits on them
+    }
+
+    void destroy()
+    {
+        if (nccl) {
+            (void)RcclApi::get().CommDestroy(nccl);
+            nccl = nullptr;
+        }
+        if (local) {
+            local->abandon();
+            local.reset();
+        }
+        if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
+        if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+        rank = 0;
+        world = 1;
+    }
+};
+
+}  // namespace cc

@@ -171,6 +171,24 @@ struct Ctl {
     long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
 };
 
+// Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole
+// units of `unit` rows (1: table rows of a snapshot scan, current pcores of the association argmin; 64: p rows of
+// the offline pair matrices = whole words of the adjacency bitmask).  Every rank gets the same share
+// ceil(units / world) * unit, so the blocks tile [0, n) in rank order and all-gathers have one block size.
+__host__ __device__ inline int cc_shard_share(int n, int world, int unit)
+{
+    const int units = (n + unit - 1) / unit;
+    return ((units + world - 1) / world) * unit;
+}
+__host__ __device__ inline void cc_shard_range(int n, int world, int rank, int unit, int* lo, int* hi)
+{
+    const int share = cc_shard_share(n, world, unit);
+    const long long a = (long long)rank * share;
+    *lo = (int)(a < n ? a : n);
+    const long long b = a + share;
+    *hi = (int)(b < n ? b : n);
+}
+
 __host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)
 {
     return ad < bd || (ad == bd && ak < bk);

@@ -123,14 +123,15 @@ __global__ void k_core_flags(PcoreView pv, int mp, int d, double eps_sq, double 
 // waves walks 16 values of p; ballot -> one word of the adjacency bitmask per (p, 64 q).
 // Euclidean distance = sqrt of the left-to-right sum of squares (the reference's np.linalg.norm is
 // platform-defined in the last ulp: nrm2 under numba, sqrt(dot) under numpy).
+// (p_base: first p row of this launch - on the multi-GPU path a rank takes a block of p rows)
 __global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
-                                                        unsigned long long* __restrict__ adj, int words)
+                                                        unsigned long long* __restrict__ adj, int words, int p_base)
 {
     extern __shared__ double s_tiles[];  // [64][d + 1] q rows, then [64][d + 1] p rows
     const int ld = d + 1;
     double* sq = s_tiles;
     double* sp = s_tiles + 64 * ld;
-    const int q0 = blockIdx.x * 64, p0 = blockIdx.y * 64;
+    const int q0 = blockIdx.x * 64, p0 = p_base + blockIdx.y * 64;
     for (int e = threadIdx.x; e < 64 * d; e += 256) {
         const int r = e / d, i = e - r * d;
         sq[r * ld + i] = (q0 + r < mp) ? cen[(size_t)(q0 + r) * d + i] : 0.0;
@@ -161,10 +162,10 @@ __global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict
 // the neighbours' centroids, summed in dict (= list) order.  Note `<= delta`, not delta^2 (predecon.py:213).
 __global__ void k_subspace_pref(const double* __restrict__ cen, const unsigned long long* __restrict__ adj,
                                 int words, int mp, int d, double delta, double k, double* __restrict__ wvec,
-                                int* __restrict__ nn)
+                                int* __restrict__ nn, int p_base, int p_end)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= mp * d) return;
+    const int e = p_base * d + blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p_end * d) return;
     const int p = e / d, c = e - p * d;
     const double cp = cen[e];
     double acc = 0.0;
@@ -199,9 +200,9 @@ __global__ void k_pdim(const double* __restrict__ wvec, int mp, int d, int* __re
 __global__ __launch_bounds__(64) void k_weighted_reach(const double* __restrict__ cen, const double* __restrict__ wvec,
                                                        const unsigned long long* __restrict__ adj,
                                                        unsigned long long* __restrict__ adjw, int words, int mp,
-                                                       int d, double eps_sq)
+                                                       int d, double eps_sq, int p_base)
 {
-    const int p = blockIdx.y;
+    const int p = p_base + blockIdx.y;
     const int q = blockIdx.x * 64 + threadIdx.x;
     const unsigned long long nb = adj[(size_t)p * words + blockIdx.x];
     bool in = false;
@@ -261,9 +262,9 @@ __global__ __launch_bounds__(64) void k_assoc_argmin(const double* __restrict__ 
                                                      const double* __restrict__ cur_pref,
                                                      const double* __restrict__ prev_cen, int mc, int mp, int d,
                                                      double k, double inv_k, int pow2, int* __restrict__ out_idx,
-                                                     double* __restrict__ out_dist)
+                                                     double* __restrict__ out_dist, int c_base)
 {
-    const int c = blockIdx.x;
+    const int c = c_base + blockIdx.x;
     if (c >= mc) return;
     const int lane = threadIdx.x;
     double best = __builtin_huge_val();

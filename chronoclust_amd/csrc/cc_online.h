@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
                                                              Cand* __restrict__ part, int round, int mode,
-                                                             size_t part_stride)
+                                                             size_t part_stride, int shard_rank, int shard_world)
 {
     constexpr int PT = 1;  // window points per lane (two measured 10 % slower on C2)
     if (DIRTY) CC_LATENCY_KERNEL();
@@ -237,12 +237,17 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
     const int sub = blockIdx.y * NW + wv;
     // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
     // (a carried row matters to every point up to the first one that targets its MC)
-    const int nrows = DIRTY ? (carried ? car_n : min(B, j0 + 64 * PT - 1)) : m_rows_scan;
+    // Exact multi-GPU path: the table is replicated, rank r of `shard_world` scans the rows
+    // [r * ceil(M / world), (r + 1) * ceil(M / world)) of the snapshot and the ranks exchange their per-point
+    // candidates afterwards (k_merge_partials + all-gather); shard_world == 1: the whole table.
+    int row_lo = 0, row_hi = DIRTY ? (carried ? car_n : min(B, j0 + 64 * PT - 1)) : m_rows_scan;
+    if (!DIRTY && shard_world > 1) cc_shard_range(m_rows_scan, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int nrows = row_hi - row_lo;
     // dirty scan: sub-ranges are whole 16-row tiles so that the per-tile displacement maxima line up
     const int per = DIRTY ? (((nrows + nsub - 1) / nsub + CC_SCAN_TM - 1) / CC_SCAN_TM) * CC_SCAN_TM
                           : (nrows + nsub - 1) / nsub;
-    const int r0 = sub * per;
-    const int r1 = min(nrows, r0 + per);
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
     const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
     const size_t n_pts = (size_t)ctl->n_points;
     const Par par = cc_load_par(ctl);
@@ -705,6 +710,44 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
 }
 
 // ---------------------------------------------------------------------------------
+// k_merge_partials (exact multi-GPU path): the S partials a rank's snapshot scan left per window point -> ONE record
+// of four candidates per point, the unit the ranks all-gather (64 B per point instead of S x 64 B).  Candidates are
+// totally ordered by (distance, list-order key), so the best two of a union do not depend on the merge order and
+// every rank derives the same lists from the gathered records.  One thread per point; `round` / `mode` select the
+// window exactly as in k_scan.  Always recomputed from the scan's partials (idempotent), also when the in-place scan
+// it follows found that the window had been scanned ahead.
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ ctl, const Cand* __restrict__ part,
+                                                        size_t part_stride, int S, Cand* __restrict__ out,
+                                                        size_t out_stride, int round, int mode)
+{
+    int B, q;
+    if (mode == 1) {
+        q = round & 1;
+        B = ctl->la_b[q];
+    } else {
+        q = (int)(ctl->window_seq & 1ull);
+        B = ctl->win_b;
+    }
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    part += (size_t)q * part_stride;
+    out += (size_t)q * out_stride;
+    const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
+    Cand p1 = none, p2 = none, o1 = none, o2 = none;
+    for (int s = 0; s < S; ++s) {
+        const Cand* c = part + ((size_t)j * S + s) * 4;
+        cc_top2_push(p1, p2, c[0]);
+        cc_top2_push(p1, p2, c[1]);
+        cc_top2_push(o1, o2, c[2]);
+        cc_top2_push(o1, o2, c[3]);
+    }
+    Cand* o = out + (size_t)j * 4;
+    o[0] = p1; o[1] = p2; o[2] = o1; o[3] = o2;
+}
+
+// ---------------------------------------------------------------------------------
 // 32-lane groups: one group per window point in k_decide / k_chain.  Lane l owns dimensions l and l + 32
 // (d <= 64); sums over dimensions stay strictly left to right through an ordered shuffle loop.
 // ---------------------------------------------------------------------------------
@@ -1123,7 +1166,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const Cand* __restrict__ dseed,
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
-                                                int scan_rows)
+                                                int scan_rows, int part_inner, size_t part_outer)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1142,8 +1185,11 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const bool la_mode = ctl->mode != 0;
     if (round == 0) {
         part += (size_t)(wseq & 1ull) * part_stride;  // the snapshot scan of this window wrote the copy of its parity
+        // partial s of point j: one launch wrote S partials per point (part_inner = S, part_outer unused); on the
+        // exact multi-GPU path every rank contributed one merged record (part_inner = 1, part_outer = the distance
+        // between the ranks' blocks in the gathered buffer)
         for (int s = gl; s < S; s += 32) {
-            const Cand* q = part + ((size_t)j * S + s) * 4;
+            const Cand* q = part + (size_t)(s / part_inner) * part_outer + ((size_t)j * part_inner + (s % part_inner)) * 4;
             cc_top2_push(p1, p2, q[0]);
             cc_top2_push(p1, p2, q[1]);
             cc_top2_push(o1, o2, q[2]);

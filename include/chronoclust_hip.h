@@ -48,7 +48,8 @@ enum cc_status {
     CC_ERR_BAD_ARG = -2,     /* null pointer, d mismatch, d > CC_MAX_DIM ... */
     CC_ERR_NONFINITE = -3,   /* NaN/Inf in the input points                  */
     CC_ERR_OOM = -4,
-    CC_ERR_INTERNAL = -5
+    CC_ERR_INTERNAL = -5,
+    CC_ERR_COMM = -6         /* RCCL / in-process exchange between ranks failed */
 };
 
 enum cc_kind { CC_PCORE = 0, CC_OUTLIER = 1 };
@@ -95,7 +96,10 @@ typedef struct cc_stats {
     int64_t rows;            /* microcluster rows in the table after the run     */
     int64_t table_rows_scanned; /* sum over windows of the table rows a scan read  */
     int64_t lookahead_windows; /* windows whose snapshot scan ran ahead             */
-    int64_t reserved[5];
+    int64_t sharded_windows; /* windows whose snapshot scan was split over the ranks (multi-GPU) */
+    int64_t comm_launches;   /* merge + all-gather steps timed (time_kernels = 1)  */
+    double  comm_ms;         /* sum of their HIP-event durations                  */
+    int64_t reserved[2];
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -188,6 +192,36 @@ int cc_points_download(cc_handle* h, double* out, const double* scale, const dou
  * sum_d (prev - cur)^2 / cur_pref; strict <, first minimum wins. */
 int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref, int32_t mc,
                     const double* prev_cen, int32_t mp, int32_t d, int32_t* out_idx, double* out_dist);
+
+/* Exact multi-GPU path for ONE event stream (the reference is a single Python thread and
+ * has no counterpart).  `world` handles - one per GPU, each in its own process (RCCL) or, for verification on a
+ * single GPU, several in one process with one host thread each (local) - hold the same state and receive the same
+ * calls with the same arguments.  From then on cc_online_run, cc_offline and cc_assoc_argmin are collective:
+ *   - the snapshot scan of a window (the loop of hddstream.py:311-328 / :371-375 over the microclusters) is
+ *     split by table rows; the ranks all-gather one 64-byte candidate record per window point and every rank
+ *     validates and commits the window redundantly and deterministically, so all ranks end with bit-identical
+ *     tables, labels and clusters - identical to what one GPU computes;
+ *   - the pair matrices of the offline phase (predecon.py:161-188, :219-239) and of the association tracker
+ *     (cluster_tracker.py:127-141) are split by rows and all-gathered.
+ * Small tables are not split (cc_set_shard_thresholds): below ~1 ms of scan per window the exchange costs more
+ * than it saves.
+ *   cc_comm_unique_id  : rank 0 obtains the 128-byte RCCL id and hands it to the other ranks (any channel)
+ *   cc_comm_init_rccl  : joins the communicator (collective; librccl is loaded here, not before)
+ *   cc_comm_init_local : the in-process group of handles[0..world)
+ *   cc_comm_info       : transport 0 none, 1 RCCL, 2 local */
+#define CC_COMM_ID_BYTES 128
+int cc_comm_unique_id(void* out_id);
+int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world);
+int cc_comm_init_local(cc_handle** handles, int world);
+int cc_comm_destroy(cc_handle* h);
+int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport);
+/* The block [lo, hi) of n rows rank `rank` of `world` takes, in whole units of `unit` rows: the partition every
+ * kernel of the multi-GPU path uses (unit 1: table rows of a scan, current pcores of the association argmin;
+ * 64: rows of the offline pair matrices).  Pure host arithmetic, needs no handle and no GPU. */
+int cc_shard_rows(int32_t n, int32_t world, int32_t rank, int32_t unit, int32_t* lo, int32_t* hi);
+/* split the scan when rows * d >= min_row_dims, the offline / association pair matrices when rows >=
+ * offline_min_rows; a negative value keeps the current setting (defaults 400 000 and 8 192) */
+int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows);
 
 int cc_get_stats(cc_handle* h, cc_stats* out);
 

@@ -18,14 +18,14 @@ class _RecordingHandle(object):
         return idx, dist
 
 
-def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None):
+def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None, stream=None):
     """Returns one dict per timepoint: labels_uid, pcore / outlier tables, `rows` = what write_result_file would
     write per cluster (weight, pcore ids, preferred dimensions, lineage id, association string; app.py:229-260),
     merge-ordered members of every cluster, and the recorded association argmin calls."""
     from chronoclust_amd.clustering.hddstream import HDDStream
     from chronoclust_amd.objects.cluster import Cluster
     from chronoclust_amd.tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
-    h = HDDStream(cfg, device=device, tuning=tuning)
+    h = stream if stream is not None else HDDStream(cfg, device=device, tuning=tuning)  # (a member of a group)
     assoc_log = []
     lineage = TrackByLineage()
     assoc = TrackByHistoricalAssociation(handle=_RecordingHandle(h._h, assoc_log))

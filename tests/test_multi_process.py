@@ -56,3 +56,37 @@ def test_single_process_defaults():
         os.environ.pop(k, None)
     assert multi.rank_info() == (0, 1, 0)
     assert multi.max_over_ranks(1.5, None) == 1.5
+
+
+def _partition_worker(rank, world, port, out):
+    """Each rank asks the library for ITS block of the three partitions of the exact multi-GPU path (cc_shard_rows:
+    the arithmetic k_scan, cc_offline and cc_assoc_argmin use) and the ranks exchange them over gloo."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        from chronoclust_amd import _lib
+        cases = [(n, unit) for unit in (1, 64) for n in (0, 1, 2, 63, 64, 65, 1000, 5000, 50_000, 123_457)]
+        mine = torch.tensor([_lib.shard_rows(n, world, rank, unit) for n, unit in cases], dtype=torch.int64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        for i, (n, unit) in enumerate(cases):
+            blocks = [tuple(int(v) for v in g[i]) for g in gathered]
+            # the blocks tile [0, n) in rank order, every block but the last non-empty one is a whole share
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+            share = max(hi - lo for lo, hi in blocks)
+            assert share % unit == 0 or share == n
+            assert all(hi - lo == share for lo, hi in blocks if hi < n)
+        out[rank] = [tuple(int(v) for v in mine[6])]  # n = 1000, unit 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_partition_arithmetic_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_partition_worker, args=(world, port, out), nprocs=world, join=True)
+        assert out[0] == [(0, 500)] and out[1] == [(500, 1000)]

@@ -1,0 +1,134 @@
+"""The exact multi-GPU path verified on ONE GPU: `world` handles in one process form an
+in-process group (cc_comm_init_local), each driven by its own host thread.  Every rank scans only its share of the
+table rows, the ranks all-gather one candidate record per window point, and the offline / association pair
+matrices are split by rows.  The claim under test: every rank ends with the results one GPU computes alone - bit for
+bit (labels, tables, id counters, merge-ordered clusters, lineage and association strings) - and therefore with the
+oracle's.  The RCCL transport is the same code path with ncclAllGather as the exchange; here it is exercised with a
+communicator of one rank (all a single-GPU machine allows)."""
+import threading
+
+import numpy as np
+import pytest
+
+import pipeline_util as P
+import scenarios
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
+
+
+def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0):
+    """The pipeline of app.run on `world` replicas of one stream, one thread per rank.  Returns the per-timepoint
+    results of every rank."""
+    from chronoclust_amd import _lib
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    streams = [HDDStream(cfg, tuning=tuning) for _ in range(world)]
+    _lib.comm_init_local([s._h for s in streams])
+    for r, s in enumerate(streams):
+        s._h.set_shard_thresholds(min_row_dims, offline_min_rows)
+        assert s._h.comm_info() == dict(rank=r, world=world, transport="local")
+    results, errors = [None] * world, [None] * world
+
+    def work(rank):
+        try:
+            results[rank] = P.run_pipeline(Xs, cfg, stream=streams[rank])
+        except BaseException as e:  # noqa: BLE001 - reported after the join
+            errors[rank] = e
+            try:
+                streams[rank]._h.comm_destroy()  # the peers must not wait for this rank
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["d40", "d14_filter", "d20"])
+def test_golden_scenarios_sharded_equal_single_and_reference(name, world, golden_dir):
+    """Oracle-sized scenarios with every split forced on from the first window (thresholds 0): the ranks reproduce
+    the single-GPU results, which the other parity tests pin to the Python reference's dumps."""
+    sc = scenarios.BLOB_SCENARIOS[name]
+    cfg = scenarios.params_to_config(sc["params"])
+    Xs = scenarios.make_blob_timepoints(sc)
+    single = P.run_pipeline(Xs, cfg)
+    for tuning in (None, dict(window=512, segments=8, lookahead=3), dict(window=2048, lookahead=2)):
+        for res in run_group(world, Xs, cfg, tuning=tuning):
+            P.same_results(res, single)
+            assert all(r["stats"]["sharded_windows"] == r["stats"]["windows"] for r in res)
+    rec = np.load("%s/blob_%s.npz" % (golden_dir, name))
+    for t, r in enumerate(single):
+        assert np.array_equal(r["labels_uid"], rec["t%d_labels_uid" % t])
+
+
+def test_sharded_matches_oracle_with_churn():
+    from oracle import oracle as O
+    sc = dict(seed=9, n=30_000, d=20, g=900, sigma=0.01, timepoints=3, drift=0.01, churn=0.08)
+    cfg = scenarios.params_to_config(scenarios.blob_params(sc["n"], param_omicron=0.00007, param_lambda=2))
+    Xs = scenarios.make_blob_timepoints(sc, raw=True)
+    res = run_group(2, Xs, cfg)
+    o = O.OracleHDDStream(cfg)
+    for t, X in enumerate(Xs):
+        o.online_microcluster_maintenance(X, t)
+        for rank in range(2):
+            r = res[rank][t]
+            assert np.array_equal(r["labels_uid"], o.labels_uid)
+            assert r["counters"] == o.counters
+            for kind, name in ((0, "pcore"), (1, "outlier")):
+                b = o.table(kind)
+                for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+                    assert np.array_equal(r[name][key], b[key]), (t, rank, kind, key)
+            assert r["members"] == [[int(x) for x in c["members"]] for c in o.clusters]
+
+
+def test_split_switches_on_while_the_table_grows():
+    """Default-style threshold: the first windows run unsplit (small table), later ones split - the lookahead chain is
+    restarted at the switch.  600 k x 20 with 25 000 blobs crosses rows * d = 400 000 while microclusters are created."""
+    n, d, g = 600_000, 20, 25_000
+    X = scenarios.make_blobs(7, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    single = P.run_pipeline([X], cfg)
+    res = run_group(2, [X], cfg, min_row_dims=400_000, offline_min_rows=8192)
+    for r in res:
+        P.same_results(r, single)
+        st = r[0]["stats"]
+        assert 0 < st["sharded_windows"] < st["windows"]
+
+
+def test_c5_shaped_sharded_equals_single():
+    """2 M x 40 with 50 000 microclusters (the stress config's table on one GPU's share of its points), two ranks
+    with the default thresholds: scan split once the table holds 10 000 rows, offline pair matrices split."""
+    n, d, g = 2_000_000, 40, 50_000
+    X = scenarios.make_blobs(42, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    single = P.run_pipeline([X], cfg)
+    res = run_group(2, [X], cfg, min_row_dims=-1, offline_min_rows=-1)
+    for r in res:
+        P.same_results(r, single)
+        assert r[0]["stats"]["sharded_windows"] > 0
+
+
+def test_rccl_transport_with_one_rank():
+    """ncclCommInitRank / ncclAllGather through the dlopen'ed librccl, communicator of one rank: the calls the
+    multi-process path makes, on the streams it makes them on (scan forced through merge + all-gather)."""
+    from chronoclust_amd import _lib
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    sc = scenarios.BLOB_SCENARIOS["d20"]
+    cfg = scenarios.params_to_config(sc["params"])
+    Xs = scenarios.make_blob_timepoints(sc)
+    single = P.run_pipeline(Xs, cfg)
+    h = HDDStream(cfg)
+    h._h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)
+    assert h._h.comm_info() == dict(rank=0, world=1, transport="rccl")
+    h._h.set_shard_thresholds(0, 0)  # every scan, offline phase and association argmin goes through the exchange
+    res = P.run_pipeline(Xs, cfg, stream=h)
+    P.same_results(res, single)
+    assert all(r["stats"]["sharded_windows"] == r["stats"]["windows"] > 0 for r in res)
+    h._h.comm_destroy()
+    assert h._h.comm_info()["transport"] == "none"
