@@ -3,9 +3,13 @@
 
 A step = one timepoint of the hot path over one batch of synthetic input that is already resident in HBM:
 reset to an empty HDDStream, the exact per-point online phase over N points (cc_online_run) and the offline
-PreDeCon phase (cc_offline).  Workload at N GPUs = N independent event streams of the same shape, one per
-rank ("replicas only": the online phase is a sequential chain over points and does not shard exactly, see
-DESIGN.md), so scaling is weak and there is no data-path collective.
+PreDeCon phase (cc_offline) with the export of all clusters.
+
+At N GPUs the headline `value` is N independent event streams of the C2 shape, one per rank (weak scaling, no
+data-path collective: the online phase of one stream is a sequential chain over its points).  The same JSON line
+also carries `one_stream_exact`: ONE stream of the stress config's shape (d = 40, 50 000 microclusters) clustered by
+all N GPUs together - snapshot scans split by table rows, one RCCL all-gather of 64 B per window point, offline pair
+matrices split by rows - with a check that every rank ended with the same bytes.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -13,9 +17,11 @@ DESIGN.md), so scaling is weak and there is no data-path collective.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -24,7 +30,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2; this path has no FMA
+FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def make_blobs(seed, n, d, g, sigma=0.01):
@@ -50,6 +57,121 @@ def set_params(h, cfg, n, d):
                  cfg["omicron"] * 0, ups, ups ** 2, delta, pi)
 
 
+def cpu_baseline(cfg, X, sample, cores, gpu_uid):
+    """The oracle (oracle/chrono_oracle.c, a scalar C port of the reference's loop) on a prefix of the same stream:
+    one thread, then one independent copy of the same work on every host core (the algorithm is a sequential chain,
+    so cores can only be used by independent streams - as the GPU replicas do)."""
+    from oracle import oracle as O
+    m = min(sample, X.shape[0])
+    o = O.OracleHDDStream(cfg)
+    o.set_dataset_dependent_parameters(X)  # thresholds of the full timepoint (mu = mu_cfg * N), like the GPU run
+    t1 = time.perf_counter()
+    o.online_microcluster_maintenance(X[:m], 0, reset_param=False, offline=False)
+    one = time.perf_counter() - t1
+    rows = o.table(O.PCORE)["id"].shape[0] + o.table(O.OUTLIER)["id"].shape[0]
+    out = {"value": m / one, "unit": "points/s", "cores": 1, "kind": "port",
+           "sample": "first %d points of the same stream (microclusters grow 0 -> %d), online phase only, "
+                     "oracle/chrono_oracle.c single thread" % (m, rows),
+           "labels_match_gpu_prefix": None if gpu_uid is None else bool(np.array_equal(o.labels_uid, gpu_uid[:m]))}
+    if cores > 1:
+        workers = [O.OracleHDDStream(cfg) for _ in range(cores)]
+        for w in workers:
+            w.set_dataset_dependent_parameters(X)
+        threads = [threading.Thread(target=w.online_microcluster_maintenance, args=(X[:m], 0),
+                                    kwargs=dict(reset_param=False, offline=False)) for w in workers]
+        t2 = time.perf_counter()
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        allc = time.perf_counter() - t2
+        out["all_cores"] = {"value": cores * m / allc, "unit": "points/s", "cores": cores,
+                            "note": "%d independent copies of the same sample, one thread per usable host core, "
+                                    "ctypes threads; the sequential chain of one stream cannot use more than one "
+                                    "core" % cores}
+    # the Python reference itself, measured in the build container (1 core, d = 20, 100 - 400 microclusters;
+    # BASELINE.md section 2): it cannot be imported on the GPU box
+    out["reference_py"] = {"value": [209, 571], "unit": "points/s", "cores": 1,
+                           "note": "ghar1821/Chronoclust (no-op numba stand-in), N = 10 k, d = 20, M = 400 / 100, "
+                                   "committed measurement, not re-run here"}
+    return out
+
+
+def digest_of(h):
+    """Bytes that pin the state a run ended in: labels, both tables, id counters."""
+    from chronoclust_amd import _lib
+    m = hashlib.sha256()
+    uid, path = h.labels_download()
+    m.update(uid.tobytes())
+    m.update(path.tobytes())
+    for kind in (_lib.PCORE, _lib.OUTLIER):
+        t = h.export(kind)
+        for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+            m.update(np.ascontiguousarray(t[key]).tobytes())
+    m.update(repr(h.counters()).encode())
+    return m.hexdigest()
+
+
+def one_stream_exact(args, rank, world, local_rank, dist, sync):
+    """ONE stream on all ranks (exact multi-GPU path).  Every rank generates the same input."""
+    from chronoclust_amd import _lib, multi
+    n, d, g = args.stream_points, args.stream_dim, args.stream_blobs
+    X = make_blobs(4242, n, d, g)
+    cfg = blob_config(n)
+    h = _lib.Handle(local_rank)
+    h.set_tuning(time_kernels=1)
+    if world > 1:
+        multi.join_stream_group(h, dist)
+    set_params(h, cfg, n, d)
+    h.points_upload(X)
+    del X
+
+    def step():
+        h.reset()
+        h.online_run()
+        s = h.stats()
+        arrays, _ = h.offline_arrays()
+        return s, len(arrays[2])
+
+    for _ in range(args.stream_warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0)
+    for _ in range(args.stream_steps):
+        s, n_clusters = step()
+        for k in acc:
+            acc[k] += s[k]
+    sync()
+    elapsed = time.perf_counter() - t0
+    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    dg = digest_of(h)
+    agree = multi.all_ranks_equal(dg, dist) if world > 1 else True
+    info = h.comm_info()
+    if world > 1:
+        h.comm_destroy()
+    h.close()
+    secs = acc["scan_ms"] * 1e-3
+    return {
+        "workload": "C5-shaped: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters, exact sequential "
+                    "semantics; online + offline phases per step; every rank holds the table and the points, "
+                    "scans 1/%d of the table rows per window" % (n, d, g, world),
+        "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
+        "n_gpus": world, "steps": args.stream_steps, "warmup": args.stream_warmup,
+        "ms_per_step": 1e3 * elapsed / args.stream_steps,
+        "collective": "none (one rank)" if world == 1 else "%s all-gather of 64 B per window point, %d per step; "
+                      "offline: all-gather of preference vectors + reachability bitmask" % (
+                          info["transport"], int(acc["comm_launches"] / args.stream_steps)),
+        "microclusters": int(s["rows"]), "clusters": n_clusters, "windows_per_step": int(s["windows"]),
+        "sharded_windows_per_step": int(s["sharded_windows"]),
+        "rank0_online_ms_per_step": acc["run_ms"] / args.stream_steps,
+        "rank0_scan_ms_per_step": acc["scan_ms"] / args.stream_steps,
+        "rank0_exchange_ms_per_step": acc["comm_ms"] / args.stream_steps,
+        "rank0_scan_fp64_valu_frac": (3.0 * acc["scan_pair_dims"] / secs / 1e12 / FP64_VALU_PEAK_TOPS) if secs else None,
+        "all_ranks_bit_identical": bool(agree), "state_sha256": dg[:16],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,10 +185,19 @@ def main():
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--lookahead", type=int, default=0, help="0/1 on (default), 2 off, 3 forced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=150_000)
+    ap.add_argument("--cpu-sample", type=int, default=100_000)
+    ap.add_argument("--cpu-cores", type=int, default=16, help="threads of the all-cores CPU column (at most the usable cores)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
+    ap.add_argument("--no-one-stream", action="store_true", help="skip the one-stream-on-all-GPUs leg")
+    ap.add_argument("--stream-points", type=int, default=2_000_000)
+    ap.add_argument("--stream-dim", type=int, default=40)
+    ap.add_argument("--stream-blobs", type=int, default=50_000)
+    ap.add_argument("--stream-steps", type=int, default=2)
+    ap.add_argument("--stream-warmup", type=int, default=1)
+    ap.add_argument("--stream-timeout", type=float, default=240.0,
+                    help="seconds after which a one-stream leg that has not finished is abandoned")
     args = ap.parse_args()
 
     from chronoclust_amd import multi
@@ -125,87 +256,98 @@ def main():
     elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
     uid, _ = h.labels_download()
 
-    if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "points clustered/sec (20-dim)" if d == 20 else "points clustered/sec (%d-dim)" % d,
+            "value": multi.whole_job_rate(n, args.steps, world, elapsed),
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C2: 1 timepoint, %dx%d synthetic blobs (seed 42+rank), %d microclusters; "
+                                   "exact sequential semantics; online + offline phases per step; one independent "
+                                   "stream per GPU" % (n, d, g),
+                       "points": n, "dim": d, "microclusters": int(s["rows"]), "clusters": n_clusters,
+                       "streams": world, "window": args.window or 24576, "windows_per_step": int(s["windows"]),
+                       "lookahead_windows_per_step": int(s["lookahead_windows"]),
+                       "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
+            "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,
+        }
+        if scan_launches:
+            # The dominant kernel is bound by fp64 VALU issue, not by HBM (intensity ~1.5 M flop/B): per
+            # (point, microcluster, dim) the reference does sub, mul, div-by-pref, add; k = 4 is a power of two, so
+            # the kernel issues 3 fp64 instructions for them (v_add, v_mul, v_fma - one rounding of x2 * 2^e + acc is
+            # the same double, guarded against subnormal products).  achieved = those instruction-lanes per second
+            # over ALL timed launches of the kernel (short start-up windows and co-running lookahead scans
+            # included); the best-two update per (point, microcluster) is overhead and not counted.
+            n_pts = n * args.steps
+            alg_bytes = n_pts * (8 * d + 4) + table_rows * (16 * d + 8)
+            secs = scan_ms * 1e-3
+            hbm = alg_bytes / secs / 1e9
+            issued = 3.0 * pair_dims / secs / 1e12
+            out["roofline"] = {
+                "bound": "fp64_valu", "kernel": "k_scan<DIRTY=false>", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
+                "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
+                "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
+                "instr_per_pair_dim": 3.0, "pair_dims_per_launch": pair_dims / scan_launches,
+                "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
+                        "note": "algorithmic bytes: the window's points (8d + 4 label bytes each) + the table columns "
+                                "the distance reads (16d + 8 bytes per row); this roof does not bind"},
+                "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead scans "
+                               "(second stream, beside the validation kernels of the previous window, including the "
+                               "few that go unused) and in-place scans (short windows of the start-up phase included)"}
+            # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
+            # separate runs); only quoted when it was measured on this workload shape
+            try:
+                with open(PMC_TRAFFIC_FILE) as f:
+                    pmc = json.load(f)
+                if (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
+                    out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = pmc["note"]
+            except (OSError, KeyError, ValueError):
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            # (the GPU box gives a one-GPU job 16 of the host's cores; os.cpu_count() reports the whole machine)
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(cfg, X, args.cpu_sample, max(1, min(usable, args.cpu_cores)), uid)
+            out["cpu_baseline"]["host_cpu_count"] = os.cpu_count()
+    h.close()
+    del X
 
-    out = {
-        "metric": "points clustered/sec (20-dim)" if d == 20 else "points clustered/sec (%d-dim)" % d,
-        "value": multi.whole_job_rate(n, args.steps, world, elapsed),
-        "unit": "points/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "C2: 1 timepoint, %dx%d synthetic blobs (seed 42+rank), %d microclusters; "
-                               "exact sequential semantics; online + offline phases per step" % (n, d, g),
-                   "points": n, "dim": d, "microclusters": int(s["rows"]), "clusters": n_clusters,
-                   "streams": world, "window": args.window or 24576, "windows_per_step": int(s["windows"]),
-                   "lookahead_windows_per_step": int(s["lookahead_windows"]),
-                   "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
-        "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,
-    }
-    if scan_launches:
-        # algorithmic traffic of one k_scan launch: its window's points (8d read + 4 label bytes per point,
-        # SURVEY 8d) + the table columns the distance needs (centroid, pref: 16d + kind, key: 8 bytes per row)
-        n_pts = n * args.steps
-        alg_bytes = n_pts * (8 * d + 4) + table_rows * (16 * d + 8)
-        secs = scan_ms * 1e-3
-        achieved = alg_bytes / secs / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "k_scan<DIRTY=false>", "achieved": achieved,
-                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
-                           "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
-                           "fp64_valu": {"algorithmic_top_s": 4.0 * pair_dims / secs / 1e12,
-                                         "instr_per_pair_dim": 3.0,
-                                         "issued_top_s": 3.0 * pair_dims / secs / 1e12,
-                                         "peak_top_s": FP64_VALU_PEAK_TOPS,
-                                         "frac": 3.0 * pair_dims / secs / 1e12 / FP64_VALU_PEAK_TOPS,
-                                         "note": "per (point, microcluster, dim) the reference does sub, mul, div-by-pref, "
-                                                 "add (4 flops, left to right); k = 4 is a power of two, so the kernel "
-                                                 "issues 3 fp64 instructions for them (v_add, v_mul, v_fma: one rounding "
-                                                 "of x2 * 2^e + acc is the same double, guarded against subnormal "
-                                                 "products); frac = those instructions / the 39.3 T fp64 VALU "
-                                                 "instruction-lanes per second of the chip at 2.4 GHz, over ALL timed "
-                                                 "launches (short start-up windows, co-running lookahead scans); the "
-                                                 "11-instruction best-two update per (point, microcluster) is not "
-                                                 "counted.  PMC (SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE) for a full "
-                                                 "24 576-point launch running alone: DESIGN.md section 8"},
-                           "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead "
-                                          "scans (second stream, beside the validation kernels of the previous window, "
-                                          "including the few that go unused) and in-place scans (short windows of the "
-                                          "start-up phase included)"}
-    if "roofline" in out:
-        # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
-        # separate runs, profiles/r01_pmc_traffic.json); only quoted when it was measured on this workload shape
+    if not args.no_one_stream:
+        # A collective that never completes must not take the headline measurement with it: every rank arms a
+        # timer; if the leg is still running when it fires, rank 0 prints the line without it and all ranks leave.
+        done = threading.Event()
+
+        def abandon():
+            if done.is_set():
+                return
+            if rank == 0:
+                out["one_stream_exact"] = {"error": "not finished after %.0f s, abandoned" % args.stream_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(args.stream_timeout, abandon)
+        timer.daemon = True
+        timer.start()
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            if (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
-                out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = pmc["note"]
-        except (OSError, KeyError, ValueError):
-            pass
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        m = min(args.cpu_sample, n)
-        o = O.OracleHDDStream(cfg)
-        t1 = time.perf_counter()
-        o.online_microcluster_maintenance(X[:m], 0, offline=False)
-        # the sample runs with the full workload's thresholds (mu = mu_cfg * N), like the GPU run
-        cpu_s = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": m / cpu_s, "unit": "points/s", "cores": 1, "kind": "port",
-                               "sample": "first %d points of the same stream (microclusters grow 0 -> %d), "
-                                         "online phase only, oracle/chrono_oracle.c single thread" % (
-                                             m, o.table(O.PCORE)["id"].shape[0] + o.table(O.OUTLIER)["id"].shape[0])}
-        out["cpu_baseline"]["labels_match_gpu_prefix"] = bool(np.array_equal(o.labels_uid, uid[:m]))
-    print(json.dumps(out))
+            leg = one_stream_exact(args, rank, world, local_rank, dist, sync)
+        except Exception as e:  # noqa: BLE001 - reported in the line
+            leg = {"error": "%s: %s" % (type(e).__name__, e)}
+        done.set()
+        timer.cancel()
+        if rank == 0:
+            out["one_stream_exact"] = leg
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -1,8 +1,16 @@
-"""Multi-GPU layout of the hot path: replicas only.
+"""Multi-GPU layouts of the hot path.  One process per GPU in both.
 
-The online phase is one sequential chain over the points of a timepoint, so events of one stream are never
-sharded; N GPUs process N independent event streams (samples), one per rank, with no data-path collective.
-`torch.distributed` is used by bench.py only for the barrier and the max-over-ranks time."""
+1. Independent streams ("replicas"): N GPUs cluster N event streams (samples, patients), one per rank, with no
+   data-path collective.  The online phase of ONE stream is a sequential chain over its points
+   (hddstream.py:220-237), so events of a stream are never sharded.
+2. One stream on N GPUs, exact: every rank holds the whole microcluster table and
+   receives the same calls; the snapshot scan of a window is split by table rows and the ranks all-gather one
+   candidate record per window point over RCCL (cc_comm_init_rccl), the offline and association pair matrices
+   are split by rows.  All ranks end with bit-identical results.  `join_stream_group` sets this up.
+
+`torch.distributed` is plumbing here: the barrier / max-over-ranks time of bench.py and the channel that carries
+the 128-byte RCCL id from rank 0 to the other ranks.  The collectives of the data path are RCCL calls made by
+the C-ABI library on its own HIP streams."""
 import os
 
 
@@ -12,7 +20,7 @@ def rank_info():
 
 
 def stream_seed(base_seed, rank):
-    """Every rank clusters its own synthetic stream (same shape, different seed)."""
+    """Layout 1: every rank clusters its own synthetic stream (same shape, different seed)."""
     return int(base_seed) + int(rank)
 
 
@@ -27,5 +35,34 @@ def max_over_ranks(value, dist=None, device=None):
 
 
 def whole_job_rate(points_per_rank, steps, world, seconds):
-    """value of bench.py: units all ranks processed / max-over-ranks time."""
+    """value of bench.py, layout 1: units all ranks processed / max-over-ranks time."""
     return world * points_per_rank * steps / seconds
+
+
+def one_stream_rate(points, steps, seconds):
+    """Layout 2: the ranks share ONE stream, so the job processed `points` per step whatever the rank count."""
+    return points * steps / seconds
+
+
+def broadcast_bytes(payload, dist, src=0):
+    """`payload` (bytes on rank `src`, ignored elsewhere) to every rank, through torch.distributed."""
+    box = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def join_stream_group(handle, dist):
+    """Layout 2: makes `handle` (a chronoclust_amd._lib.Handle on this rank's GPU) a member of the RCCL group of
+    all ranks of `dist`.  Collective.  Afterwards online_run / offline / assoc_argmin are collective calls."""
+    from . import _lib
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = broadcast_bytes(_lib.comm_unique_id() if rank == 0 else None, dist)
+    handle.comm_init_rccl(uid, rank, world)
+    return rank, world
+
+
+def all_ranks_equal(digest, dist):
+    """True when every rank passes the same bytes (e.g. a hash of its labels and tables)."""
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, digest)
+    return all(b == box[0] for b in box)
