@@ -10,13 +10,11 @@ import csv
 import logging
 import os
 from collections import defaultdict
-from decimal import ROUND_HALF_UP, Decimal
 
 import numpy as np
 import pandas as pd
 
 from .clustering.hddstream import HDDStream
-from .objects.cluster import Cluster
 from .scaling.scaler import Scaler, read_timepoint
 from .tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
 
@@ -90,14 +88,9 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
             hddstream.online_microcluster_maintenance(raw, timepoint, device_scaling=(scaler.scale_, scaler.min_))
         else:
             hddstream.online_microcluster_maintenance(raw, timepoint)
-        pcore_by_id = {mc.id[0]: mc for mc in hddstream.pcore_MC}
-
-        for found in hddstream.final_clusters:
-            # one decimal place, half up, through the float's shortest repr (app.py:184)
-            rounded_weight = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)
-            cluster = Cluster(list(found.id), found.cluster_centroids, rounded_weight,
-                              found.preferred_dimension_vector)
-            cluster.add_pcore_objects(pcore_by_id)
+        # app.py:179-190: one Cluster record per final cluster (weight to one decimal place, half up, through the
+        # float's shortest repr; member pcores attached), built from the exported arrays
+        for cluster in hddstream.cluster_records():
             tracker_by_lineage.add_new_child_cluster(cluster)
 
         tracker_by_lineage.calculate_ids()
@@ -153,8 +146,8 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, clust
     uid_of_pcore = {int(i): int(u) for i, u in zip(pcore["id"], pcore["uid"])}
     label_of_uid = {}
     for cluster in clusters:
-        for p in cluster.pcore_objects:
-            label_of_uid[uid_of_pcore[p.id[0]]] = cluster.id
+        for pcore_id in cluster.pcore_ids:
+            label_of_uid[uid_of_pcore[pcore_id]] = cluster.id
     uids, inverse = np.unique(hddstream.labels_uid, return_inverse=True)
     names = np.array([label_of_uid.get(int(u), "None") for u in uids], dtype=object)
     cluster_ids = names[inverse] if n else np.empty(0, dtype=object)

@@ -10,11 +10,28 @@ expressions so thresholds are the same doubles.
 """
 import logging
 import sys
+from decimal import ROUND_HALF_UP, Decimal
 
 import numpy as np
 
 from .. import _lib
 from ..objects.microcluster import ClusterView, MicroclusterView
+
+
+def rounded_weights(w):
+    """app.py:184 for a whole array: Decimal(str(x)).quantize(Decimal('1.1'), ROUND_HALF_UP) per weight.  Weights
+    whose tenths are not within 1e-6 of a half-way case are rounded in float arithmetic (the decimal value of the
+    shortest repr differs from the double by less than an ulp, so it falls on the same side); the rest - and
+    anything unusual - goes through the reference's own expression."""
+    w = np.asarray(w, dtype=np.float64)
+    v = w * 10.0
+    frac = v - np.floor(v)
+    plain = np.isfinite(v) & (v >= 0.0) & (v < 1e14) & (np.abs(frac - 0.5) > 1e-6)
+    tenths = np.floor(np.where(plain, v, 0.0) + 0.5).astype(np.int64).tolist()
+    out = [Decimal(t).scaleb(-1) for t in tenths]
+    for i in np.nonzero(~plain)[0].tolist():
+        out[i] = Decimal(str(float(w[i]))).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)
+    return out
 
 
 class HDDStream(object):
@@ -44,6 +61,7 @@ class HDDStream(object):
         self.labels_path = None
         self._tables = {}
         self._clusters = None
+        self._cl_arrays = None
         self._uid_rows = None
 
     # ---- parameters -----------------------------------------------------------------------------
@@ -121,20 +139,20 @@ class HDDStream(object):
 
     def offline_clustering(self, dataset_daystamp):
         self._push_params()
-        clusters, _ = self._h.offline()
+        self._cl_arrays, _ = self._h.offline_arrays()  # (members, offsets, w, cf1, cf2, cen, pref): all clusters
+        self._clusters = None                          # ClusterView objects are built on demand (final_clusters)
         num_core = self._h.num_core()
         num_pcore = self._h.count(_lib.PCORE) - num_core
         self.logger.info(f'Starting offline clustering with {num_core} core clusters and {num_pcore} pcore clusters.')
-        self._clusters = [ClusterView(c["members"], c["w"], c["cf1"], c["cf2"], c["cen"], c["pref"])
-                          for c in clusters]
         self.logger.info('Finish offline clustering for dataset with timepoint: {}'.format(dataset_daystamp))
-        self.logger.info("Offline clustering yield {} clusters.".format(len(self._clusters)))
+        self.logger.info("Offline clustering yield {} clusters.".format(len(self._cl_arrays[2])))
 
     # ---- results ---------------------------------------------------------------------------------
 
     def _invalidate(self):
         self._tables = {}
         self._clusters = None
+        self._cl_arrays = None
         self._uid_rows = None
 
     def table(self, kind):
@@ -158,7 +176,49 @@ class HDDStream(object):
 
     @property
     def final_clusters(self):
-        return [] if self._clusters is None else self._clusters
+        """hddstream.py:508: the merged PredeconMC objects of the offline phase (views over the exported arrays)."""
+        if self._clusters is None:
+            if getattr(self, "_cl_arrays", None) is None:
+                return []
+            mem, off, w, cf1, cf2, cen, pref = self._cl_arrays
+            self._clusters = [ClusterView(mem[off[c]:off[c + 1]], w[c], cf1[c], cf2[c], cen[c], pref[c])
+                              for c in range(len(w))]
+        return self._clusters
+
+    def cluster_records(self):
+        """The tracking-side records of this timepoint's clusters: what app.py:181-190 builds one by one -
+        Cluster(list(id_set), centroid, weight rounded to one decimal place, preferred dimensions) plus the member
+        pcores - assembled from the exported arrays (member centroids / preferred dimensions are gathered from the
+        pcore table in one indexing operation instead of one object per pcore)."""
+        from ..objects.cluster import Cluster
+        if getattr(self, "_cl_arrays", None) is None:
+            return []
+        mem, off, w, _, _, cen, pref = self._cl_arrays
+        pc = self.table(_lib.PCORE)
+        order = np.argsort(pc["id"], kind="stable")
+        pos = order[np.searchsorted(pc["id"][order], mem)] if len(mem) else np.empty(0, np.int64)
+        weights = rounded_weights(w)
+        mem_list, off_list = mem.tolist(), off.tolist()
+        m_cen, m_pref, m_uid = pc["cen"][pos], pc["pref"][pos], pc["uid"][pos]  # member pcores, merge order
+        out = []
+        for c in range(len(w)):
+            a, b = off_list[c], off_list[c + 1]
+            merged = mem_list[a:b]
+            cl_cen, cl_pref, cl_uid = m_cen[a:b], m_pref[a:b], m_uid[a:b]
+            if b - a == 1:
+                ids = merged
+            else:
+                id_set = set()
+                for m in merged:  # predecon_mc.py:67: the set is filled in merge order (CPython iteration order depends on it)
+                    id_set.add(m)
+                ids = list(id_set)  # app.py:186
+                where = {m: i for i, m in enumerate(merged)}
+                perm = [where[m] for m in ids]
+                cl_cen, cl_pref, cl_uid = cl_cen[perm], cl_pref[perm], cl_uid[perm]
+            cl = Cluster(ids, cen[c], weights[c], pref[c])
+            cl.set_pcore_arrays(cl_cen, cl_pref, cl_uid)
+            out.append(cl)
+        return out
 
     @property
     def pcore_MC_last_id(self):

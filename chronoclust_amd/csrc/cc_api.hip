@@ -180,8 +180,8 @@ struct cc_handle {
     int n_core = 0;
 
     // association scratch
-    DevBuf<double> a_cur_cen, a_cur_pref, a_prev_cen, a_dist;
-    DevBuf<int> a_idx;
+    DevBuf<double> a_cur_cen, a_cur_pref, a_prev_cen, a_dist, a_pdist;
+    DevBuf<int> a_idx, a_pidx;
     DevBuf<int> flags;
 
     std::vector<hipEvent_t> ev_pool;
@@ -1502,14 +1502,43 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
         h->a_cur_cen.ensure(cd); h->a_cur_pref.ensure(cd); h->a_prev_cen.ensure(pd);
         h->a_idx.ensure(shard ? (size_t)share * world : (size_t)mc);
         h->a_dist.ensure(shard ? (size_t)share * world : (size_t)mc);
-        HIPCHK(hipMemcpyAsync(h->a_cur_cen.p, cur_cen, cd * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->a_cur_pref.p, cur_pref, cd * 8, hipMemcpyHostToDevice, h->stream));
-        if (pd) HIPCHK(hipMemcpyAsync(h->a_prev_cen.p, prev_cen, pd * 8, hipMemcpyHostToDevice, h->stream));
+        // the distance operand per (current pcore, dim): 1 or 1/k when every preference entry is 1 or k and k is a power
+        // of two (x / k == x * (1/k) bit for bit), else the preference entry itself (the kernel divides)
         const double k = h->have_par ? h->par.k : 1.0;
-        const int pow2 = is_pow2(k) ? 1 : 0;
-        if (c_hi > c_lo)
-            hipLaunchKernelGGL(k_assoc_argmin, dim3(c_hi - c_lo), dim3(64), 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,
-                               h->a_prev_cen.p, mc, mp, d, k, pow2 ? 1.0 / k : 0.0, pow2, h->a_idx.p, h->a_dist.p, c_lo);
+        bool unit = is_pow2(k);
+        for (size_t i = 0; unit && i < cd; ++i) unit = cur_pref[i] == 1.0 || cur_pref[i] == k;
+        std::vector<double> op(cd);
+        const double inv_k = unit ? 1.0 / k : 0.0;
+        for (size_t i = 0; i < cd; ++i) op[i] = unit ? (cur_pref[i] == 1.0 ? 1.0 : inv_k) : cur_pref[i];
+        HIPCHK(hipMemcpyAsync(h->a_cur_cen.p, cur_cen, cd * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->a_cur_pref.p, op.data(), cd * 8, hipMemcpyHostToDevice, h->stream));
+        if (pd) HIPCHK(hipMemcpyAsync(h->a_prev_cen.p, prev_cen, pd * 8, hipMemcpyHostToDevice, h->stream));
+        if (c_hi > c_lo && mp > 0) {
+            const int ctiles = (c_hi - c_lo + 255) / 256;  // workgroups of 4 x 64 current pcores
+            // previous pcores in S sub-ranges so that the launch fills the machine (>= ~1024 workgroups)
+            const int S = std::max(1, std::min((mp + CC_ASSOC_TQ - 1) / CC_ASSOC_TQ, (1024 + ctiles - 1) / ctiles));
+            h->a_pdist.ensure((size_t)S * mc);
+            h->a_pidx.ensure((size_t)S * mc);
+            const dim3 grid(ctiles, S), block(256);
+#define CC_ASSOC(DP)                                                                                                        \
+    do {                                                                                                                    \
+        if (unit) hipLaunchKernelGGL((k_assoc_tiled<DP, true>), grid, block, 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,   \
+                                     h->a_prev_cen.p, mc, mp, d, c_lo, c_hi, h->a_pdist.p, h->a_pidx.p);                      \
+        else hipLaunchKernelGGL((k_assoc_tiled<DP, false>), grid, block, 0, h->stream, h->a_cur_cen.p, h->a_cur_pref.p,       \
+                                h->a_prev_cen.p, mc, mp, d, c_lo, c_hi, h->a_pdist.p, h->a_pidx.p);                           \
+    } while (0)
+            if (d <= 4) CC_ASSOC(4);
+            else if (d <= 8) CC_ASSOC(8);
+            else if (d <= 16) CC_ASSOC(16);
+            else if (d <= 24) CC_ASSOC(24);
+            else if (d <= 40) CC_ASSOC(40);
+            else CC_ASSOC(64);
+#undef CC_ASSOC
+            hipLaunchKernelGGL(k_assoc_merge, dim3((c_hi - c_lo + 255) / 256), dim3(256), 0, h->stream, h->a_pdist.p,
+                               h->a_pidx.p, S, mc, c_lo, c_hi, h->a_idx.p, h->a_dist.p);
+        } else if (c_hi > c_lo) {
+            HIPCHK(hipMemsetAsync(h->a_idx.p + c_lo, 0xFF, (size_t)(c_hi - c_lo) * 4, h->stream));  // no previous pcores: -1
+        }
         if (shard) {
             h->comm.all_gather(h->a_idx.p + (size_t)rank * share, h->a_idx.p, (size_t)share * 4, h->stream);
             h->comm.all_gather(h->a_dist.p + (size_t)rank * share, h->a_dist.p, (size_t)share * 8, h->stream);

@@ -254,45 +254,84 @@ __global__ void k_cluster_merge(PcoreView pv, const int* __restrict__ members, c
 }
 
 // ---------------------------------------------------------------------------------
-// K9: association tracker, cluster_tracker.py:127-141.  One wave per current pcore; lanes stride over the
-// previous pcores, then a wavefront shuffle reduction of (distance, index) keeps "first minimum wins".
+// K9: association tracker, cluster_tracker.py:127-141: for every current pcore the previous pcore with the smallest
+// sum_d (prev - cur)^2 / cur_pref, strict <, first minimum wins.
+//
+// Lane = one current pcore, its centroid and distance operands in registers; the previous centroids are wave-uniform:
+// a workgroup (4 waves = 4 tiles of 64 current pcores) stages 32 of them at a time in LDS with coalesced loads and
+// every lane walks them in ascending order (broadcast reads), so the running minimum needs no cross-lane step and
+// "first minimum wins" is the loop order.  The previous pcores are split into gridDim.y sub-ranges for parallelism;
+// k_assoc_merge folds the partial minima in sub-range order.  UNIT: every preference entry is 1 or k with k a power
+// of two (x / k == x * (1/k) bit for bit, the operand is 1 or 1/k); otherwise the operand is the entry itself and
+// the term is divided.
 // ---------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(64) void k_assoc_argmin(const double* __restrict__ cur_cen,
-                                                     const double* __restrict__ cur_pref,
-                                                     const double* __restrict__ prev_cen, int mc, int mp, int d,
-                                                     double k, double inv_k, int pow2, int* __restrict__ out_idx,
-                                                     double* __restrict__ out_dist, int c_base)
+#define CC_ASSOC_TQ 32
+
+template <int DP, bool UNIT>
+__global__ __launch_bounds__(256) void k_assoc_tiled(const double* __restrict__ cur_cen, const double* __restrict__ cur_op,
+                                                     const double* __restrict__ prev_cen, int mc, int mp, int d, int c_lo,
+                                                     int c_hi, double* __restrict__ part_dist, int* __restrict__ part_idx)
 {
-    const int c = c_base + blockIdx.x;
-    if (c >= mc) return;
-    const int lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double s_q[CC_ASSOC_TQ * DP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int c = c_lo + (blockIdx.x * 4 + wv) * 64 + lane;
+    const bool valid = c < c_hi;
+    double cc[DP], op[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) {
+        cc[i] = (valid && i < d) ? cur_cen[(size_t)c * d + i] : 0.0;
+        op[i] = (valid && i < d) ? cur_op[(size_t)c * d + i] : 1.0;
+    }
+    const int S = gridDim.y;
+    const int per = (mp + S - 1) / S;
+    const int q0 = blockIdx.y * per, q1 = min(mp, q0 + per);
     double best = __builtin_huge_val();
-    int bidx = CC_IDX_INF;
-    for (int q = lane; q < mp; q += 64) {
-        double acc = 0.0;
-        for (int i = 0; i < d; ++i) {
-            double t = prev_cen[(size_t)q * d + i] - cur_cen[(size_t)c * d + i];
-            t = t * t;
-            const double pr = cur_pref[(size_t)c * d + i];
-            if (pr != 1.0) t = (pow2 && pr == k) ? t * inv_k : t / pr;
-            acc = acc + t;
+    int bidx = -1;
+    for (int qt = q0; qt < q1; qt += CC_ASSOC_TQ) {
+        const int tq = min(CC_ASSOC_TQ, q1 - qt);
+        __syncthreads();
+        for (int e = threadIdx.x; e < CC_ASSOC_TQ * DP; e += 256) {
+            const int m = e / DP, i = e - m * DP;
+            s_q[e] = (m < tq && i < d) ? prev_cen[(size_t)(qt + m) * d + i] : 0.0;
         }
-        if (bidx == CC_IDX_INF || acc < best) {  // ascending q inside a lane: strict < keeps the first
-            best = acc;
-            bidx = q;
+        __syncthreads();
+        for (int m = 0; m < tq; ++m) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                double t = s_q[m * DP + i] - cc[i];  // padded dimensions: 0 - 0, operand 1: the terms add +0.0
+                t = t * t;
+                t = UNIT ? t * op[i] : ((op[i] != 1.0) ? t / op[i] : t);
+                acc = acc + t;
+            }
+            if (bidx < 0 || acc < best) {  // ascending q: strict < keeps the first minimum
+                best = acc;
+                bidx = qt + m;
+            }
         }
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        const double od = __shfl_xor(best, off);
-        const int oi = __shfl_xor(bidx, off);
-        if (oi != CC_IDX_INF && (bidx == CC_IDX_INF || od < best || (od == best && oi < bidx))) {
-            best = od;
-            bidx = oi;
+    if (valid) {
+        part_dist[(size_t)blockIdx.y * mc + c] = best;
+        part_idx[(size_t)blockIdx.y * mc + c] = bidx;
+    }
+}
+
+__global__ void k_assoc_merge(const double* __restrict__ part_dist, const int* __restrict__ part_idx, int S, int mc,
+                              int c_lo, int c_hi, int* __restrict__ out_idx, double* __restrict__ out_dist)
+{
+    const int c = c_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c_hi) return;
+    double best = __builtin_huge_val();
+    int bidx = -1;
+    for (int s = 0; s < S; ++s) {  // sub-ranges in ascending order of q: strict < keeps the first minimum
+        const int i = part_idx[(size_t)s * mc + c];
+        const double v = part_dist[(size_t)s * mc + c];
+        if (i >= 0 && (bidx < 0 || v < best)) {
+            best = v;
+            bidx = i;
         }
     }
-    if (lane == 0) {
-        out_idx[c] = (bidx == CC_IDX_INF) ? -1 : bidx;
-        if (out_dist) out_dist[c] = best;
-    }
+    out_idx[c] = bidx;
+    if (out_dist) out_dist[c] = best;
 }

@@ -25,7 +25,10 @@ class Cluster(object):
         self.centroid = cluster_centroid
         self.cumulative_weight = cumulative_weight
         self.preferred_dimensions = preferred_dimensions
-        self.pcore_objects = []
+        self._pcore_objects = None   # list of PcoreSnapshot, built on first access of `pcore_objects`
+        self._pc_cen = None          # [members, d] centroids / preferred dimensions of the member pcores as arrays
+        self._pc_pref = None         # (set_pcore_arrays: the vectorised form of add_pcore_objects)
+        self._pc_uid = None
         self.historical_associates = set()
         self.historical_associates_pcores = set()
 
@@ -45,11 +48,48 @@ class Cluster(object):
         return self.parents
 
     # -- association side (cluster.py:50-76) --------------------------------------------------
+    @property
+    def pcore_objects(self):
+        """The member pcores as objects (cluster.py:57 keeps deep copies of whole Microclusters); materialised from
+        the arrays of set_pcore_arrays on first use."""
+        if self._pcore_objects is None:
+            self._pcore_objects = []
+            if self._pc_cen is not None:
+                for i, pcore_id in enumerate(self.pcore_ids):
+                    self._pcore_objects.append(PcoreSnapshot(pcore_id, self._pc_cen[i], self._pc_pref[i],
+                                                             None if self._pc_uid is None else int(self._pc_uid[i])))
+        return self._pcore_objects
+
     def add_pcore_objects(self, pcore_id_to_object):
         for pcore_id in self.pcore_ids:
             src = pcore_id_to_object[pcore_id]
             self.pcore_objects.append(PcoreSnapshot(pcore_id, src.cluster_centroids, src.preferred_dimension_vector,
                                                     getattr(src, "prev_outlier_id", None)))
+
+    def set_pcore_arrays(self, centroids, preferred_dimensions, uids=None):
+        """add_pcore_objects from arrays: row i belongs to pcore_ids[i]."""
+        self._pc_cen, self._pc_pref, self._pc_uid = centroids, preferred_dimensions, uids
+        self._pcore_objects = None
+
+    def pcore_arrays(self):
+        """(ids, centroids [n, d], preferred dimensions [n, d]) of the member pcores, in pcore_ids order."""
+        import numpy as np
+        if self._pcore_objects is None and self._pc_cen is not None:
+            return list(self.pcore_ids), self._pc_cen, self._pc_pref
+        objs = self.pcore_objects
+        if not objs:
+            return [], np.empty((0, 0)), np.empty((0, 0))
+        return ([p.id[0] for p in objs], np.array([np.asarray(p.cluster_centroids, dtype=np.float64) for p in objs]),
+                np.array([np.asarray(p.preferred_dimension_vector, dtype=np.float64) for p in objs]))
+
+    def __getstate__(self):
+        return self.__dict__
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if "pcore_objects" in state:  # images written before the arrays existed
+            self._pcore_objects = self.__dict__.pop("pcore_objects")
+            self._pc_cen = self._pc_pref = self._pc_uid = None
 
     def add_historical_associate(self, associate):
         self.historical_associates.add(associate)

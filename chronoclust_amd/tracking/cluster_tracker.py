@@ -108,22 +108,32 @@ class TrackByHistoricalAssociation(object):
             return
         prev_owner, prev_pcore, prev_cen = [], [], []
         for pc in self.previous_timepoint_clusters:
-            for p in pc.pcore_objects:
-                prev_owner.append(pc.id)
-                prev_pcore.append(p.id)
-                prev_cen.append(np.asarray(p.cluster_centroids, dtype=np.float64))
-        cur = [(cl, p) for cl in self.current_clusters for p in cl.pcore_objects]
-        if not cur:
+            ids, cen, _ = pc.pcore_arrays()
+            if ids:
+                prev_owner += [pc.id] * len(ids)
+                prev_pcore += ids
+                prev_cen.append(cen)
+        cur_owner, cur_cen, cur_pref = [], [], []
+        for cl in self.current_clusters:
+            ids, cen, pref = cl.pcore_arrays()
+            if ids:
+                cur_owner += [cl] * len(ids)
+                cur_cen.append(cen)
+                cur_pref.append(pref)
+        if not cur_owner:
             return
-        cur_cen = np.array([np.asarray(p.cluster_centroids, dtype=np.float64) for _, p in cur])
-        cur_pref = np.array([np.asarray(p.preferred_dimension_vector, dtype=np.float64) for _, p in cur])
         if prev_cen:
-            idx, _ = self._hip().assoc_argmin(cur_cen, cur_pref, np.array(prev_cen))
+            idx, _ = self._hip().assoc_argmin(np.concatenate(cur_cen), np.concatenate(cur_pref),
+                                              np.concatenate(prev_cen))
+            idx = idx.tolist()
         else:
-            idx = np.full(len(cur), -1)
-        for (cluster, _), i in zip(cur, idx):
-            cluster.add_historical_associate(prev_owner[i] if i >= 0 else None)
-            cluster.add_historical_associate_pcore(prev_pcore[i] if i >= 0 else None)
+            idx = [-1] * len(cur_owner)
+        for cluster, i in zip(cur_owner, idx):
+            if i >= 0:
+                cluster.historical_associates.add(prev_owner[i])          # Cluster.add_historical_associate
+                cluster.historical_associates_pcores.add(prev_pcore[i])   # ....add_historical_associate_pcore([id])
+            else:
+                cluster.historical_associates.add(None)
 
     def transfer_current_to_previous(self):
         self.previous_timepoint_clusters = self.current_clusters

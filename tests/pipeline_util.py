@@ -18,7 +18,7 @@ class _RecordingHandle(object):
         return idx, dist
 
 
-def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None, stream=None):
+def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None, stream=None, object_records=False):
     """Returns one dict per timepoint: labels_uid, pcore / outlier tables, `rows` = what write_result_file would
     write per cluster (weight, pcore ids, preferred dimensions, lineage id, association string; app.py:229-260),
     merge-ordered members of every cluster, and the recorded association argmin calls."""
@@ -34,12 +34,17 @@ def run_pipeline(Xs, cfg, tuning=None, device=0, on_timepoint=None, stream=None)
         before = {kind: {k: v.copy() for k, v in h.table(kind).items() if k in ("uid", "w")} for kind in (0, 1)} \
             if t > 0 else None
         h.online_microcluster_maintenance(X, t)
-        pcore_by_id = {mc.id[0]: mc for mc in h.pcore_MC}
-        for found in h.final_clusters:
-            w = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)  # app.py:184
-            cl = Cluster(list(found.id), found.cluster_centroids, w, found.preferred_dimension_vector)
-            cl.add_pcore_objects(pcore_by_id)
-            lineage.add_new_child_cluster(cl)
+        if object_records:
+            # app.py:179-190 literally: one object per pcore and per cluster
+            pcore_by_id = {mc.id[0]: mc for mc in h.pcore_MC}
+            for found in h.final_clusters:
+                w = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)  # app.py:184
+                cl = Cluster(list(found.id), found.cluster_centroids, w, found.preferred_dimension_vector)
+                cl.add_pcore_objects(pcore_by_id)
+                lineage.add_new_child_cluster(cl)
+        else:
+            for cl in h.cluster_records():  # the same records assembled from arrays (what app.run does)
+                lineage.add_new_child_cluster(cl)
         lineage.calculate_ids()
         assoc.set_current_clusters(lineage.child_clusters)
         n_calls = len(assoc_log)

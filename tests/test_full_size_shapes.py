@@ -73,6 +73,13 @@ def test_c3_results_do_not_depend_on_window_or_lookahead(c3, tuning):
     P.same_results(P.run_pipeline(Xs, cfg, tuning=tuning), res)
 
 
+def test_c3_array_built_cluster_records_equal_object_built(c3):
+    """HDDStream.cluster_records (arrays) against the reference's per-object construction (app.py:179-190) at
+    5 000 clusters: same weights, pcore id order, lineage and association strings."""
+    Xs, cfg, res = c3
+    P.same_results(P.run_pipeline(Xs[:3], cfg, object_records=True), res[:3])
+
+
 def test_c3_first_timepoint_prefix_matches_oracle(c3):
     Xs, cfg, res = c3
     _oracle_prefix(cfg, Xs[0], 100_000, res[0]["labels_uid"])

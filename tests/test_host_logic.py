@@ -93,3 +93,25 @@ def test_drop_rows_after_keeps_header_and_earlier_timepoints(tmp_path):
         rows = list(csv.reader(f))
     assert rows == [["timepoint", "cumulative_size", "tracking_by_lineage"], ["0", "10.0", "A"], ["1", "12.5", "(A,B)"]]
     assert open(fn, newline="").read() == before[:before.index("2,3.0")]
+
+
+def test_rounded_weights_equal_the_reference_expression():
+    """chronoclust_amd.clustering.hddstream.rounded_weights against app.py:184 evaluated per value, on integers,
+    decayed weights, exact and near half-way cases (x.y5 decimal strings whose doubles lie on either side)."""
+    from decimal import ROUND_HALF_UP, Decimal
+    import numpy as np
+    from chronoclust_amd.clustering.hddstream import rounded_weights
+    rng = np.random.default_rng(0)
+    w = np.concatenate([
+        rng.integers(0, 5000, 2000).astype(np.float64),
+        rng.integers(0, 5000, 2000) * 2.0 ** (-rng.integers(1, 12, 2000) * 0.5),      # decayed weights
+        rng.uniform(0, 3000, 4000),
+        np.round(rng.uniform(0, 500, 4000), 2),                                        # two decimals: many x.y5
+        np.array([0.05, 0.15, 0.25, 0.35, 1.45, 2.675, 1.005, 10.05, 200.25, 0.04999999999999999, 0.0, 1e15, 123456789.25]),
+        np.nextafter(np.round(rng.uniform(0, 500, 500), 1) + 0.05, 0), np.nextafter(np.round(rng.uniform(0, 500, 500), 1) + 0.05, 1e9),
+    ])
+    got = rounded_weights(w)
+    exp = [Decimal(str(float(x))).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP) for x in w]
+    assert got == exp
+    assert [str(g) for g in got] == [str(e) for e in exp]
+    assert [g.as_tuple() for g in got] == [e.as_tuple() for e in exp]

@@ -3,7 +3,6 @@ association (the app.run pipeline without CSV I/O).  Prints the time of every ph
 import os
 import sys
 import time
-from decimal import ROUND_HALF_UP, Decimal
 
 import numpy as np
 
@@ -12,7 +11,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import scenarios  # noqa: E402
 from chronoclust_amd.clustering.hddstream import HDDStream  # noqa: E402
-from chronoclust_amd.objects.cluster import Cluster  # noqa: E402
 from chronoclust_amd.tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage  # noqa: E402
 
 if __name__ == "__main__":
@@ -31,11 +29,7 @@ if __name__ == "__main__":
         a = time.perf_counter()
         h.online_microcluster_maintenance(X, t)
         b = time.perf_counter()
-        pcore_by_id = {mc.id[0]: mc for mc in h.pcore_MC}
-        for found in h.final_clusters:
-            w = Decimal(str(found.cumulative_weight)).quantize(Decimal('1.1'), rounding=ROUND_HALF_UP)
-            cl = Cluster(list(found.id), found.cluster_centroids, w, found.preferred_dimension_vector)
-            cl.add_pcore_objects(pcore_by_id)
+        for cl in h.cluster_records():
             lineage.add_new_child_cluster(cl)
         c = time.perf_counter()
         lineage.calculate_ids()
