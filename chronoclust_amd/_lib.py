@@ -93,7 +93,7 @@ def load():
     """Loads libchronoclust_hip.so (built in-tree by chronoclust_amd.build).  Raises if it is missing."""
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("CHRONOCLUST_HIP_LIB") or _build.LIB_PATH  # (a build variant, for kernel experiments)
         if not os.path.exists(path):
             raise ChronoclustHipError(
                 "HIP library %s not built; run `python -m chronoclust_amd.build` (needs hipcc). "

@@ -15,18 +15,20 @@ def needs_build():
     return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, out=None, defines=()):
+    """out / defines: a variant of the library under another name with build-time knobs set (kernel experiments,
+    loaded through CHRONOCLUST_HIP_LIB)."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
            # bit-exactness: no FMA contraction, no fast-math anywhere (host or device)
-           "-ffp-contract=off", "-fno-fast-math",
-           "-o", LIB_PATH, SOURCES[0]]
+           "-ffp-contract=off", "-fno-fast-math"] + ["-D" + x for x in defines] + [
+           "-o", out or LIB_PATH, SOURCES[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out or LIB_PATH
 
 
 if __name__ == "__main__":

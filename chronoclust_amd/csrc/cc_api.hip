@@ -141,6 +141,7 @@ struct cc_handle {
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
+    bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -373,7 +374,8 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 {
     constexpr int NW = ScanWaves<DP>::value;
     const dim3 block(64 * NW);
-    const dim3 grid((win + 63) / 64, S);
+    constexpr int TILE = 64 * ScanShape<DP, DIRTY>::PT;  // window points per workgroup
+    const dim3 grid((win + TILE - 1) / TILE, S);
     // the clean scan is compiled without the pdim filter for the common case pi >= d; the dirty scan (few rows
     // survive its pruning) tests the flag at run time
     const bool filter = DIRTY || h->hc.filter != 0;
@@ -399,8 +401,10 @@ void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* c
 {
     const int d = h->d;
 #define CC_SCAN_DP(DP) launch_scan_dp<DP, DIRTY>(h, st, win, rows, clean, part, S, round, mode, shard_rank, shard_world)
+    // (padded dimensions cost full distance terms: the ladder follows the shapes of BASELINE.json - d = 14, 20, 40)
     if (d <= 4) CC_SCAN_DP(4);
     else if (d <= 8) CC_SCAN_DP(8);
+    else if (d <= 14) CC_SCAN_DP(14);
     else if (d <= 16) CC_SCAN_DP(16);
     else if (d <= 20) CC_SCAN_DP(20);
     else if (d <= 32) CC_SCAN_DP(32);
@@ -486,6 +490,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_nodirty = !(nd && nd[0] == '0');
         const char* cl = getenv("CHRONOCLUST_HIP_CLAIMS");
         h->allow_claims = !(cl && cl[0] == '0');
+        const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
+        h->allow_long = !(lc && lc[0] == '0');
         push_ctl(h);
         HIPCHK(hipStreamSynchronize(h->stream));
         return CC_OK;
@@ -832,6 +838,9 @@ int cc_online_run(cc_handle* h)
             // few MCs: the claims of a window are gathered per MC by k_claims (rows beyond scan_rows, e.g. rows created
             // during the batch, keep k_decide's atomics)
             const int scan_rows = (h->allow_claims && h->hc.m_rows > 0 && h->hc.m_rows <= 1024) ? h->hc.m_rows : 0;
+            // ... and their long chains (more than CC_CHAIN_MEMB claimants; k_claims leaves the exact count) are replayed
+            // by k_chain_long, one workgroup per MC, instead of one point after the other
+            const int long_rows = h->allow_long ? scan_rows : 0;
             // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
             // a batch, then kept up commit by commit
             ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
@@ -907,7 +916,10 @@ int cc_online_run(cc_handle* h)
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), 0, sA,
-                                       h->ctl.p, h->X.p, tab, ver, car, told, r);
+                                       h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
+                    if (long_rows > 0)
+                        hipLaunchKernelGGL(k_chain_long, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                           told, r, long_rows);
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, told, r);
                     if (!nodirty) {

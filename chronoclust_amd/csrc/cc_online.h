@@ -179,6 +179,28 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 // ---------------------------------------------------------------------------------
 
 #define CC_SCAN_TM 16     // MC rows per LDS tile
+// window points per lane of the clean scan at DP == 20 / workgroups per CU it is compiled for (build-time knobs)
+#ifndef CC_SCAN_PT_CLEAN
+#define CC_SCAN_PT_CLEAN 1
+#endif
+#ifndef CC_SCAN_WGS_CLEAN
+#define CC_SCAN_WGS_CLEAN 4
+#endif
+#ifndef CC_SCAN_ROW_UNROLL
+#define CC_SCAN_ROW_UNROLL 1
+#endif
+#ifndef CC_SCAN_WGS_CLEAN40
+#define CC_SCAN_WGS_CLEAN40 3
+#endif
+#ifndef CC_SCAN_WGS_DIRTY32
+#define CC_SCAN_WGS_DIRTY32 3
+#endif
+template <int DP, bool DIRTY>
+struct ScanShape {
+    static constexpr int PT = (!DIRTY && DP == 20) ? CC_SCAN_PT_CLEAN : 1;
+    static constexpr int WGS = (!DIRTY && DP == 20) ? CC_SCAN_WGS_CLEAN
+                               : (DP <= 20 ? 4 : (DP <= 40 ? (DIRTY ? CC_SCAN_WGS_DIRTY32 : (DP == 40 ? CC_SCAN_WGS_CLEAN40 : 3)) : 2));
+};
 // waves per workgroup (template parameter NW): same points, disjoint MC sub-ranges, merged through LDS
 
 
@@ -187,14 +209,14 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 // (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
 // the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
 template <int DP, bool FILTER, bool POW2, bool DIRTY, int NW>
-__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void k_scan(const Ctl* __restrict__ ctl,
+__global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(const Ctl* __restrict__ ctl,
                                                              const double* __restrict__ X,
                                                              const double* __restrict__ Xt, Rows rows,
                                                              const Cand* __restrict__ clean,
                                                              Cand* __restrict__ part, int round, int mode,
                                                              size_t part_stride, int shard_rank, int shard_world)
 {
-    constexpr int PT = 1;  // window points per lane (two measured 10 % slower on C2)
+    constexpr int PT = ScanShape<DP, DIRTY>::PT;  // window points per lane
     if (DIRTY) CC_LATENCY_KERNEL();
     // Which window, which rows:
     //   clean, mode 0: the current window against the table as it is (only if the window has no lookahead scan)
@@ -442,6 +464,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
             auto clean_rows = [&](auto FUSEC, auto KSELC) {
             constexpr bool FUSE = decltype(FUSEC)::value;
             constexpr int KSEL = decltype(KSELC)::value;
+#pragma unroll CC_SCAN_ROW_UNROLL
             for (int m = 0; m < tm; ++m) {
                 double acc[PT];
                 // (rows of an even DP start on 16-byte boundaries: ds_read_b128)
@@ -1390,7 +1413,8 @@ __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Tab
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                               Versions ver, Carry car, const int* __restrict__ T, int round)
+                                               Versions ver, Carry car, const int* __restrict__ T, int round,
+                                               int long_rows)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1419,6 +1443,8 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const unsigned long long cw = tab.cnt[t];
     const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
     const bool listed = n_memb <= CC_CHAIN_MEMB;
+    // a long chain on one of the first long_rows table rows is replayed by k_chain_long (launched right after)
+    if (!listed && t < long_rows && t < ctl->m_rows) return;
     int sorted_memb = CC_IDX_INF;
     if (listed) {
         const int mine = (gl < n_memb) ? tab.memb[(size_t)t * CC_CHAIN_MEMB + gl] : CC_IDX_INF;
@@ -1596,6 +1622,277 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         first = mem[NB];
     }
     if (gl == 0 && !isnew) tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it
+}
+
+// ---------------------------------------------------------------------------------
+// k_chain_long: the chains k_chain leaves alone - more than CC_CHAIN_MEMB claimants on one of the first scan_rows
+// table rows (few microclusters: every MC absorbs hundreds of window points).  k_chain replays such a chain one
+// point after the other (~1.6 us per step: locate the member, fetch its point, two IEEE divisions per dimension,
+// ordered radius sum, 14 stores).  Only the CF sums are sequential by nature (microcluster.py:147, mc_functions.py:
+// 24-29: CF1 += p, CF2 += p * p, W += 1); the radius test of step k (mc_functions.py:45-56) is a function of the sums
+// after k alone.  One workgroup per MC therefore works in batches of K members:
+//   1. the members are collected in order from the claims (ordered compaction of 1 024 claims per pass),
+//   2. their points are staged in LDS, thread i < d runs the two additions per step of dimension i over the batch
+//      (the same additions in the same order as k_chain), one more thread the additions of W,
+//   3. thread k evaluates step k - variances, preferred dimensions, ordered radius sum, promotion test - assuming
+//      that every earlier step of the batch was accepted,
+//   4. up to the first rejected step f that assumption holds, so the version rows 0 .. f - 1 (and the unchanged state
+//      as the row of f) are exactly what the sequential replay produces; the chain resumes after f from the state
+//      of f - 1.
+// Rows and stamps are written in k_chain's formats.  New MCs (created inside the window) stay with k_chain.
+// ---------------------------------------------------------------------------------
+
+#define CC_LONG_XY_DOUBLES 6144  // staged CF1 / CF2 prefixes of a batch: 2 * K * d doubles (48 KB)
+#define CC_LONG_QUEUE 2048       // pending chain members (ring buffer)
+
+__global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                                    Versions ver, Carry car, const int* __restrict__ T, int round,
+                                                    int scan_rows)
+{
+    CC_LATENCY_KERNEL();
+    const int B = ctl->win_b;
+    if (B == 0) return;
+    if (ctl->fc[round - 1] >= B) return;
+    const int t = blockIdx.x;
+    const int M0 = ctl->m_rows;
+    if (t >= M0 || t >= scan_rows) return;
+    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    const size_t rd = (size_t)(round & 1) * tab.cap + (size_t)t;
+    const unsigned long long ft = tab.touch[rd], lt = tab.last[rd];
+    if ((ft >> 20) != stamp) return;  // nobody targets this MC in this round
+    const unsigned long long cw = tab.cnt[t];
+    const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
+    if (n_memb <= CC_CHAIN_MEMB) return;  // a listed chain: k_chain walks it
+    const int head = 0xFFFFF - (int)(ft & 0xFFFFFull);
+    const int last_j = ((lt >> 20) == stamp) ? (int)(lt & 0xFFFFFull) : head;
+
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
+    const int tid = threadIdx.x;
+    const long long cursor = ctl->cursor;
+    const int pk_base = ctl->n_pkeys;
+    // steps per batch: the CF1 / CF2 prefixes of a batch have to fit the staging area
+    const int K = (d <= 24) ? 128 : ((d <= 48) ? 64 : 32);
+
+    __shared__ __attribute__((aligned(16))) double s_xy[CC_LONG_XY_DOUBLES];
+    __shared__ double s_w[128], s_dq[128];
+    __shared__ unsigned long long s_mask[128];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
+    __shared__ int s_flag[128];                 // bit 0: radius test passed, bit 1: promotion condition holds
+    __shared__ int s_queue[CC_LONG_QUEUE];
+    __shared__ double s_b1[64], s_b2[64], s_bcen[64], s_bpref[64], s_c0[64], s_w0[64];  // running state / snapshot metric
+    __shared__ double s_bw, s_bdq;
+    __shared__ int s_wsum[4];
+    __shared__ int s_first_fail, s_first_up;
+    double* const xs = s_xy;
+    double* const ys = s_xy + (size_t)K * d;
+
+    // running state of the chain (same meaning as k_chain's registers)
+    int bkind = tab.kind[t], bkey = tab.key[t], bupg = -1;
+    if (tid < d) {
+        s_b1[tid] = tab.cf1[(size_t)t * d + tid]; s_b2[tid] = tab.cf2[(size_t)t * d + tid];
+        s_bcen[tid] = tab.cen[(size_t)t * d + tid]; s_bpref[tid] = tab.pref[(size_t)t * d + tid];
+    }
+    if (tid == 0) s_bw = tab.w[t];
+    __syncthreads();
+    // centroid, metric and kind in the snapshot the window was scanned against (k_chain: c0, w0, kind0)
+    int kind0 = bkind;
+    {
+        bool from_carry = false;
+        size_t r = 0;
+        if (ctl->mode != 0) {
+            const unsigned long long co = tab.carry_of[t];
+            if ((co >> 20) == ctl->window_seq) {
+                from_carry = true;
+                r = (size_t)(co & 0xFFFFFull);
+                kind0 = car.kind0[r];
+            }
+        }
+        if (tid < d) {
+            s_c0[tid] = from_carry ? car.c0[r * d + tid] : s_bcen[tid];
+            s_w0[tid] = from_carry ? car.w0[r * d + tid] : 1.0 / s_bpref[tid];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double dq = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double df = s_bcen[i] - s_c0[i];
+            dq += df * df * s_w0[i];
+        }
+        s_bdq = dq;
+    }
+
+    const int4* T4 = reinterpret_cast<const int4*>(T);  // (the claims buffer is padded to whole 128-entry blocks)
+    int qhead = 0, qcount = 0;     // ring buffer of pending members (the same in every thread)
+    int scan_pos = head & ~1023;   // next block of 1 024 claims to look at
+    bool scan_done = false;
+    int walked = 0;
+    bool promoted_any = false;
+
+    for (;;) {
+        // ---- 1. members in order: ordered compaction of the next claims into the queue ----
+        while (!scan_done && qcount < K + 1 && qcount + 1024 <= CC_LONG_QUEUE) {
+            const int i0 = scan_pos + tid * 4;
+            int4 v = make_int4(-1, -1, -1, -1);
+            if (i0 <= last_j) v = T4[i0 >> 2];
+            const int e[4] = {v.x, v.y, v.z, v.w};
+            int f[4], cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = i0 + c;
+                f[c] = (j >= head && j <= last_j && j < B && e[c] == t) ? 1 : 0;
+                cnt += f[c];
+            }
+            int incl = cnt;
+            const int lane = tid & 63, wv = tid >> 6;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            __syncthreads();  // (s_wsum of the previous pass has been read)
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w < wv) base += s_wsum[w];
+                total += s_wsum[w];
+            }
+            int pos = qcount + base + incl - cnt;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (f[c]) { s_queue[(qhead + pos) & (CC_LONG_QUEUE - 1)] = i0 + c; ++pos; }
+            qcount += total;
+            scan_pos += 1024;
+            if (scan_pos > last_j) scan_done = true;
+        }
+        __syncthreads();
+        if (qcount == 0) break;
+        const int n = qcount < K ? qcount : K;  // steps of this batch (the member after it is known, or the chain ends)
+
+        // ---- 2. stage the points, then the sequential additions per dimension ----
+        for (int e = tid; e < n * d; e += 256) {
+            const int k = e / d, i = e - k * d;
+            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            xs[e] = X[(cursor + m) * d + i];
+        }
+        if (tid == 0) { s_first_fail = n; s_first_up = n; }
+        __syncthreads();
+        if (tid < d) {
+            double c1 = s_b1[tid], c2 = s_b2[tid];
+            for (int k = 0; k < n; ++k) {
+                const double x = xs[k * d + tid];
+                c1 = c1 + x;          // mc_functions.py:24-29, the additions k_chain makes, in its order
+                c2 = c2 + x * x;
+                xs[k * d + tid] = c1;
+                ys[k * d + tid] = c2;
+            }
+        } else if (tid == 64) {
+            double w = s_bw;
+            for (int k = 0; k < n; ++k) {
+                w = w + 1.0;  // microcluster.py:147
+                s_w[k] = w;
+            }
+        }
+        __syncthreads();
+
+        // ---- 3. every step evaluated on its own prefix ----
+        if (tid < n) {
+            const int k = tid;
+            const double w1 = s_w[k];
+            double r2 = 0.0, dq = 0.0;
+            int gt1 = 0;
+            unsigned long long mask = 0ull;
+            for (int i = 0; i < d; ++i) {
+                const double qa = ys[k * d + i] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
+                const double qb = xs[k * d + i] / w1;
+                const double var = qa - qb * qb;
+                const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
+                const double pr = prefd ? par.k : 1.0;
+                r2 = r2 + cc_div_pref(var, pr, par);     // mc_functions.py:54, left to right
+                gt1 += (pr > 1.0) ? 1 : 0;
+                mask |= prefd ? (1ull << i) : 0ull;
+                const double df = qb - s_c0[i];
+                dq += df * df * s_w0[i];
+            }
+            const bool ok = r2 <= par.eps_sq;                          // hddstream.py:334-337
+            const bool up = w1 >= par.beta_mu && gt1 <= par.pi;        // hddstream.py:416-417
+            s_flag[k] = (ok ? 1 : 0) | (up ? 2 : 0);
+            s_mask[k] = mask;
+            s_dq[k] = dq;
+            if (!ok) atomicMin(&s_first_fail, k);
+            if (up) atomicMin(&s_first_up, k);
+        }
+        __syncthreads();
+        const int f = s_first_fail;                 // first rejected step (n: none)
+        const int n_ok = f < n ? f : n;             // accepted steps 0 .. n_ok - 1
+        const int n_rows = f < n ? f + 1 : n;       // members consumed by this batch (the rejected one included)
+        // hddstream.py:416-430: the first accepted add to an outlier MC that fulfils the condition promotes it
+        int u = -1;
+        if (bkind == CC_KIND_OUTLIER && s_first_up < n_ok) u = s_first_up;
+        const int up_point = (u >= 0) ? s_queue[(qhead + u) & (CC_LONG_QUEUE - 1)] : -1;
+
+        // ---- 4. version rows: vectors by (row, dimension), the rest by row ----
+        for (int e = tid; e < n_rows * d; e += 256) {
+            const int k = e / d, i = e - k * d;
+            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            const int src = (k < n_ok) ? k : k - 1;  // a rejected step leaves the state of the step before it
+            double c1, c2, ce, pr;
+            if (src >= 0) {
+                c1 = xs[src * d + i]; c2 = ys[src * d + i];
+                ce = c1 / s_w[src];  // mc_functions.py:31-33: the quotient the variance was formed from
+                pr = ((s_mask[src] >> i) & 1ull) ? par.k : 1.0;
+            } else {
+                c1 = s_b1[i]; c2 = s_b2[i]; ce = s_bcen[i]; pr = s_bpref[i];
+            }
+            const size_t o = (size_t)m * d + i;
+            ver.cf1[o] = c1; ver.cf2[o] = c2; ver.cen[o] = ce; ver.pref[o] = pr;
+            ver.scl[o] = par.pow2 ? (pr == 1.0 ? 1.0 : par.inv_k) : pr;
+        }
+        if (tid < n_rows) {
+            const int k = tid;
+            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            const int src = (k < n_ok) ? k : k - 1;
+            const bool promoted = u >= 0 && k >= u;
+            const int kind = promoted ? CC_KIND_PCORE : bkind;
+            double dq = (src >= 0) ? s_dq[src] : s_bdq;
+            if (kind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+            const int nx = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (CC_LONG_QUEUE - 1)] : CC_IDX_INF;
+            ver.w[m] = (src >= 0) ? s_w[src] : s_bw;
+            ver.tgt[m] = t;
+            ver.kind[m] = kind;
+            ver.key[m] = promoted ? pk_base + up_point : bkey;
+            ver.upg[m] = promoted ? up_point : bupg;
+            ver.acc[m] = (k < n_ok) ? 1 : 0;
+            ver.next[m] = nx;
+            ver.dsq[m] = dq;
+            atomicMax(&ver.tile_dsq[m >> 4], (unsigned long long)__double_as_longlong(dq));
+        }
+        __syncthreads();  // every read of the running state and of the queue slots is done
+
+        // ---- 5. the running state moves on to the last accepted step ----
+        if (n_ok > 0) {
+            const int l = n_ok - 1;
+            if (tid < d) {
+                s_b1[tid] = xs[l * d + tid]; s_b2[tid] = ys[l * d + tid];
+                s_bcen[tid] = xs[l * d + tid] / s_w[l];
+                s_bpref[tid] = ((s_mask[l] >> tid) & 1ull) ? par.k : 1.0;
+            }
+            if (tid == 64) { s_bw = s_w[l]; s_bdq = s_dq[l]; }
+        }
+        if (u >= 0) {
+            bkind = CC_KIND_PCORE; bkey = pk_base + up_point; bupg = up_point;
+            promoted_any = true;
+        }
+        qhead = (qhead + n_rows) & (CC_LONG_QUEUE - 1);
+        qcount -= n_rows;
+        walked += n_rows;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it
+        if (promoted_any) ctl->any_up[round] = 1;
+    }
 }
 
 // ---------------------------------------------------------------------------------
