@@ -27,7 +27,7 @@ class CcParams(C.Structure):
 class CcTuning(C.Structure):
     _fields_ = [("window", C.c_int32), ("rounds", C.c_int32), ("segments", C.c_int32),
                 ("windows_per_sync", C.c_int32), ("time_kernels", C.c_int32), ("dirty_segments", C.c_int32),
-                ("early_window", C.c_int32), ("lookahead", C.c_int32)]
+                ("early_window", C.c_int32), ("lookahead", C.c_int32), ("sequential", C.c_int32)]
 
 
 class CcStats(C.Structure):
@@ -35,7 +35,7 @@ class CcStats(C.Structure):
                 ("scan_launches", C.c_int64), ("scan_ms", C.c_double), ("scan_pair_dims", C.c_double),
                 ("run_ms", C.c_double), ("rows", C.c_int64), ("table_rows_scanned", C.c_int64),
                 ("lookahead_windows", C.c_int64), ("sharded_windows", C.c_int64), ("comm_launches", C.c_int64),
-                ("comm_ms", C.c_double), ("reserved", C.c_int64 * 2)]
+                ("comm_ms", C.c_double), ("seq_points", C.c_int64), ("reserved", C.c_int64 * 1)]
 
 
 _dp = C.POINTER(C.c_double)
@@ -175,9 +175,9 @@ class Handle(object):
         return rc
 
     def set_tuning(self, window=0, rounds=0, segments=0, windows_per_sync=0, time_kernels=0, dirty_segments=0,
-                   lookahead=0, early_window=0):
+                   lookahead=0, early_window=0, sequential=0):
         t = CcTuning(window, rounds, segments, windows_per_sync, time_kernels, dirty_segments, int(early_window),
-                     int(lookahead))
+                     int(lookahead), int(sequential))
         self._check(self._lib.cc_set_tuning(self._h, C.byref(t)))
 
     def reset(self):

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -142,6 +143,7 @@ struct cc_handle {
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
+    bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -535,6 +537,7 @@ int cc_set_tuning(cc_handle* h, const cc_tuning* t)
     h->tun.time_kernels = t->time_kernels;
     if (t->dirty_segments > 0) h->tun.dirty_segments = std::min(t->dirty_segments, 1024);
     h->tun.lookahead = t->lookahead;
+    h->tun.sequential = t->sequential;
     if (t->early_window > 0) h->tun.early_window = t->early_window;
     return CC_OK;
 }
@@ -550,6 +553,7 @@ int cc_reset(cc_handle* h)
         c.cursor = 0;
         h->tainted = false;
         h->adapt_win = 0;  // an empty table starts with small windows again
+        h->seq_sticky = false;
         h->clean_batches = 0;
         h->since_shrink = 1000;
         h->clusters.clear();
@@ -807,6 +811,18 @@ int cc_online_run(cc_handle* h)
 
         long long done = 0;
         int m_known = c.m_rows;
+        // The sequential kernel (k_seq) for streams on which speculation does not pay: used while the table fits its
+        // LDS image and either the caller forces it or (default) the windows keep being cut short and it measures
+        // faster than they do.  Never inside a multi-GPU group (every rank has to take the same path, and wall-clock
+        // measurements differ between ranks).
+        const int seq_mode = h->tun.sequential;
+        const int seq_cap = cc_seq_cap_rows(h->d);
+        auto seq_possible = [&]() { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; };
+        bool seq_on = seq_possible() && (seq_mode == 2 || h->seq_sticky);
+        bool seq_banned = false;          // it measured slower than the windows in this call
+        double win_rate = 0.0;            // points per millisecond of the last batch of windows (wall clock)
+        c.stat_seq_points = 0;
+        auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
         // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
         const int Rmax = R;
@@ -823,6 +839,36 @@ int cc_online_run(cc_handle* h)
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
             const Table tab = h->tab.view();
+            if (seq_on) {
+                const int chunk = 8192;
+                const double t0 = now_ms();
+                hipLaunchKernelGGL(k_seq, dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk);
+                HIPCHK(hipGetLastError());
+                pull_ctl(h);
+                const double dt = now_ms() - t0;
+                const long long got = h->hc.cursor - done;
+                done = h->hc.cursor;
+                m_known = h->hc.m_rows;
+                seq_host = h->hc.window_seq;
+                rows_prev = h->hc.m_rows; cursor_prev = h->hc.cursor;
+                const double seq_rate = got > 0 ? (double)got / std::max(dt, 1e-3) : 0.0;
+                if (h->trace)
+                    fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms\n", done, h->hc.m_rows, got, dt);
+                const bool full = !seq_possible() || (got < chunk && done < N);
+                const bool slower = seq_mode != 2 && win_rate > 0.0 && got >= 1024 && seq_rate < win_rate;
+                if ((full || slower) && done < N) {
+                    // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
+                    seq_on = false;
+                    seq_banned = slower;
+                    HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
+                    h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
+                    nodirty = false;
+                    set_lookahead(la_forced);
+                    push_ctl(h);
+                }
+                continue;
+            }
+            const double batch_t0 = now_ms();
             const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, 0};
             const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
@@ -950,6 +996,11 @@ int cc_online_run(cc_handle* h)
             pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_on ? (double)world : 1.0);
             pair_rows_prev = h->hc.stat_pair_rows;
             {
+                const double dt = now_ms() - batch_t0;
+                const long long pts_b = h->hc.cursor - cursor_prev;
+                if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
+            }
+            {
                 int used = 1;
                 for (int r = 1; r <= CC_MAX_ROUNDS; ++r) {
                     if (h->hc.round_hist[r] - hist_prev[r] > 0) used = r;
@@ -1038,6 +1089,12 @@ int cc_online_run(cc_handle* h)
                                                                                   : h->tun.windows_per_sync;
                 if (want < fast_below && trunc_batch == 0) batch_windows = 2;
                 first_batch = false;
+                // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back
+                // if it measures slower than this batch did)
+                if (seq_mode == 0 && !seq_banned && seq_possible() && trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024 &&
+                    done < N)
+                    seq_on = true;
+                if (seq_mode == 2 && seq_possible() && done < N) seq_on = true;
             }
         }
         HIPCHK(hipEventRecord(ev1, h->stream));
@@ -1052,6 +1109,8 @@ int cc_online_run(cc_handle* h)
         h->stats.rows = h->hc.m_rows;
         h->stats.scan_pair_dims = pair_rows_eff * (double)h->d;
         h->stats.sharded_windows = sharded_windows;
+        h->stats.seq_points = h->hc.stat_seq_points;
+        h->seq_sticky = seq_on;
         h->stats.table_rows_scanned = h->hc.stat_table_rows;
         h->stats.lookahead_windows = h->hc.stat_lookahead;
         if (timing) {

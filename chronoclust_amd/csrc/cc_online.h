@@ -2188,6 +2188,214 @@ __global__ __launch_bounds__(256) void k_apply_carry(const CommitRec* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------
+// k_seq: the reference's loop taken literally (hddstream.py:220-237), for streams on which speculation does not pay:
+// a handful of microclusters absorb every point (the bundled d0-d4 data: 2-15 pcore MCs), so the chains of a window
+// are hundreds of points long, decisions keep moving and windows commit a few hundred points per validation pass.
+// One wavefront walks the points in order with the whole table in LDS (structure of arrays, row = lane-strided):
+//   per point: lanes take the rows r = lane, lane + 64, ...: projected distance to the pcore rows (with the
+//   tentative-add pdim filter when pi < d), wave argmin by (distance, list-order key) through DPP row operations,
+//   tentative add of the winner with lane = dimension (two IEEE divisions per dimension side by side), ordered
+//   radius sum, commit into LDS; only if that fails the same over the outlier rows (+ promotion), else a new row.
+// No speculation, nothing to validate: ~0.2-0.4 us per point whatever the data.  The host uses it while the table
+// fits the LDS image (seq_cap_rows) and the windows of the speculative path keep being cut short; both paths are
+// exact, so switching between them between windows never changes a result.
+// ---------------------------------------------------------------------------------
+
+#define CC_SEQ_DOUBLES 7000  // LDS image of the table: (4 d + 4) doubles per row
+
+__host__ __device__ inline int cc_seq_cap_rows(int d) { return CC_SEQ_DOUBLES / (4 * d + 4); }
+
+__device__ __forceinline__ double cc_readlane_f64(double v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// minimum over the wavefront (no NaN among the operands), the same value in every lane
+__device__ __forceinline__ double cc_wave_min_f64(double x)
+{
+    x = cc_vmin(x, cc_dpp_f64<0xB1>(x));   // quad_perm [1,0,3,2]
+    x = cc_vmin(x, cc_dpp_f64<0x4E>(x));   // quad_perm [2,3,0,1]
+    x = cc_vmin(x, cc_dpp_f64<0x141>(x));  // row_half_mirror
+    x = cc_vmin(x, cc_dpp_f64<0x140>(x));  // row_mirror: every lane of a row of 16 holds the row's minimum
+    const double a = cc_readlane_f64(x, 0), b = cc_readlane_f64(x, 16), c = cc_readlane_f64(x, 32), e = cc_readlane_f64(x, 48);
+    const double ab = a < b ? a : b, ce = c < e ? c : e;
+    return ab < ce ? ab : ce;
+}
+
+__global__ __launch_bounds__(64) void k_seq(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                            long long* __restrict__ lab_uid, int8_t* __restrict__ lab_path, int n_max)
+{
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
+    const int lane = threadIdx.x;
+    const int cap = cc_seq_cap_rows(d);
+    int M = ctl->m_rows;
+    if (M > cap) return;  // (the host checks the same bound)
+    const long long cursor0 = ctl->cursor;
+    long long left = ctl->n_points - cursor0;
+    const int n = (int)(left < (long long)n_max ? left : (long long)n_max);
+    if (n <= 0) return;
+    int n_pkeys = ctl->n_pkeys, n_okeys = ctl->n_okeys;
+    long long pcore_last_id = ctl->pcore_last_id, outlier_last_id = ctl->outlier_last_id;
+    const bool filter = par.filter != 0;
+
+    __shared__ __attribute__((aligned(16))) double s_tab[CC_SEQ_DOUBLES];
+    __shared__ double s_p[64];
+    double* const Lcf1 = s_tab;
+    double* const Lcf2 = Lcf1 + (size_t)d * cap;
+    double* const Lcen = Lcf2 + (size_t)d * cap;
+    double* const Lpref = Lcen + (size_t)d * cap;
+    double* const Lw = Lpref + (size_t)d * cap;
+    int* const Lkind = reinterpret_cast<int*>(Lw + cap);
+    int* const Lkey = Lkind + cap;
+    long long* const Lid = reinterpret_cast<long long*>(Lw + 2 * (size_t)cap);
+    long long* const Luid = Lid + cap;
+
+    for (int r = lane; r < M; r += 64) {
+        for (int i = 0; i < d; ++i) {
+            Lcf1[i * cap + r] = tab.cf1[(size_t)r * d + i]; Lcf2[i * cap + r] = tab.cf2[(size_t)r * d + i];
+            Lcen[i * cap + r] = tab.cen[(size_t)r * d + i]; Lpref[i * cap + r] = tab.pref[(size_t)r * d + i];
+        }
+        Lw[r] = tab.w[r]; Lkind[r] = tab.kind[r]; Lkey[r] = tab.key[r]; Lid[r] = tab.id[r]; Luid[r] = tab.uid[r];
+    }
+    double next_p = (lane < d) ? X[cursor0 * d + lane] : 0.0;
+    CC_WAVE_SYNC();
+
+    int done = 0;
+    for (int j = 0; j < n; ++j) {
+        const double myp = next_p;  // this lane's dimension of point j
+        if (j + 1 < n) next_p = (lane < d) ? X[(cursor0 + j + 1) * d + lane] : 0.0;  // in flight while j is processed
+        CC_WAVE_SYNC();  // (every lane is done with the previous point's s_p and table rows)
+        s_p[lane] = myp;
+        CC_WAVE_SYNC();
+
+        int target = -1, path = 2;
+        bool promoted = false;
+        // stage 0: _add_to_pcore (hddstream.py:288-343), stage 1: _add_to_outlier (:345-395)
+        for (int stage = 0; stage < 2 && target < 0; ++stage) {
+            const int want = stage == 0 ? CC_KIND_PCORE : CC_KIND_OUTLIER;
+            double bd = CC_INF;
+            int bk = CC_IDX_INF, br = -1;
+            for (int r = lane; r < M; r += 64) {
+                if (Lkind[r] != want) continue;
+                if (stage == 0 && filter) {
+                    // hddstream.py:317-321: pdim of the MC with the point added must be <= pi
+                    const double w1 = Lw[r] + 1.0;
+                    int ne1 = 0;
+                    for (int i = 0; i < d; ++i) {
+                        const double x = s_p[i];
+                        const double c1 = Lcf1[i * cap + r] + x, c2 = Lcf2[i * cap + r] + x * x;
+                        const double var = cc_sqvar(c1, c2, w1);
+                        ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                    }
+                    if (ne1 > par.pi) continue;
+                }
+                double acc = 0.0;
+                for (int i = 0; i < d; ++i) {
+                    double x = s_p[i] - Lcen[i * cap + r];          // mc_functions.py:37
+                    x = x * x;                                      // :38
+                    acc = acc + cc_div_pref(x, Lpref[i * cap + r], par);  // :39 + :41, left to right
+                }
+                const int key = Lkey[r];
+                if (cand_less(acc, key, bd, bk)) { bd = acc; bk = key; br = r; }  // strict <, first in list order wins (:326/:373)
+            }
+            // wave argmin by (distance, key): the minimum distance, then the smallest key among the lanes that hold it
+            const double D = cc_wave_min_f64(bd);
+            unsigned long long tied = __builtin_amdgcn_ballot_w64(br >= 0 && bd == D);
+            if (tied == 0ull) continue;  // no (admissible) MC of this kind
+            int wl = __builtin_ctzll(tied);
+            if (tied & (tied - 1ull)) {
+                int best_key = CC_IDX_INF;
+                for (unsigned long long m = tied; m; m &= m - 1ull) {
+                    const int l = __builtin_ctzll(m);
+                    const int k2 = __builtin_amdgcn_readlane(bk, l);
+                    if (k2 < best_key) { best_key = k2; wl = l; }
+                }
+            }
+            const int R = __builtin_amdgcn_readlane(br, wl);
+            // tentative add (microcluster.py:213-233) with lane = dimension, then the radius test (:334-337 / :378-381)
+            const double w1 = Lw[R] + 1.0;
+            double c1 = 0.0, c2 = 0.0, qb = 0.0, pr = 1.0, term = 0.0;
+            if (lane < d) {
+                c1 = Lcf1[lane * cap + R] + myp;
+                c2 = Lcf2[lane * cap + R] + myp * myp;
+                const double qa = c2 / w1;
+                qb = c1 / w1;
+                const double var = qa - qb * qb;
+                pr = (var <= par.delta_sq) ? par.k : 1.0;
+                term = cc_div_pref(var, pr, par);
+            }
+            double r2 = 0.0;
+            for (int i = 0; i < d; ++i) r2 = r2 + cc_readlane_f64(term, i);  // mc_functions.py:54, left to right
+            if (!(r2 <= par.eps_sq)) continue;
+            if (lane < d) {
+                Lcf1[lane * cap + R] = c1; Lcf2[lane * cap + R] = c2; Lcen[lane * cap + R] = qb; Lpref[lane * cap + R] = pr;
+            }
+            if (lane == 0) Lw[R] = w1;
+            target = R;
+            path = stage;
+            if (stage == 1) {
+                // hddstream.py:416-430
+                const int gt1 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < d && pr > 1.0));
+                if (w1 >= par.beta_mu && gt1 <= par.pi) {
+                    promoted = true;
+                    if (lane == 0) { Lkind[R] = CC_KIND_PCORE; Lkey[R] = n_pkeys; Lid[R] = pcore_last_id; }
+                    n_pkeys += 1;
+                    pcore_last_id += 1;
+                }
+            }
+        }
+        if (target < 0) {
+            // hddstream.py:434-462: a new outlier MC holding this point (an add to an empty MC)
+            if (M >= cap) break;  // the LDS image is full: the host continues with the windowed path
+            const int R = M;
+            if (lane < d) {
+                const double c1 = 0.0 + myp, c2 = 0.0 + myp * myp;
+                const double qa = c2 / 1.0, qb = c1 / 1.0;
+                const double var = qa - qb * qb;
+                Lcf1[lane * cap + R] = c1; Lcf2[lane * cap + R] = c2; Lcen[lane * cap + R] = qb;
+                Lpref[lane * cap + R] = (var <= par.delta_sq) ? par.k : 1.0;
+            }
+            if (lane == 0) {
+                Lw[R] = 0.0 + 1.0; Lkind[R] = CC_KIND_OUTLIER; Lkey[R] = n_okeys; Lid[R] = outlier_last_id; Luid[R] = outlier_last_id;
+            }
+            n_okeys += 1;
+            outlier_last_id += 1;
+            M += 1;
+            target = R;
+            path = 2;
+        }
+        CC_WAVE_SYNC();
+        if (lane == 0) {
+            lab_uid[cursor0 + j] = Luid[target];
+            lab_path[cursor0 + j] = (int8_t)(path | (promoted ? 4 : 0));
+        }
+        done = j + 1;
+    }
+    CC_WAVE_SYNC();
+    // the table image back to HBM (every column the windowed path reads, scl included)
+    for (int r = lane; r < M; r += 64) {
+        for (int i = 0; i < d; ++i) {
+            const double pr = Lpref[i * cap + r];
+            tab.cf1[(size_t)r * d + i] = Lcf1[i * cap + r]; tab.cf2[(size_t)r * d + i] = Lcf2[i * cap + r];
+            tab.cen[(size_t)r * d + i] = Lcen[i * cap + r]; tab.pref[(size_t)r * d + i] = pr;
+            tab.scl[(size_t)r * d + i] = par.pow2 ? (pr == 1.0 ? 1.0 : par.inv_k) : pr;
+        }
+        tab.w[r] = Lw[r]; tab.kind[r] = Lkind[r]; tab.key[r] = Lkey[r]; tab.id[r] = Lid[r]; tab.uid[r] = Luid[r];
+    }
+    if (lane == 0) {
+        ctl->cursor = cursor0 + done;
+        ctl->m_rows = M;
+        ctl->n_pkeys = n_pkeys; ctl->n_okeys = n_okeys;
+        ctl->pcore_last_id = pcore_last_id; ctl->outlier_last_id = outlier_last_id;
+        ctl->window_seq += 1ull;  // stamps and carry marks of earlier windows are history
+        ctl->mode = 0; ctl->car_n = 0;
+        ctl->stat_seq_points += done;
+    }
+}
+
 // dimension-major copy of the points for the scan's coalesced loads: xt[i * n + r] = x[r * d + i]
 __global__ void k_transpose_points(const double* __restrict__ x, double* __restrict__ xt, long long n, int d)
 {

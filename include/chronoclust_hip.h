@@ -82,6 +82,10 @@ typedef struct cc_tuning {
     int32_t lookahead;       /* 0 / 1: scan the next window on a second stream
                               * while this one is validated, as long as windows
                               * commit in full (default); 2: off; 3: always      */
+    int32_t sequential;      /* the one-wavefront sequential kernel for small tables:
+                              * 0 when the speculative windows keep being cut
+                              * short and it measures faster (default); 1 never;
+                              * 2 whenever the table fits its LDS image           */
 } cc_tuning;
 
 typedef struct cc_stats {
@@ -99,7 +103,8 @@ typedef struct cc_stats {
     int64_t sharded_windows; /* windows whose snapshot scan was split over the ranks (multi-GPU) */
     int64_t comm_launches;   /* merge + all-gather steps timed (time_kernels = 1)  */
     double  comm_ms;         /* sum of their HIP-event durations                  */
-    int64_t reserved[2];
+    int64_t seq_points;      /* points taken by the sequential kernel             */
+    int64_t reserved[1];
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
