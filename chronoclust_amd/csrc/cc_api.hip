@@ -759,6 +759,8 @@ int cc_online_run(cc_handle* h)
         c.stat_unprovable = c.stat_unsafe = 0;
         c.stat_trunc_unknown = 0;
         c.stat_table_rows = 0;
+        c.stat_seq_points = 0;
+        c.stat_seq_clk = c.stat_seq_wall = 0;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         const bool la_forced = h->tun.lookahead == 3;                    // from the first window on, whatever happens (tests)
         const bool la_enabled = h->tun.lookahead != 2;                   // 0 (default) and 1: while windows commit in full
@@ -819,9 +821,13 @@ int cc_online_run(cc_handle* h)
         const int seq_cap = cc_seq_cap_rows(h->d);
         auto seq_possible = [&]() { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; };
         bool seq_on = seq_possible() && (seq_mode == 2 || h->seq_sticky);
-        bool seq_banned = false;          // it measured slower than the windows in this call
-        double win_rate = 0.0;            // points per millisecond of the last batch of windows (wall clock)
-        c.stat_seq_points = 0;
+        // default policy: the sequential kernel takes over after two batches in a row whose windows were cut short
+        // at a few hundred points; it works in stints (32 k points, doubling), after each of which one batch of
+        // windows is run again and the two measured rates decide who continues
+        int bad_batches = 0;              // consecutive batches of short, truncated windows
+        long long seq_stint_len = 32768, seq_stint_left = seq_stint_len;
+        bool seq_probe = false;           // the batch of windows in flight is a probe after a sequential stint
+        double win_rate = 0.0, seq_rate_last = 0.0;  // points per millisecond (wall clock) of the last batch / chunk
         auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
         // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
@@ -842,7 +848,15 @@ int cc_online_run(cc_handle* h)
             if (seq_on) {
                 const int chunk = 8192;
                 const double t0 = now_ms();
-                hipLaunchKernelGGL(k_seq, dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk);
+                {
+                    const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
+#define CC_SEQ(F, P) hipLaunchKernelGGL((k_seq<F, P>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk)
+                    if (f && p2) CC_SEQ(true, true);
+                    else if (f) CC_SEQ(true, false);
+                    else if (p2) CC_SEQ(false, true);
+                    else CC_SEQ(false, false);
+#undef CC_SEQ
+                }
                 HIPCHK(hipGetLastError());
                 pull_ctl(h);
                 const double dt = now_ms() - t0;
@@ -853,13 +867,17 @@ int cc_online_run(cc_handle* h)
                 rows_prev = h->hc.m_rows; cursor_prev = h->hc.cursor;
                 const double seq_rate = got > 0 ? (double)got / std::max(dt, 1e-3) : 0.0;
                 if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms\n", done, h->hc.m_rows, got, dt);
+                    fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms (so far %lld shader cycles, %.3f ms of kernel time)\n",
+                            done, h->hc.m_rows, got, dt, (long long)h->hc.stat_seq_clk, (double)h->hc.stat_seq_wall / 1e5);
+                if (got >= 1024) seq_rate_last = seq_rate;
+                seq_stint_left -= got;
                 const bool full = !seq_possible() || (got < chunk && done < N);
-                const bool slower = seq_mode != 2 && win_rate > 0.0 && got >= 1024 && seq_rate < win_rate;
-                if ((full || slower) && done < N) {
+                const bool stint_over = seq_mode != 2 && seq_stint_left <= 0;
+                if ((full || stint_over) && done < N) {
                     // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
                     seq_on = false;
-                    seq_banned = slower;
+                    seq_probe = stint_over && !full;
+                    bad_batches = 0;
                     HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
                     h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
                     nodirty = false;
@@ -1091,10 +1109,27 @@ int cc_online_run(cc_handle* h)
                 first_batch = false;
                 // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back
                 // if it measures slower than this batch did)
-                if (seq_mode == 0 && !seq_banned && seq_possible() && trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024 &&
-                    done < N)
-                    seq_on = true;
-                if (seq_mode == 2 && seq_possible() && done < N) seq_on = true;
+                {
+                    const bool bad = trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024;
+                    bad_batches = bad ? bad_batches + 1 : 0;
+                    if (seq_mode == 0 && seq_possible() && done < N) {
+                        if (seq_probe) {
+                            // after a stint: back to the sequential kernel (for twice as long) only if the windows
+                            // are still being cut short and were measurably slower
+                            if (bad && seq_rate_last > 0.0 && win_rate < seq_rate_last) {
+                                seq_on = true;
+                                seq_stint_len = std::min<long long>(seq_stint_len * 2, 1 << 20);
+                            } else {
+                                seq_stint_len = 32768;
+                            }
+                        } else if (bad_batches >= 2 && !(seq_rate_last > 0.0 && win_rate >= seq_rate_last)) {
+                            seq_on = true;
+                        }
+                        if (seq_on) seq_stint_left = seq_stint_len;
+                    }
+                    seq_probe = false;
+                    if (seq_mode == 2 && seq_possible() && done < N) seq_on = true;
+                }
             }
         }
         HIPCHK(hipEventRecord(ev1, h->stream));

@@ -170,6 +170,7 @@ struct Ctl {
     long long stat_unprovable, stat_unsafe;  // points whose live versions k_dseed could not locate / that needed the dirty scans
     long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
     long long stat_seq_points;               // points taken by the sequential kernel (k_seq)
+    long long stat_seq_clk, stat_seq_wall;   // ... its shader-clock cycles / constant 100 MHz ticks (trace)
 };
 
 // Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole
