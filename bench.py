@@ -200,6 +200,15 @@ def main():
                     help="seconds after which a one-stream leg that has not finished is abandoned")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints its path when a communicator is
+    # created) and anything else that writes to file descriptor 1 during the run go to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     from chronoclust_amd import multi
     rank, world, local_rank = multi.rank_info()
     import torch
@@ -332,7 +341,7 @@ def main():
                 return
             if rank == 0:
                 out["one_stream_exact"] = {"error": "not finished after %.0f s, abandoned" % args.stream_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         timer = threading.Timer(args.stream_timeout, abandon)
@@ -347,7 +356,7 @@ def main():
         if rank == 0:
             out["one_stream_exact"] = leg
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

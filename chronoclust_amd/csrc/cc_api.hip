@@ -1122,7 +1122,9 @@ int cc_online_run(cc_handle* h)
                             } else {
                                 seq_stint_len = 32768;
                             }
-                        } else if (bad_batches >= 2 && !(seq_rate_last > 0.0 && win_rate >= seq_rate_last)) {
+                        } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : 700.0)) {
+                            // (700 points per millisecond: what k_seq delivers whatever the data, until it has been measured
+                            // in this call; the short windows of a stream that is merely starting up run faster than that)
                             seq_on = true;
                         }
                         if (seq_on) seq_stint_left = seq_stint_len;
