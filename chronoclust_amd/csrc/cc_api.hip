@@ -364,17 +364,11 @@ Versions versions_view(cc_handle* h)
 
 // ---- scan dispatch over the padded dimensionality ---------------------------------
 
-// waves per scan workgroup: as many as the LDS budget of the padded dimensionality allows
-template <int DP>
-struct ScanWaves {
-    static constexpr int value = 4;  // 8 waves halve the partials but measured 5 % slower on C2
-};
-
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
                     int mode, int shard_rank, int shard_world)
 {
-    constexpr int NW = ScanWaves<DP>::value;
+    constexpr int NW = ScanShape<DP, DIRTY>::NW;
     const dim3 block(64 * NW);
     constexpr int TILE = 64 * ScanShape<DP, DIRTY>::PT;  // window points per workgroup
     const dim3 grid((win + TILE - 1) / TILE, S);
@@ -415,7 +409,12 @@ void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* c
 #undef CC_SCAN_DP
 }
 
-int scan_waves_for_dim(int) { return 4; }
+// waves per workgroup of the scans at dimensionality d (the host turns `segments` sub-ranges into partials per point)
+int scan_waves_for_dim(int d, bool dirty)
+{
+    if (dirty) return 4;
+    return (d > 16 && d <= 20) ? ScanShape<20, false>::NW : 4;
+}
 
 hipEvent_t get_event(cc_handle* h, size_t i)
 {
@@ -705,8 +704,9 @@ int cc_online_run(cc_handle* h)
         const long long N = h->n_points;
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
-        const int S = std::max(1, h->tun.segments / scan_waves_for_dim(h->d));
-        const int Sd_full = h->tun.dirty_segments > 0 ? std::max(1, h->tun.dirty_segments / scan_waves_for_dim(h->d)) : S;
+        const int S = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
+        const int Sd_full = std::max(1, (h->tun.dirty_segments > 0 ? h->tun.dirty_segments : h->tun.segments) /
+                                            scan_waves_for_dim(h->d, true));
         // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
         // few workgroups per point tile then, the full split while they really run (set per batch below)
         int Sd = Sd_full;
