@@ -60,27 +60,6 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
 };
 
-// page-locked host buffer for device -> host copies that sit on the step's critical path
-struct PinBuf {
-    void* p = nullptr;
-    size_t n = 0;
-    void* ensure(size_t bytes)
-    {
-        if (bytes > n) {
-            if (p) (void)hipHostFree(p);
-            p = nullptr;
-            n = 0;
-            HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
-            n = bytes;
-        }
-        return p;
-    }
-    ~PinBuf() { if (p) (void)hipHostFree(p); }
-    PinBuf() = default;
-    PinBuf(const PinBuf&) = delete;
-    PinBuf& operator=(const PinBuf&) = delete;
-};
-
 struct TableStore {
     DevBuf<double> cf1, cf2, cen, pref, scl, w;
     DevBuf<int> kind, key;
@@ -174,7 +153,8 @@ struct cc_handle {
     // offline results
     DevBuf<double> pv_cf1, pv_cf2, pv_cen, pv_pref, pv_w, wvec;
     DevBuf<long long> pv_id;
-    DevBuf<int> prow, nn, pdim, mem_dev, off_dev;
+    DevBuf<int> prow, nn, pdim, mem_dev, off_dev, nw_cnt, nw_nbr;
+    DevBuf<long long> nw_off;
     DevBuf<int8_t> core;
     DevBuf<unsigned long long> adj, adjw;
     DevBuf<double> c_cf1, c_cf2, c_cen, c_pref, c_w;
@@ -188,7 +168,6 @@ struct cc_handle {
     DevBuf<int> flags;
 
     std::vector<hipEvent_t> ev_pool;
-    PinBuf pin_adj;  // offline phase: weighted-reachability bitmask
 
     // exact multi-GPU path: this handle is rank comm.rank of comm.world replicas of one stream
     cc::Comm comm;
@@ -1446,32 +1425,40 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         }
         hipLaunchKernelGGL(k_pdim, dim3((mp + 255) / 256), dim3(256), 0, h->stream, h->wvec.p, mp, d, h->pdim.p);
         if (my_rows > 0)
-            hipLaunchKernelGGL(k_weighted_reach, dim3(words, my_rows), dim3(64), 0, h->stream, pv.cen, h->wvec.p, h->adj.p,
-                               h->adjw.p, words, mp, d, p.ups_eps_sq, p_lo);
+            hipLaunchKernelGGL(k_weighted_reach, dim3(my_rows), dim3(64), 0, h->stream, pv.cen, h->wvec.p, h->adj.p,
+                               h->adjw.p, words, mp, d, p.ups_eps_sq, p_lo, p_hi);
         if (shard)
             h->comm.all_gather(h->adjw.p + (size_t)rank * share * words, h->adjw.p, (size_t)share * words * 8, h->stream);
+        // the reachability rows as neighbour lists: counts -> offsets (host prefix sums) -> ascending positions
+        h->nw_cnt.ensure(mp);
+        hipLaunchKernelGGL(k_adj_counts, dim3(mp), dim3(64), 0, h->stream, h->adjw.p, words, mp, h->nw_cnt.p);
         std::vector<int8_t> core(mp);
-        std::vector<int> pdim(mp), nn(mp);
-        unsigned long long* const adjw = static_cast<unsigned long long*>(h->pin_adj.ensure((size_t)mp * words * 8));
+        std::vector<int> pdim(mp), nn(mp), nw_cnt(mp);
         h->pcore_ids_host.resize(mp);
         HIPCHK(hipMemcpyAsync(core.data(), h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(pdim.data(), h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(adjw, h->adjw.p, (size_t)mp * words * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(nw_cnt.data(), h->nw_cnt.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->pcore_ids_host.data(), h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipGetLastError());
+        std::vector<long long> nw_off((size_t)mp + 1, 0);
+        for (int i = 0; i < mp; ++i) nw_off[(size_t)i + 1] = nw_off[i] + nw_cnt[i];
+        const long long n_edges = nw_off[mp];
+        std::vector<int> nbr((size_t)std::max<long long>(n_edges, 1));
+        if (n_edges > 0) {
+            h->nw_off.ensure((size_t)mp + 1);
+            h->nw_nbr.ensure((size_t)n_edges);
+            HIPCHK(hipMemcpyAsync(h->nw_off.p, nw_off.data(), ((size_t)mp + 1) * 8, hipMemcpyHostToDevice, h->stream));
+            hipLaunchKernelGGL(k_adj_fill, dim3(mp), dim3(64), 0, h->stream, h->adjw.p, words, mp, h->nw_off.p, h->nw_nbr.p);
+            HIPCHK(hipMemcpyAsync(nbr.data(), h->nw_nbr.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            HIPCHK(hipGetLastError());
+        }
 
         // ---- ordered expansion on the host: predecon.py:62-120, 242-267 (integer / graph work only) ----
-        auto for_each_nw = [&](int q, auto&& fn) {
-            for (int wd = 0; wd < words; ++wd) {
-                unsigned long long m = adjw[(size_t)q * words + wd];
-                while (m) {
-                    const int b = __builtin_ctzll(m);
-                    m &= m - 1;
-                    fn(wd * 64 + b);
-                }
-            }
+        auto for_each_nw = [&](int q, auto&& fn) {  // the weighted neighbours of q in ascending (= dict) order
+            for (long long e = nw_off[q]; e < nw_off[(size_t)q + 1]; ++e) fn(nbr[(size_t)e]);
         };
         std::vector<int8_t> cls(mp, 0);  // 0 'u', 1 'c', 2 'n'
         std::vector<int> queue;
@@ -1520,13 +1507,7 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         if (out_core) memcpy(out_core, core.data(), mp);
         if (out_pdim) memcpy(out_pdim, pdim.data(), (size_t)mp * 4);
         if (out_nn) memcpy(out_nn, nn.data(), (size_t)mp * 4);
-        if (out_nw) {
-            for (int i = 0; i < mp; ++i) {
-                int cnt = 0;
-                for (int wd = 0; wd < words; ++wd) cnt += __builtin_popcountll(adjw[(size_t)i * words + wd]);
-                out_nw[i] = cnt;
-            }
-        }
+        if (out_nw) memcpy(out_nw, nw_cnt.data(), (size_t)mp * 4);
         if (n_clusters) *n_clusters = nc;
         return (int)CC_OK;
     });

@@ -196,34 +196,88 @@ __global__ void k_pdim(const double* __restrict__ wvec, int mp, int d, int* __re
     pdim[p] = cnt;
 }
 
-// K8: predecon.py:155-159, 219-239 + predeconmc_functions.py:44-62 on the eps-neighbour pairs
+// K8: predecon.py:155-159, 219-239 + predeconmc_functions.py:44-62 on the eps-neighbour pairs.  One wavefront per p:
+// the words of p's eps-neighbour row are read 64 at a time (coalesced) and only the non-empty ones - a handful per row
+// when the MCs are well separated - are evaluated, lane = q; every word of the output row is written (zeros included).
 __global__ __launch_bounds__(64) void k_weighted_reach(const double* __restrict__ cen, const double* __restrict__ wvec,
                                                        const unsigned long long* __restrict__ adj,
                                                        unsigned long long* __restrict__ adjw, int words, int mp,
-                                                       int d, double eps_sq, int p_base)
+                                                       int d, double eps_sq, int p_base, int p_end)
 {
-    const int p = p_base + blockIdx.y;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    const unsigned long long nb = adj[(size_t)p * words + blockIdx.x];
-    bool in = false;
-    if (q < mp && ((nb >> threadIdx.x) & 1ull)) {
-        double dpq = 0.0, dqp = 0.0;
-        for (int i = 0; i < d; ++i) {
-            const double a = cen[(size_t)p * d + i], b = cen[(size_t)q * d + i];
-            double t = a - b;
-            t = t * t;
-            t = wvec[(size_t)p * d + i] * t;
-            dpq = dpq + t;
-            double u = b - a;
-            u = u * u;
-            u = wvec[(size_t)q * d + i] * u;
-            dqp = dqp + u;
+    const int p = p_base + blockIdx.x;
+    if (p >= p_end) return;
+    const int lane = threadIdx.x;
+    for (int w0 = 0; w0 < words; w0 += 64) {
+        const int wd = w0 + lane;
+        const unsigned long long nb = (wd < words) ? adj[(size_t)p * words + wd] : 0ull;
+        unsigned long long res = 0ull;
+        for (unsigned long long todo = __builtin_amdgcn_ballot_w64(nb != 0ull); todo; todo &= todo - 1ull) {
+            const int l = __builtin_ctzll(todo);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nb & 0xFFFFFFFFull), l);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(nb >> 32), l);
+            const unsigned long long bits = ((unsigned long long)hi << 32) | lo;
+            const int q = (w0 + l) * 64 + lane;
+            bool in = false;
+            if (q < mp && ((bits >> lane) & 1ull)) {
+                double dpq = 0.0, dqp = 0.0;
+                for (int i = 0; i < d; ++i) {
+                    const double a = cen[(size_t)p * d + i], b = cen[(size_t)q * d + i];
+                    double t = a - b;
+                    t = t * t;
+                    t = wvec[(size_t)p * d + i] * t;
+                    dpq = dpq + t;
+                    double u = b - a;
+                    u = u * u;
+                    u = wvec[(size_t)q * d + i] * u;
+                    dqp = dqp + u;
+                }
+                const double dist = dpq > dqp ? dpq : dqp;  // Python max(a, b): b only if b > a
+                in = dist <= eps_sq;
+            }
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+            if (lane == l) res = mask;
         }
-        const double dist = dpq > dqp ? dpq : dqp;  // Python max(a, b): b only if b > a
-        in = dist <= eps_sq;
+        if (wd < words) adjw[(size_t)p * words + wd] = res;
     }
-    const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
-    if (threadIdx.x == 0) adjw[(size_t)p * words + blockIdx.x] = mask;
+}
+
+// The weighted-reachability rows as neighbour lists (what the ordered expansion on the host walks): per p the number
+// of set bits, then - offsets being the host's prefix sums - the set bit positions in ascending order.  One wavefront
+// per p in both kernels.
+__global__ __launch_bounds__(64) void k_adj_counts(const unsigned long long* __restrict__ adjw, int words, int mp,
+                                                   int* __restrict__ cnt)
+{
+    const int p = blockIdx.x;
+    if (p >= mp) return;
+    int c = 0;
+    for (int wd = threadIdx.x; wd < words; wd += 64) c += __builtin_popcountll(adjw[(size_t)p * words + wd]);
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if (threadIdx.x == 0) cnt[p] = c;
+}
+
+__global__ __launch_bounds__(64) void k_adj_fill(const unsigned long long* __restrict__ adjw, int words, int mp,
+                                                 const long long* __restrict__ off, int* __restrict__ nbr)
+{
+    const int p = blockIdx.x;
+    if (p >= mp) return;
+    const int lane = threadIdx.x;
+    long long base = off[p];
+    for (int w0 = 0; w0 < words; w0 += 64) {
+        const int wd = w0 + lane;
+        unsigned long long m = (wd < words) ? adjw[(size_t)p * words + wd] : 0ull;
+        const int mine = __builtin_popcountll(m);
+        int incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        long long pos = base + incl - mine;
+        while (m) {
+            nbr[pos++] = wd * 64 + __builtin_ctzll(m);
+            m &= m - 1ull;
+        }
+        base += __shfl(incl, 63);
+    }
 }
 
 // predecon_mc.py:50-68 merge_mc in merge order + predecon.py:80 update_preferred_dimensions.
