@@ -109,7 +109,7 @@ if __name__ == "__main__":
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from golden_util import GOLDEN, StateDump
             dump = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
-            extra = {k.lower(): int(v) for k, v in os.environ.items() if k in ("LOOKAHEAD", "SEGMENTS", "ROUNDS")}
+            extra = {k.lower(): int(v) for k, v in os.environ.items() if k in ("LOOKAHEAD", "SEGMENTS", "ROUNDS", "SEQUENTIAL")}
             run("c1", scenarios.params_to_config(scenarios.C1_PARAMS), [dump.get(t, "X") for t in range(5)],
                 window=int(os.environ.get("WINDOW", "1024")), **extra)
     except Exception:
