@@ -123,6 +123,7 @@ struct cc_handle {
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
+    int n_cus = 256;            // compute units of the device (hipDeviceProp_t::multiProcessorCount)
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -388,6 +389,37 @@ void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* c
 #undef CC_SCAN_DP
 }
 
+// workgroups of the clean scan that are resident at once (compute units x workgroups per CU it is compiled for)
+int scan_resident_wgs(const cc_handle* h)
+{
+    const int d = h->d;
+    int per_cu;
+    if (d <= 4) per_cu = ScanShape<4, false>::WGS;
+    else if (d <= 8) per_cu = ScanShape<8, false>::WGS;
+    else if (d <= 14) per_cu = ScanShape<14, false>::WGS;
+    else if (d <= 16) per_cu = ScanShape<16, false>::WGS;
+    else if (d <= 20) per_cu = ScanShape<20, false>::WGS;
+    else if (d <= 32) per_cu = ScanShape<32, false>::WGS;
+    else if (d <= 40) per_cu = ScanShape<40, false>::WGS;
+    else per_cu = ScanShape<64, false>::WGS;
+    return h->n_cus * per_cu;
+}
+
+// Partials per point for a batch whose windows have `tiles` point tiles: at most S, not less than S / 2, chosen so that
+// the launch (tiles x S' workgroups) fills whole rounds of the resident workgroups - 1 024 workgroups on a machine that
+// holds 768 at once (d = 40) run as long as 1 536 would.
+int scan_partials_for(int tiles, int S, int resident)
+{
+    int best = S;
+    double best_eff = 0.0;
+    for (int s = S; s >= std::max(1, S / 2); --s) {
+        const double x = (double)tiles * s / (double)resident;
+        const double eff = x / std::ceil(x);
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
 // waves per workgroup of the scans at dimensionality d (the host turns `segments` sub-ranges into partials per point)
 int scan_waves_for_dim(int d, bool dirty)
 {
@@ -458,6 +490,8 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
         h->badflag.ensure(1);
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
         memset(&h->hc, 0, sizeof(Ctl));
         h->tun.window = 24576;
         h->tun.rounds = 3;
@@ -683,12 +717,13 @@ int cc_online_run(cc_handle* h)
         const long long N = h->n_points;
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
-        const int S = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
+        const int S_cfg = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
         const int Sd_full = std::max(1, (h->tun.dirty_segments > 0 ? h->tun.dirty_segments : h->tun.segments) /
                                             scan_waves_for_dim(h->d, true));
         // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
         // few workgroups per point tile then, the full split while they really run (set per batch below)
         int Sd = Sd_full;
+        const int S = S_cfg;  // (refined per batch below)
         // While k_dseed rules the dirty scans out for every tile they are not launched at all (beside a lookahead scan
         // even a launch whose workgroups all return at once waits for registers until the scan has dispatched its last
         // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
@@ -875,6 +910,9 @@ int cc_online_run(cc_handle* h)
             ev_sync = ev_base;
             // grids cover the window size of this batch (no window of the batch is larger), not the configured maximum
             const int gw = std::max(64, std::min(win, h->hc.win_cfg));
+            // partials per point of this batch's clean scans (a pending lookahead scan was launched with the same value:
+            // it only depends on the window size, and a change of that restarts the lookahead chain)
+            const int S = scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h));
             const int dblocks = (gw + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
             const int cblocks = (gw + 7) / 8;
             const int rblocks = std::min((gw + 7) / 8, 1024);

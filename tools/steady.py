@@ -11,7 +11,7 @@ import bench  # noqa: E402
 from chronoclust_amd import _lib  # noqa: E402
 
 if __name__ == "__main__":
-    n, d, g = 1_000_000, 20, 5000
+    n, d, g = int(os.environ.get("N", 1_000_000)), int(os.environ.get("D", 20)), int(os.environ.get("G", 5000))
     X = bench.make_blobs(42, n, d, g)
     cfg = bench.blob_config(n)
     h = _lib.Handle(0)
