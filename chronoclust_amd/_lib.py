@@ -38,6 +38,11 @@ class CcStats(C.Structure):
                 ("comm_ms", C.c_double), ("seq_points", C.c_int64), ("reserved", C.c_int64 * 1)]
 
 
+class CcRelaxedStats(C.Structure):
+    _fields_ = [("super_steps", C.c_int64), ("minibatch_points", C.c_int64), ("deferred_points", C.c_int64),
+                ("reserved", C.c_int64 * 5)]
+
+
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -80,6 +85,8 @@ SYMBOLS = {
     "cc_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "cc_comm_destroy": (C.c_int, [C.c_void_p]),
     "cc_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
+    "cc_comm_set_relaxed": (C.c_int, [C.c_void_p, C.c_int32]),
+    "cc_get_relaxed_stats": (C.c_int, [C.c_void_p, C.POINTER(CcRelaxedStats)]),
     "cc_shard_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
     "cc_set_shard_thresholds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
 }
@@ -330,6 +337,16 @@ class Handle(object):
         r, w, t = C.c_int32(), C.c_int32(), C.c_int32()
         self._check(self._lib.cc_comm_info(self._h, C.byref(r), C.byref(w), C.byref(t)))
         return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "local"}[t.value])
+
+    def comm_set_relaxed(self, minibatch_points):
+        """RELAXED multi-GPU mode (events sharded over the ranks, CF deltas all-reduced per super-step of
+        `minibatch_points` points per rank; not the reference's semantics).  0: back to the exact path."""
+        self._check(self._lib.cc_comm_set_relaxed(self._h, int(minibatch_points)))
+
+    def relaxed_stats(self):
+        s = CcRelaxedStats()
+        self._check(self._lib.cc_get_relaxed_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in CcRelaxedStats._fields_ if k != "reserved"}
 
     def set_shard_thresholds(self, min_row_dims=-1, offline_min_rows=-1):
         self._check(self._lib.cc_set_shard_thresholds(self._h, int(min_row_dims), int(offline_min_rows)))

@@ -179,6 +179,17 @@ struct cc_handle {
     DevBuf<Cand> gsend, gpart;  // one merged record per window point (two parities) / the gathered records of all ranks
     size_t gsend_stride = 0, gpart_stride = 0;
     DevBuf<int> g_i32;          // gather scratch of the offline phase
+
+    // relaxed multi-GPU mode (events sharded over the ranks): points per rank and super-step (0: the exact path)
+    int relaxed_minibatch = 0;
+    bool shard_suspended = false;  // inside a relaxed super-step the ranks cluster different points: no split scans
+    DevBuf<double> rs_cf1, rs_cf2, rs_w, r_delta, r_gather;   // snapshot of the shared table, deltas, all-reduce scratch
+    DevBuf<int> rs_kind, rs_key, r_didx, r_didx_all;
+    DevBuf<long long> rs_id;
+    DevBuf<double> rg_X, rg_Xt;                               // the set-aside points of a super-step, gathered
+    DevBuf<long long> rg_uid;
+    DevBuf<int8_t> rg_path;
+    cc_relaxed_stats rstats{};
 };
 
 namespace {
@@ -709,12 +720,150 @@ int cc_points_download(cc_handle* h, double* out, const double* scale, const dou
     });
 }
 
-int cc_online_run(cc_handle* h)
+}  // extern "C"
+
+namespace {
+
+int online_range(cc_handle* h, long long range_a, long long range_e, bool no_create, bool resume);
+
+// sum over the ranks of buf[0 .. count), the same result on every rank, ordered on `st`
+void comm_all_reduce_sum(cc_handle* h, double* buf, size_t count, hipStream_t st)
 {
-    if (!h) return CC_ERR_BAD_ARG;
-    if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
-    return guarded(h, [&]() {
-        const long long N = h->n_points;
+    cc::Comm& cm = h->comm;
+    if (cm.nccl) {
+        cm.check(cc::RcclApi::get().AllReduce(buf, buf, count, ncclDouble, ncclSum, cm.nccl, st), "ncclAllReduce");
+        return;
+    }
+    if (!cm.local || cm.world == 1) return;
+    h->r_gather.ensure((size_t)cm.world * count);
+    cm.all_gather(buf, h->r_gather.p, count * 8, st);
+    hipLaunchKernelGGL(k_sum_ranks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, h->r_gather.p, cm.world, count, buf);
+}
+
+// Relaxed multi-GPU mode: the points of the timepoint are sharded over the ranks in contiguous blocks; per super-step
+// every rank clusters `relaxed_minibatch` of its points against the shared table (exact path, no MC creation), the CF
+// changes are all-reduced, and the set-aside points of all ranks are clustered redundantly on every rank (exact path).
+int online_relaxed(cc_handle* h)
+{
+    const long long N = h->n_points;
+    const int W = h->comm.world, rank = h->comm.rank, d = h->d;
+    if (N == 0) return (int)CC_OK;
+    if (d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
+    const long long L = (N + W - 1) / W;  // shard length
+    const long long a0 = std::min(N, (long long)rank * L), e0 = std::min(N, a0 + L);
+    const long long b = h->relaxed_minibatch;
+    const long long steps = (L + b - 1) / b;
+    hipStream_t st = h->stream;
+    memset(&h->rstats, 0, sizeof(h->rstats));
+    struct Suspend {  // (restored on every way out)
+        cc_handle* h;
+        explicit Suspend(cc_handle* hh) : h(hh) { h->shard_suspended = true; }
+        ~Suspend() { h->shard_suspended = false; }
+    } suspend(h);
+    // labels: room for every rank's padded shard (the final all-gather is in place); -1 = not clustered yet
+    if (h->lab_uid.n < (size_t)(L * W)) { h->lab_uid.ensure((size_t)(L * W)); h->lab_path.ensure((size_t)(L * W)); }
+    HIPCHK(hipMemsetAsync(h->lab_uid.p, 0xFF, (size_t)(L * W) * 8, st));
+    HIPCHK(hipMemsetAsync(h->lab_path.p, 0, (size_t)(L * W), st));
+    h->r_didx.ensure((size_t)b + 1);
+    h->r_didx_all.ensure((size_t)W * (b + 1));
+    std::vector<int> didx_host((size_t)W * (b + 1)), list;
+    for (long long sidx = 0; sidx < steps; ++sidx) {
+        const long long a = std::min(e0, a0 + sidx * b), e = std::min(e0, a + b);
+        // ---- snapshot of the table all ranks share ----
+        refresh_ctl_params(h);
+        const int M = h->hc.m_rows;
+        const int n_pkeys0 = h->hc.n_pkeys;
+        const long long pid0 = h->hc.pcore_last_id;
+        const size_t md = (size_t)M * d, dl = (size_t)M * (2 * d + 1);
+        if (M > 0) {
+            h->rs_cf1.ensure(md); h->rs_cf2.ensure(md); h->rs_w.ensure(M); h->rs_kind.ensure(M); h->rs_key.ensure(M);
+            h->rs_id.ensure(M); h->r_delta.ensure(dl);
+            HIPCHK(hipMemcpyAsync(h->rs_cf1.p, h->tab.cf1.p, md * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->rs_cf2.p, h->tab.cf2.p, md * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->rs_w.p, h->tab.w.p, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->rs_kind.p, h->tab.kind.p, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->rs_key.p, h->tab.key.p, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(h->rs_id.p, h->tab.id.p, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
+        }
+        // ---- A: this rank's mini-batch, no MC creation ----
+        int rc = online_range(h, a, e, true, sidx > 0);
+        if (rc != CC_OK) return rc;
+        if (h->hc.m_rows != M) return fail(h, CC_ERR_INTERNAL, "relaxed mode: a mini-batch created microclusters");
+        // ---- M: merge the changes of the existing rows ----
+        if (M > 0) {
+            const Table tab = h->tab.view();  // (online_range may have moved the table)
+            hipLaunchKernelGGL(k_rel_delta, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, st, tab, h->rs_cf1.p, h->rs_cf2.p,
+                               h->rs_w.p, M, d, h->r_delta.p);
+            comm_all_reduce_sum(h, h->r_delta.p, dl, st);
+            hipLaunchKernelGGL(k_rel_merge, dim3((unsigned)((md + 255) / 256)), dim3(256), 0, st, tab, h->rs_cf1.p, h->rs_cf2.p,
+                               h->rs_w.p, h->rs_kind.p, h->rs_key.p, h->rs_id.p, M, d, h->r_delta.p, h->hc.delta_sq, h->hc.k,
+                               h->hc.pow2, h->hc.inv_k);
+            hipLaunchKernelGGL(k_rel_promote, dim3(1), dim3(1024), 0, st, h->ctl.p, tab, M, d, h->r_delta.p, h->hc.beta_mu,
+                               h->hc.pi, n_pkeys0, pid0);
+        }
+        // ---- B: the set-aside points of all ranks, in rank order, on every rank ----
+        hipLaunchKernelGGL(k_rel_collect, dim3(1), dim3(1024), 0, st, h->lab_uid.p, a, e, h->r_didx.p);
+        h->comm.all_gather(h->r_didx.p, h->r_didx_all.p, (size_t)(b + 1) * 4, st);
+        HIPCHK(hipMemcpyAsync(didx_host.data(), h->r_didx_all.p, didx_host.size() * 4, hipMemcpyDeviceToHost, st));
+        pull_ctl(h);  // (synchronises the stream; the counters k_rel_promote left)
+        list.clear();
+        for (int r = 0; r < W; ++r) {
+            const int* blk = didx_host.data() + (size_t)r * (b + 1);
+            list.insert(list.end(), blk + 1, blk + 1 + blk[0]);
+        }
+        h->rstats.super_steps += 1;
+        h->rstats.minibatch_points += e - a;
+        const long long K = (long long)list.size();
+        if (K > 0) {
+            h->rstats.deferred_points += K;
+            h->r_didx_all.ensure((size_t)std::max<long long>((long long)W * (b + 1), K));
+            HIPCHK(hipMemcpyAsync(h->r_didx_all.p, list.data(), (size_t)K * 4, hipMemcpyHostToDevice, st));
+            h->rg_X.ensure((size_t)K * d); h->rg_Xt.ensure((size_t)K * d); h->rg_uid.ensure((size_t)K); h->rg_path.ensure((size_t)K);
+            hipLaunchKernelGGL(k_rel_gather_points, dim3((unsigned)(((size_t)K * d + 255) / 256)), dim3(256), 0, st, h->X.p,
+                               h->r_didx_all.p, (int)K, d, h->rg_X.p);
+            hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)(((size_t)K * d + 255) / 256)), dim3(256), 0, st, h->rg_X.p,
+                               h->rg_Xt.p, K, d);
+            // the gathered points take the place of the resident ones for one exact run
+            auto swap_in = [&]() {
+                std::swap(h->X.p, h->rg_X.p); std::swap(h->X.n, h->rg_X.n);
+                std::swap(h->Xt.p, h->rg_Xt.p); std::swap(h->Xt.n, h->rg_Xt.n);
+                std::swap(h->lab_uid.p, h->rg_uid.p); std::swap(h->lab_uid.n, h->rg_uid.n);
+                std::swap(h->lab_path.p, h->rg_path.p); std::swap(h->lab_path.n, h->rg_path.n);
+            };
+            swap_in();
+            h->n_points = K;
+            try {
+                rc = online_range(h, 0, K, false, false);
+            } catch (...) {
+                swap_in();
+                h->n_points = N;
+                throw;
+            }
+            swap_in();
+            h->n_points = N;
+            if (rc != CC_OK) return rc;
+            hipLaunchKernelGGL(k_rel_scatter_labels, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, h->rg_uid.p,
+                               h->rg_path.p, h->r_didx_all.p, (int)K, h->lab_uid.p, h->lab_path.p);
+        }
+    }
+    // every rank's shard of the labels to every rank (in place, shards padded to the same length)
+    h->comm.all_gather(h->lab_uid.p + (size_t)rank * L, h->lab_uid.p, (size_t)L * 8, st);
+    h->comm.all_gather(h->lab_path.p + (size_t)rank * L, h->lab_path.p, (size_t)L, st);
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    h->stats.points = N;
+    return (int)CC_OK;
+}
+
+// The exact windowed online phase over the resident points [range_a, range_e), in row order.  no_create: a point that
+// no MC absorbs does not create one; it is set aside (label -1, path code 8) and changes nothing - the first half of a
+// super-step of the relaxed multi-GPU mode (section 6 of DESIGN.md).  Statistics are added to h->stats.
+// resume: the range continues a stream this handle was clustering a moment ago (a later mini-batch of a timepoint): the
+// window size carries over as it is instead of restarting small.
+int online_range(cc_handle* h, long long range_a, long long range_e, bool no_create, bool resume)
+{
+    {
+        const long long N = range_e;
         const int win = h->tun.window, R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
         const int S_cfg = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
@@ -729,8 +878,7 @@ int cc_online_run(cc_handle* h)
         // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
         // if that stops a window at its first point, and the next batch launches them again.
         bool nodirty = false;
-        memset(&h->stats, 0, sizeof(h->stats));
-        if (N == 0) return (int)CC_OK;
+        if (range_e <= range_a) return (int)CC_OK;
         if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
         refresh_ctl_params(h);
         ensure_window_buffers(h, win, std::max(S, Sd_full));
@@ -740,7 +888,9 @@ int cc_online_run(cc_handle* h)
         const int world = h->comm.world, myrank = h->comm.rank;
         // (a communicator of one rank takes the same path: that is how the RCCL calls are exercised on one GPU)
         const bool grouped = h->comm.active();
-        auto want_shard = [&](int m_rows) { return grouped && (long long)m_rows * h->d >= h->shard_min_row_dims; };
+        auto want_shard = [&](int m_rows) {
+            return grouped && !h->shard_suspended && (long long)m_rows * h->d >= h->shard_min_row_dims;
+        };
         if (grouped) {
             h->gsend_stride = (size_t)h->win_alloc * 4;
             h->gpart_stride = (size_t)world * h->win_alloc * 4;
@@ -752,17 +902,19 @@ int cc_online_run(cc_handle* h)
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * batch_max + 1);
 
         Ctl& c = h->hc;
-        c.cursor = 0;
+        c.cursor = range_a;
         c.n_points = N;
+        c.xt_stride = h->n_points;
+        c.no_create = no_create ? 1 : 0;
         const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
         // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
         const int start_small = 256;
         const int fast_below = 4096;  // below this size a clean batch quadruples the window (and batches are two windows)
         // (a new timepoint begins with whatever changed since the last one - decayed weights, new populations -, which
         // takes a few validation rounds per window: not with the largest window the previous one ended on)
-        if (h->adapt_win > 0) c.win_cfg = std::min(win, std::min(h->adapt_win, early0));
+        if (h->adapt_win > 0) c.win_cfg = std::min(win, resume ? h->adapt_win : std::min(h->adapt_win, early0));
         else c.win_cfg = std::min(win, (c.m_rows < 1024) ? start_small : early0);
-        c.win_b = (int)std::min<long long>(c.win_cfg, N);
+        c.win_b = (int)std::min<long long>(c.win_cfg, N - range_a);
         c.max_rounds = R;
         c.last_round = 0;
         c.fc[0] = 0;
@@ -825,7 +977,7 @@ int cc_online_run(cc_handle* h)
         size_t ev_sync = ev_base;
         ev_used = ev_base + 3 * (batch_max + 2);
 
-        long long done = 0;
+        long long done = range_a;
         int m_known = c.m_rows;
         // The sequential kernel (k_seq) for streams on which speculation does not pay: used while the table fits its
         // LDS image and either the caller forces it or (default) the windows keep being cut short and it measures
@@ -847,7 +999,7 @@ int cc_online_run(cc_handle* h)
         // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
         const int Rmax = R;
         int Rcur = R;
-        long long rows_prev = c.m_rows, cursor_prev = 0, windows_prev = 0, trunc_batch = 0;
+        long long rows_prev = c.m_rows, cursor_prev = range_a, windows_prev = 0, trunc_batch = 0;
         bool first_batch = true;
         int batch_windows = (c.win_cfg < 1024) ? 2 : std::max(2, h->tun.windows_per_sync / 4);
         const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
@@ -1155,18 +1307,18 @@ int cc_online_run(cc_handle* h)
         HIPCHK(hipEventSynchronize(ev1));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
-        h->stats.run_ms = ms;
-        h->stats.points = N;
-        h->stats.windows = h->hc.stat_windows;
-        h->stats.rounds = h->hc.stat_rounds;
-        h->stats.truncated = h->hc.stat_truncated;
+        h->stats.run_ms += ms;
+        h->stats.points += range_e - range_a;
+        h->stats.windows += h->hc.stat_windows;
+        h->stats.rounds += h->hc.stat_rounds;
+        h->stats.truncated += h->hc.stat_truncated;
         h->stats.rows = h->hc.m_rows;
-        h->stats.scan_pair_dims = pair_rows_eff * (double)h->d;
-        h->stats.sharded_windows = sharded_windows;
-        h->stats.seq_points = h->hc.stat_seq_points;
+        h->stats.scan_pair_dims += pair_rows_eff * (double)h->d;
+        h->stats.sharded_windows += sharded_windows;
+        h->stats.seq_points += h->hc.stat_seq_points;
         h->seq_sticky = seq_on;
-        h->stats.table_rows_scanned = h->hc.stat_table_rows;
-        h->stats.lookahead_windows = h->hc.stat_lookahead;
+        h->stats.table_rows_scanned += h->hc.stat_table_rows;
+        h->stats.lookahead_windows += h->hc.stat_lookahead;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {
@@ -1174,18 +1326,33 @@ int cc_online_run(cc_handle* h)
                 HIPCHK(hipEventElapsedTime(&e, h->ev_pool[t.first], h->ev_pool[t.first + 1]));
                 tot += e;
             }
-            h->stats.scan_launches = (int64_t)timed.size();
-            h->stats.scan_ms = tot;
+            h->stats.scan_launches += (int64_t)timed.size();
+            h->stats.scan_ms += tot;
             double ctot = 0.0;
             for (size_t i : timed_comm) {
                 float e = 0.f;
                 HIPCHK(hipEventElapsedTime(&e, h->ev_pool[i], h->ev_pool[i + 1]));
                 ctot += e;
             }
-            h->stats.comm_launches = (int64_t)timed_comm.size();
-            h->stats.comm_ms = ctot;
+            h->stats.comm_launches += (int64_t)timed_comm.size();
+            h->stats.comm_ms += ctot;
         }
         return (int)CC_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int cc_online_run(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    if (!h->have_par) return fail(h, CC_ERR_BAD_ARG, "cc_set_params has not been called");
+    return guarded(h, [&]() {
+        memset(&h->stats, 0, sizeof(h->stats));
+        if (h->relaxed_minibatch > 0 && h->comm.active()) return online_relaxed(h);
+        return online_range(h, 0, h->n_points, false, false);
     });
 }
 
@@ -1749,6 +1916,21 @@ int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport
     if (rank) *rank = h->comm.rank;
     if (world) *world = h->comm.world;
     if (transport) *transport = h->comm.nccl ? 1 : (h->comm.local ? 2 : 0);
+    return CC_OK;
+}
+
+int cc_comm_set_relaxed(cc_handle* h, int32_t minibatch_points)
+{
+    if (!h || minibatch_points < 0) return CC_ERR_BAD_ARG;
+    if (minibatch_points > 0 && !h->comm.active()) return fail(h, CC_ERR_BAD_ARG, "the relaxed mode needs a group (cc_comm_init_*)");
+    h->relaxed_minibatch = minibatch_points;
+    return CC_OK;
+}
+
+int cc_get_relaxed_stats(cc_handle* h, cc_relaxed_stats* out)
+{
+    if (!h || !out) return CC_ERR_BAD_ARG;
+    *out = h->rstats;
     return CC_OK;
 }
 

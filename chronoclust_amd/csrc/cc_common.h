@@ -9,6 +9,7 @@
 
 #define CC_MAX_ROUNDS 8
 #define CC_T_UNKNOWN (-2)
+#define CC_T_NONE (-3)  // relaxed multi-GPU mode: the point is set aside (no MC absorbs it and none may be created)
 #define CC_IDX_INF 0x7fffffff
 
 // One candidate of a per-point argmin: (distance, list-order key) ordered lexicographically
@@ -127,8 +128,11 @@ struct Rows {
 };
 
 struct Ctl {
-    long long cursor;    // points of this call already committed
-    long long n_points;  // N of this call
+    long long cursor;    // next point of the resident buffer to be committed
+    long long n_points;  // end of the range this call clusters
+    long long xt_stride; // rows of the resident buffer (column stride of its dimension-major copy)
+    int no_create;       // 1: points that no MC absorbs are set aside instead of creating one (CC_T_NONE)
+    int pad1;
     int d;
     int m_rows;          // table rows in use
     int n_pkeys, n_okeys;

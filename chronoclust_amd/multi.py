@@ -66,3 +66,30 @@ def all_ranks_equal(digest, dist):
     box = [None] * dist.get_world_size()
     dist.all_gather_object(box, digest)
     return all(b == box[0] for b in box)
+
+
+def label_agreement(labels, reference_labels):
+    """Agreement of two clusterings of the same points that may name their clusters differently: every cluster of
+    `labels` is matched to the cluster of `reference_labels` it shares most points with; returns the fraction of points
+    that fall into their cluster's match.  1.0 for identical partitions (whatever the ids), used to report how far the
+    relaxed multi-GPU mode is from the exact path."""
+    import numpy as np
+    a = np.asarray(labels)
+    b = np.asarray(reference_labels)
+    if a.shape != b.shape:
+        raise ValueError("label arrays differ in shape")
+    if a.size == 0:
+        return 1.0
+    _, ai = np.unique(a, return_inverse=True)
+    _, bi = np.unique(b, return_inverse=True)
+    na, nb = int(ai.max()) + 1, int(bi.max()) + 1
+    keys, counts = np.unique(ai.astype(np.int64) * nb + bi, return_counts=True)
+
+    def matched(group, n_groups):
+        best = np.zeros(n_groups, dtype=np.int64)
+        np.maximum.at(best, group, counts)
+        return float(best.sum()) / float(a.size)
+
+    # both directions: a clustering that merges two reference clusters loses in the first, one that splits a
+    # reference cluster loses in the second
+    return min(matched(keys // nb, na), matched(keys % nb, nb))

@@ -220,6 +220,26 @@ int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world);
 int cc_comm_init_local(cc_handle** handles, int world);
 int cc_comm_destroy(cc_handle* h);
 int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport);
+/* RELAXED multi-GPU mode - not the reference's semantics.  The events of a timepoint are sharded over the ranks in
+ * contiguous blocks (what BASELINE.json's north_star sketches: "events within a timestep shard across the GPUs with
+ * an RCCL all-reduce of the per-MC CF-vector deltas").  Per super-step every rank clusters `minibatch_points` of its
+ * block against the table all ranks share (exact path, but a point that no MC absorbs is set aside instead of
+ * creating one), the CF1 / CF2 / weight changes of the existing rows are all-reduced and written back with centroids
+ * and preferred dimensions recomputed and promotions decided on the merged rows, and the set-aside points of all
+ * ranks are clustered on every rank redundantly (exact path), so that new MCs are created once and all ranks keep
+ * identical tables.  Within a super-step a rank does not see the other ranks' adds: labels, ids and CF sums differ
+ * from the reference's; bench.py reports the agreement with the exact path beside the number.  Every rank must hold
+ * the whole timepoint (cc_points_upload of the same array); cc_labels_download returns all labels on every rank
+ * (path code 8 never remains: set-aside points are labelled by the second half of their super-step).
+ * minibatch_points = 0 switches back to the exact path. */
+int cc_comm_set_relaxed(cc_handle* h, int32_t minibatch_points);
+typedef struct cc_relaxed_stats {
+    int64_t super_steps;       /* of the last cc_online_run                                   */
+    int64_t minibatch_points;  /* points this rank clustered in the sharded halves             */
+    int64_t deferred_points;   /* set-aside points (all ranks) clustered in the replicated halves */
+    int64_t reserved[5];
+} cc_relaxed_stats;
+int cc_get_relaxed_stats(cc_handle* h, cc_relaxed_stats* out);
 /* The block [lo, hi) of n rows rank `rank` of `world` takes, in whole units of `unit` rows: the partition every
  * kernel of the multi-GPU path uses (unit 1: table rows of a scan, current pcores of the association argmin;
  * 64: rows of the offline pair matrices).  Pure host arithmetic, needs no handle and no GPU. */

@@ -115,3 +115,13 @@ def test_rounded_weights_equal_the_reference_expression():
     assert got == exp
     assert [str(g) for g in got] == [str(e) for e in exp]
     assert [g.as_tuple() for g in got] == [e.as_tuple() for e in exp]
+
+
+def test_label_agreement_is_symmetric_and_id_free():
+    import numpy as np
+    from chronoclust_amd import multi
+    a = np.array([5, 5, 7, 7, 7, 9])
+    assert multi.label_agreement(a, a + 100) == 1.0
+    assert multi.label_agreement(a, np.array([1, 1, 2, 2, 3, 3])) == multi.label_agreement(np.array([1, 1, 2, 2, 3, 3]), a)
+    assert multi.label_agreement(a, np.zeros(6, int)) == 0.5  # everything merged into one cluster: the largest of three
+    assert multi.label_agreement(np.arange(6), a) == 0.5      # everything split into singletons
