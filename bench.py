@@ -9,7 +9,10 @@ At N GPUs the headline `value` is N independent event streams of the C2 shape, o
 data-path collective: the online phase of one stream is a sequential chain over its points).  The same JSON line
 also carries `one_stream_exact`: ONE stream of the stress config's shape (d = 40, 50 000 microclusters) clustered by
 all N GPUs together - snapshot scans split by table rows, one RCCL all-gather of 64 B per window point, offline pair
-matrices split by rows - with a check that every rank ended with the same bytes.
+matrices split by rows - with a check that every rank ended with the same bytes, and
+`events_sharded_relaxed`: one stream of the WNV shape (d = 14, 2 000 microclusters) with its EVENTS sharded over the
+GPUs and an RCCL all-reduce of the CF deltas per super-step - relaxed semantics, reported with its agreement with the
+exact path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -172,6 +175,83 @@ def one_stream_exact(args, rank, world, local_rank, dist, sync):
     }
 
 
+def events_sharded_relaxed(args, rank, world, local_rank, dist, sync):
+    """ONE stream of the WNV shape (d = 14, 2 000 microclusters), its EVENTS sharded over the ranks: the relaxed mode
+    (cc_comm_set_relaxed).  Not the reference's semantics - the agreement with the exact path is reported beside the
+    rate (rank 0 runs the exact path on the same input after the timed region)."""
+    from chronoclust_amd import _lib, multi
+    n, d, g = args.relaxed_points, 14, 2000
+    X = make_blobs(777, n, d, g)
+    cfg = blob_config(n)
+    h = _lib.Handle(local_rank)
+    if world > 1:
+        multi.join_stream_group(h, dist)
+    else:
+        h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)  # a communicator of one rank: the same code path
+    h.comm_set_relaxed(args.relaxed_minibatch)
+    set_params(h, cfg, n, d)
+    h.points_upload(X)
+
+    def step():
+        h.reset()
+        h.online_run()
+        s = h.stats()
+        arrays, _ = h.offline_arrays()
+        return s, arrays
+
+    for _ in range(args.stream_warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.stream_steps):
+        s, arrays = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    rs = h.relaxed_stats()
+    dg = digest_of(h)
+    agree_ranks = multi.all_ranks_equal(dg, dist) if world > 1 else True
+    uid, _ = h.labels_download()
+    pc = h.export(_lib.PCORE)
+    pci = multi.point_cluster_index(uid, pc["id"], pc["uid"], arrays[0], arrays[1])
+    n_clusters = len(arrays[2])
+    h.comm_destroy()
+    h.close()
+    out = {
+        "workload": "C4-shaped: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters; its events sharded "
+                    "over %d rank(s) in contiguous blocks; online + offline phases per step" % (n, d, g, world),
+        "semantics": "RELAXED (not the reference's): per super-step of %d points per rank the ranks cluster against "
+                     "the shared table without seeing each other's adds, CF deltas are all-reduced, points that no "
+                     "MC absorbs are clustered on every rank redundantly" % args.relaxed_minibatch,
+        "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
+        "n_gpus": world, "steps": args.stream_steps, "warmup": args.stream_warmup,
+        "ms_per_step": 1e3 * elapsed / args.stream_steps,
+        "collective": "RCCL all-reduce (sum, f64) of [%d, 2 x %d + 1] CF deltas + all-gather of the set-aside point "
+                      "indices per super-step, %d super-steps per step" % (int(s["rows"]), d, rs["super_steps"]),
+        "microclusters": int(s["rows"]), "clusters": n_clusters,
+        "set_aside_points_per_step": rs["deferred_points"], "all_ranks_bit_identical": bool(agree_ranks),
+    }
+    if rank == 0:
+        # the exact path on the same input, one GPU: what the relaxed result is measured against
+        e = _lib.Handle(local_rank)
+        set_params(e, cfg, n, d)
+        e.points_upload(X)
+        t1 = time.perf_counter()
+        e.reset()
+        e.online_run()
+        e_arrays, _ = e.offline_arrays()
+        exact_s = time.perf_counter() - t1
+        e_uid, _ = e.labels_download()
+        e_pc = e.export(_lib.PCORE)
+        e_pci = multi.point_cluster_index(e_uid, e_pc["id"], e_pc["uid"], e_arrays[0], e_arrays[1])
+        out["exact_path_one_gpu_points_per_s"] = n / exact_s
+        out["agreement_with_exact_by_cluster"] = multi.label_agreement(pci, e_pci)
+        out["agreement_with_exact_by_microcluster"] = multi.label_agreement(uid, e_uid)
+        out["exact_clusters"] = len(e_arrays[2])
+        e.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +278,9 @@ def main():
     ap.add_argument("--stream-warmup", type=int, default=1)
     ap.add_argument("--stream-timeout", type=float, default=240.0,
                     help="seconds after which a one-stream leg that has not finished is abandoned")
+    ap.add_argument("--no-relaxed", action="store_true", help="skip the event-sharded relaxed leg")
+    ap.add_argument("--relaxed-points", type=int, default=5_000_000)
+    ap.add_argument("--relaxed-minibatch", type=int, default=65536, help="points per rank and super-step")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints its path when a communicator is
@@ -331,16 +414,21 @@ def main():
     h.close()
     del X
 
+    legs = []
     if not args.no_one_stream:
+        legs.append(("one_stream_exact", one_stream_exact))
+    if not args.no_relaxed:
+        legs.append(("events_sharded_relaxed", events_sharded_relaxed))
+    for name, fn in legs:
         # A collective that never completes must not take the headline measurement with it: every rank arms a
         # timer; if the leg is still running when it fires, rank 0 prints the line without it and all ranks leave.
         done = threading.Event()
 
-        def abandon():
+        def abandon(name=name, done=done):
             if done.is_set():
                 return
             if rank == 0:
-                out["one_stream_exact"] = {"error": "not finished after %.0f s, abandoned" % args.stream_timeout}
+                out[name] = {"error": "not finished after %.0f s, abandoned" % args.stream_timeout}
                 emit(out)
             os._exit(0)
 
@@ -348,13 +436,15 @@ def main():
         timer.daemon = True
         timer.start()
         try:
-            leg = one_stream_exact(args, rank, world, local_rank, dist, sync)
+            leg = fn(args, rank, world, local_rank, dist, sync)
         except Exception as e:  # noqa: BLE001 - reported in the line
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
         done.set()
         timer.cancel()
         if rank == 0:
-            out["one_stream_exact"] = leg
+            out[name] = leg
+        if "error" in leg and world > 1:
+            break  # the ranks may no longer be in step: no further collective legs
     if rank == 0:
         emit(out)
     if dist is not None:

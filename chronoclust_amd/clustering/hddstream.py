@@ -191,22 +191,10 @@ class HDDStream(object):
         app.py:303-332 derives from the per-MC `points` dicts; written as the literal None there)."""
         if self.labels_uid is None or getattr(self, "_cl_arrays", None) is None:
             return np.empty(0, np.int64)
+        from ..multi import point_cluster_index
         mem, off, *_ = self._cl_arrays
         pc = self.table(_lib.PCORE)
-        cluster_of_member = np.repeat(np.arange(len(off) - 1, dtype=np.int64), np.diff(off))
-        order = np.argsort(mem, kind="stable")
-        ids_sorted = mem[order]
-        pos = np.searchsorted(ids_sorted, pc["id"])
-        pos_c = np.clip(pos, 0, max(len(ids_sorted) - 1, 0))
-        hit = (pos < len(ids_sorted)) & (ids_sorted[pos_c] == pc["id"]) if len(ids_sorted) else np.zeros(len(pc["id"]), bool)
-        cluster_of_pcore = np.where(hit, cluster_of_member[order][pos_c] if len(ids_sorted) else -1, -1)
-        # microcluster uid -> cluster (outlier MCs: -1)
-        uo = np.argsort(pc["uid"], kind="stable")
-        uid_sorted = pc["uid"][uo]
-        q = np.searchsorted(uid_sorted, self.labels_uid)
-        q_c = np.clip(q, 0, max(len(uid_sorted) - 1, 0))
-        ok = (q < len(uid_sorted)) & (uid_sorted[q_c] == self.labels_uid) if len(uid_sorted) else np.zeros(len(self.labels_uid), bool)
-        return np.where(ok, cluster_of_pcore[uo][q_c] if len(uid_sorted) else -1, -1).astype(np.int64)
+        return point_cluster_index(self.labels_uid, pc["id"], pc["uid"], mem, off)
 
     def cluster_records(self):
         """The tracking-side records of this timepoint's clusters: what app.py:181-190 builds one by one -

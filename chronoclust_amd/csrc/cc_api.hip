@@ -832,15 +832,20 @@ int online_relaxed(cc_handle* h)
             };
             swap_in();
             h->n_points = K;
+            // (the window policy this rank's mini-batches settled on is not the business of the replicated half)
+            const int keep_win = h->adapt_win, keep_clean = h->clean_batches, keep_shrink = h->since_shrink;
+            auto restore_policy = [&]() { h->adapt_win = keep_win; h->clean_batches = keep_clean; h->since_shrink = keep_shrink; };
             try {
                 rc = online_range(h, 0, K, false, false);
             } catch (...) {
                 swap_in();
                 h->n_points = N;
+                restore_policy();
                 throw;
             }
             swap_in();
             h->n_points = N;
+            restore_policy();
             if (rc != CC_OK) return rc;
             hipLaunchKernelGGL(k_rel_scatter_labels, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, st, h->rg_uid.p,
                                h->rg_path.p, h->r_didx_all.p, (int)K, h->lab_uid.p, h->lab_path.p);

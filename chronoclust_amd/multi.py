@@ -93,3 +93,26 @@ def label_agreement(labels, reference_labels):
     # both directions: a clustering that merges two reference clusters loses in the first, one that splits a
     # reference cluster loses in the second
     return min(matched(keys // nb, na), matched(keys % nb, nb))
+
+
+def point_cluster_index(labels_uid, pcore_id, pcore_uid, cluster_members, cluster_offsets):
+    """For every point the index of the final cluster its microcluster belongs to, or -1 (outlier MCs, pcore MCs
+    outside every cluster): labels_uid[n] = creation number of the point's MC; pcore_id / pcore_uid = the pcore list;
+    cluster_members / cluster_offsets = member pcore ids of all clusters (cc_clusters_export)."""
+    import numpy as np
+    labels_uid = np.asarray(labels_uid)
+    mem, off = np.asarray(cluster_members), np.asarray(cluster_offsets)
+    pcore_id, pcore_uid = np.asarray(pcore_id), np.asarray(pcore_uid)
+    if len(labels_uid) == 0:
+        return np.empty(0, np.int64)
+    if len(pcore_id) == 0 or len(mem) == 0:
+        return np.full(len(labels_uid), -1, np.int64)
+    cluster_of_member = np.repeat(np.arange(len(off) - 1, dtype=np.int64), np.diff(off))
+    order = np.argsort(mem, kind="stable")
+    ids_sorted = mem[order]
+    pos = np.clip(np.searchsorted(ids_sorted, pcore_id), 0, len(ids_sorted) - 1)
+    cluster_of_pcore = np.where(ids_sorted[pos] == pcore_id, cluster_of_member[order][pos], -1)
+    uo = np.argsort(pcore_uid, kind="stable")
+    uid_sorted = pcore_uid[uo]
+    q = np.clip(np.searchsorted(uid_sorted, labels_uid), 0, len(uid_sorted) - 1)
+    return np.where(uid_sorted[q] == labels_uid, cluster_of_pcore[uo][q], -1).astype(np.int64)

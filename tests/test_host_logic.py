@@ -125,3 +125,15 @@ def test_label_agreement_is_symmetric_and_id_free():
     assert multi.label_agreement(a, np.array([1, 1, 2, 2, 3, 3])) == multi.label_agreement(np.array([1, 1, 2, 2, 3, 3]), a)
     assert multi.label_agreement(a, np.zeros(6, int)) == 0.5  # everything merged into one cluster: the largest of three
     assert multi.label_agreement(np.arange(6), a) == 0.5      # everything split into singletons
+
+
+def test_point_cluster_index_maps_points_through_microclusters_to_clusters():
+    import numpy as np
+    from chronoclust_amd import multi
+    # pcores (id, uid): (10, 0), (11, 1), (12, 2), (13, 7); clusters: [10, 12] and [11]; pcore 13 is in no cluster;
+    # uid 5 is an outlier MC
+    got = multi.point_cluster_index(np.array([0, 1, 2, 5, 1, 7]), np.array([10, 11, 12, 13]), np.array([0, 1, 2, 7]),
+                                    np.array([10, 12, 11]), np.array([0, 2, 3]))
+    assert got.tolist() == [0, 1, 0, -1, 1, -1]
+    assert multi.point_cluster_index(np.array([3, 4]), np.array([], int), np.array([], int), np.array([], int),
+                                     np.array([0])).tolist() == [-1, -1]
