@@ -184,7 +184,7 @@ struct cc_handle {
     int relaxed_minibatch = 0;
     bool shard_suspended = false;  // inside a relaxed super-step the ranks cluster different points: no split scans
     DevBuf<double> rs_cf1, rs_cf2, rs_w, r_delta, r_gather;   // snapshot of the shared table, deltas, all-reduce scratch
-    DevBuf<int> rs_kind, rs_key, r_didx, r_didx_all;
+    DevBuf<int> rs_kind, rs_key, r_didx, r_didx_all, r_cnt_all;
     DevBuf<long long> rs_id;
     DevBuf<double> rg_X, rg_Xt;                               // the set-aside points of a super-step, gathered
     DevBuf<long long> rg_uid;
@@ -752,7 +752,12 @@ int online_relaxed(cc_handle* h)
     const long long L = (N + W - 1) / W;  // shard length
     const long long a0 = std::min(N, (long long)rank * L), e0 = std::min(N, a0 + L);
     const long long b = h->relaxed_minibatch;
-    const long long steps = (L + b - 1) / b;
+    // Mini-batches grow from 2 048 points per rank by doubling: while the table is (nearly) empty every point is set
+    // aside and clustered by all ranks redundantly, so the first super-steps are kept small; the schedule depends on
+    // nothing but the shard length, hence is the same on every rank.
+    std::vector<long long> starts(1, 0);
+    for (long long sz = std::min<long long>(b, 2048); starts.back() < L; sz = std::min(b, sz * 2)) starts.push_back(std::min(L, starts.back() + sz));
+    const long long steps = (long long)starts.size() - 1;
     hipStream_t st = h->stream;
     memset(&h->rstats, 0, sizeof(h->rstats));
     struct Suspend {  // (restored on every way out)
@@ -768,7 +773,7 @@ int online_relaxed(cc_handle* h)
     h->r_didx_all.ensure((size_t)W * (b + 1));
     std::vector<int> didx_host((size_t)W * (b + 1)), list;
     for (long long sidx = 0; sidx < steps; ++sidx) {
-        const long long a = std::min(e0, a0 + sidx * b), e = std::min(e0, a + b);
+        const long long a = std::min(e0, a0 + starts[sidx]), e = std::min(e0, a0 + starts[sidx + 1]);
         // ---- snapshot of the table all ranks share ----
         refresh_ctl_params(h);
         const int M = h->hc.m_rows;
@@ -803,13 +808,24 @@ int online_relaxed(cc_handle* h)
         }
         // ---- B: the set-aside points of all ranks, in rank order, on every rank ----
         hipLaunchKernelGGL(k_rel_collect, dim3(1), dim3(1024), 0, st, h->lab_uid.p, a, e, h->r_didx.p);
-        h->comm.all_gather(h->r_didx.p, h->r_didx_all.p, (size_t)(b + 1) * 4, st);
-        HIPCHK(hipMemcpyAsync(didx_host.data(), h->r_didx_all.p, didx_host.size() * 4, hipMemcpyDeviceToHost, st));
+        // their numbers first (4 bytes per rank); the index lists only travel when there are any - in the steady state
+        // there are none
+        h->r_cnt_all.ensure((size_t)W);
+        h->comm.all_gather(h->r_didx.p, h->r_cnt_all.p, 4, st);
+        std::vector<int> cnt_host((size_t)W);
+        HIPCHK(hipMemcpyAsync(cnt_host.data(), h->r_cnt_all.p, (size_t)W * 4, hipMemcpyDeviceToHost, st));
         pull_ctl(h);  // (synchronises the stream; the counters k_rel_promote left)
+        long long total = 0;
+        for (int r = 0; r < W; ++r) total += cnt_host[r];
         list.clear();
-        for (int r = 0; r < W; ++r) {
-            const int* blk = didx_host.data() + (size_t)r * (b + 1);
-            list.insert(list.end(), blk + 1, blk + 1 + blk[0]);
+        if (total > 0) {  // (the same decision on every rank: the counts are the gathered ones)
+            h->comm.all_gather(h->r_didx.p, h->r_didx_all.p, (size_t)(b + 1) * 4, st);
+            HIPCHK(hipMemcpyAsync(didx_host.data(), h->r_didx_all.p, didx_host.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int r = 0; r < W; ++r) {
+                const int* blk = didx_host.data() + (size_t)r * (b + 1);
+                list.insert(list.end(), blk + 1, blk + 1 + blk[0]);
+            }
         }
         h->rstats.super_steps += 1;
         h->rstats.minibatch_points += e - a;

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}" || exit 1
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo "bench done"
-B="python bench.py --no-cpu-baseline --no-one-stream"
+B="python bench.py --no-cpu-baseline --no-one-stream --no-relaxed"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $B --steps 4 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 python tools/prof_summary.py $OUT/trace > $OUT/kernel_summary.txt
 echo "trace done"
