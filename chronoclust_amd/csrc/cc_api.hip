@@ -791,7 +791,11 @@ int online_relaxed(cc_handle* h)
             HIPCHK(hipMemcpyAsync(h->rs_id.p, h->tab.id.p, (size_t)M * 8, hipMemcpyDeviceToDevice, st));
         }
         // ---- A: this rank's mini-batch, no MC creation ----
+        const auto tA0 = std::chrono::steady_clock::now();
+        if (h->trace) HIPCHK(hipStreamSynchronize(st));
+        const auto tA1 = std::chrono::steady_clock::now();
         int rc = online_range(h, a, e, true, sidx > 0);
+        const auto tA2 = std::chrono::steady_clock::now();
         if (rc != CC_OK) return rc;
         if (h->hc.m_rows != M) return fail(h, CC_ERR_INTERNAL, "relaxed mode: a mini-batch created microclusters");
         // ---- M: merge the changes of the existing rows ----
@@ -826,6 +830,12 @@ int online_relaxed(cc_handle* h)
                 const int* blk = didx_host.data() + (size_t)r * (b + 1);
                 list.insert(list.end(), blk + 1, blk + 1 + blk[0]);
             }
+        }
+        if (h->trace) {
+            const auto tA3 = std::chrono::steady_clock::now();
+            auto ms = [](auto x, auto y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+            fprintf(stderr, "[cc] relaxed super-step %lld: %lld points | snapshot %.3f ms, sharded half %.3f ms, merge + collect %.3f ms, set aside %lld\n",
+                    sidx, e - a, ms(tA0, tA1), ms(tA1, tA2), ms(tA2, tA3), total);
         }
         h->rstats.super_steps += 1;
         h->rstats.minibatch_points += e - a;
