@@ -58,6 +58,7 @@ SYMBOLS = {
     "cc_set_params": (C.c_int, [C.c_void_p, C.POINTER(CcParams)]),
     "cc_decay_downgrade": (C.c_int, [C.c_void_p, C.c_double]),
     "cc_points_upload": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32]),
+    "cc_points_prefetch": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
     "cc_online_run": (C.c_int, [C.c_void_p]),
     "cc_col_minmax": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
     "cc_points_upload_scaled": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int32, _dp, _dp]),
@@ -203,6 +204,19 @@ class Handle(object):
             raise ValueError("points must be a 2-d array")
         self._check(self._lib.cc_points_upload(self._h, _ptr(x), x.shape[0], x.shape[1]))
         self._n = x.shape[0]
+
+    def points_prefetch(self, x, scale=None, min_=None):
+        """Starts the background upload of the NEXT timepoint's points (cc_points_prefetch).  `x` must be the very
+        array (C-contiguous float64) that is later passed to points_upload / points_upload_scaled / online; the
+        handle keeps a reference to it until then."""
+        if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags["C_CONTIGUOUS"] and x.ndim == 2):
+            raise ValueError("points_prefetch needs a C-contiguous float64 [n, d] array (it is not copied)")
+        if x.shape[0] == 0:
+            return
+        scale = None if scale is None else _f64(scale)
+        min_ = None if min_ is None else _f64(min_)
+        self._prefetched = (x, scale, min_)  # keeps the buffers alive while the worker reads them
+        self._check(self._lib.cc_points_prefetch(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(scale), _ptr(min_)))
 
     def col_minmax(self, x):
         """Per-column (min, max) of x, NaN ignored, reduced on the device."""

@@ -137,6 +137,18 @@ class HDDStream(object):
         self.last_data_timestamp = input_dataset_daystamp
         self.offline_clustering(input_dataset_daystamp)
 
+    def prefetch(self, input_dataset, device_scaling=None):
+        """Starts uploading the NEXT timepoint in the background (cc_points_prefetch) while the caller still works on the
+        current one.  Returns the array to pass to online_microcluster_maintenance (the same buffer, so that the upload
+        is recognised); results never depend on whether a timepoint was prefetched."""
+        X = np.ascontiguousarray(np.asarray(input_dataset, dtype=np.float64))
+        if X.ndim == 2 and X.shape[0] > 0:
+            if device_scaling is None:
+                self._h.points_prefetch(X)
+            else:
+                self._h.points_prefetch(X, device_scaling[0], device_scaling[1])
+        return X
+
     def offline_clustering(self, dataset_daystamp):
         self._push_params()
         self._cl_arrays, _ = self._h.offline_arrays()  # (members, offsets, w, cf1, cf2, cen, pref): all clusters

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <limits>
 #include <vector>
@@ -179,6 +180,25 @@ struct cc_handle {
     DevBuf<Cand> gsend, gpart;  // one merged record per window point (two parities) / the gathered records of all ranks
     size_t gsend_stride = 0, gpart_stride = 0;
     DevBuf<int> g_i32;          // gather scratch of the offline phase
+
+    // cc_points_prefetch: the next timepoint's points, uploaded by a worker thread through page-locked staging
+    struct Prefetch {
+        std::thread worker;
+        bool active = false;            // a worker was started and has not been adopted / discarded yet
+        const double* x = nullptr;      // what it uploads: pointer, shape, scaling (compared by the adopting upload)
+        long long n = 0;
+        int d = 0;
+        bool scaled = false;
+        std::vector<double> scale, mn;
+        DevBuf<double> X, Xt, sm;       // destination buffers (swapped with the handle's on adoption), scale / min
+        DevBuf<int> bad;
+        hipStream_t stream = nullptr;
+        void* pin[2] = {nullptr, nullptr};
+        size_t pin_bytes = 0;
+        int bad_host = 0;
+        int rc = 0;                     // hipError_t of the worker (0: fine)
+        const char* what = "";
+    } pf;
 
     // relaxed multi-GPU mode (events sharded over the ranks): points per rank and super-step (0: the exact path)
     int relaxed_minibatch = 0;
@@ -533,6 +553,10 @@ void cc_destroy(cc_handle* h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->pf.worker.joinable()) h->pf.worker.join();
+    if (h->pf.stream) (void)hipStreamDestroy(h->pf.stream);
+    for (int q = 0; q < 2; ++q)
+        if (h->pf.pin[q]) (void)hipHostFree(h->pf.pin[q]);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     h->comm.destroy();
@@ -657,10 +681,43 @@ int cc_col_minmax(cc_handle* h, const double* x, int64_t n, int32_t d, double* o
     });
 }
 
+// waits for a running prefetch; returns true if it finished without an error
+static bool prefetch_join(cc_handle* h)
+{
+    if (h->pf.worker.joinable()) h->pf.worker.join();
+    return h->pf.active && h->pf.rc == 0;
+}
+
+static void prefetch_discard(cc_handle* h)
+{
+    (void)prefetch_join(h);
+    h->pf.active = false;
+}
+
 static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn)
 {
     int rc = set_dim(h, d);
     if (rc != CC_OK) return rc;
+    if (h->pf.active) {
+        // the points may already be on their way (cc_points_prefetch): adopt them if it is this very upload
+        cc_handle::Prefetch& pf = h->pf;
+        bool same = pf.x == x && pf.n == n && pf.d == d && pf.scaled == (scale != nullptr);
+        for (int i = 0; same && scale && i < d; ++i) same = pf.scale[i] == scale[i] && pf.mn[i] == mn[i];
+        const bool ok = prefetch_join(h);
+        pf.active = false;
+        if (same && ok) {
+            std::swap(h->X.p, pf.X.p); std::swap(h->X.n, pf.X.n);
+            std::swap(h->Xt.p, pf.Xt.p); std::swap(h->Xt.n, pf.Xt.n);
+            h->lab_uid.ensure((size_t)n);
+            h->lab_path.ensure((size_t)n);
+            h->n_points = n;
+            if (pf.bad_host) {
+                h->n_points = 0;
+                return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
+            }
+            return (int)CC_OK;
+        }
+    }
     h->X.ensure((size_t)n * d);
     h->Xt.ensure((size_t)n * d);
     h->lab_uid.ensure((size_t)n);
@@ -689,6 +746,70 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
         return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
     }
     return (int)CC_OK;
+}
+
+int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* min_)
+{
+    if (!h || !x || n <= 0 || d <= 0 || d > CC_MAX_DIM || ((scale == nullptr) != (min_ == nullptr))) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        prefetch_discard(h);
+        cc_handle::Prefetch& pf = h->pf;
+        pf.x = x; pf.n = n; pf.d = d; pf.scaled = scale != nullptr;
+        pf.scale.assign(scale ? scale : x, scale ? scale + d : x);
+        pf.mn.assign(min_ ? min_ : x, min_ ? min_ + d : x);
+        pf.rc = 0; pf.what = ""; pf.bad_host = 0;
+        if (!pf.stream) HIPCHK(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
+        const size_t chunk = (size_t)16 << 20;
+        if (pf.pin_bytes < chunk) {
+            for (int q = 0; q < 2; ++q) {
+                if (pf.pin[q]) (void)hipHostFree(pf.pin[q]);
+                pf.pin[q] = nullptr;
+                HIPCHK(hipHostMalloc(&pf.pin[q], chunk, hipHostMallocDefault));
+            }
+            pf.pin_bytes = chunk;
+        }
+        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(1);
+        pf.active = true;
+        const int device = h->device;
+        pf.worker = std::thread([&pf, device, chunk]() {
+            auto chk = [&](hipError_t e, const char* what) {
+                if (e != hipSuccess && pf.rc == 0) { pf.rc = (int)e; pf.what = what; }
+                return e == hipSuccess;
+            };
+            if (!chk(hipSetDevice(device), "hipSetDevice")) return;
+            const size_t bytes = (size_t)pf.n * pf.d * 8;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            for (int q = 0; q < 2; ++q)
+                if (!chk(hipEventCreateWithFlags(&ev[q], hipEventDisableTiming), "hipEventCreate")) return;
+            int k = 0;
+            for (size_t off = 0; off < bytes && pf.rc == 0; off += chunk, k ^= 1) {
+                const size_t len = std::min(chunk, bytes - off);
+                if (off >= 2 * chunk) chk(hipEventSynchronize(ev[k]), "hipEventSynchronize");  // the staging buffer is free again
+                memcpy(pf.pin[k], (const char*)pf.x + off, len);
+                chk(hipMemcpyAsync((char*)pf.X.p + off, pf.pin[k], len, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
+                chk(hipEventRecord(ev[k], pf.stream), "hipEventRecord");
+            }
+            const long long tot = pf.n * (long long)pf.d;
+            if (pf.rc == 0) {
+                chk(hipMemsetAsync(pf.bad.p, 0, 4, pf.stream), "hipMemsetAsync");
+                if (pf.scaled) {
+                    chk(hipMemcpyAsync(pf.sm.p, pf.scale.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
+                    chk(hipMemcpyAsync(pf.sm.p + pf.d, pf.mn.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
+                    hipLaunchKernelGGL(k_scale_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, pf.stream, pf.X.p, tot,
+                                       pf.d, pf.sm.p, pf.sm.p + pf.d);
+                }
+                const int blocks = (int)std::min<long long>((tot + 255) / 256, 4096);
+                hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, pf.stream, pf.X.p, tot, pf.bad.p);
+                hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, pf.stream, pf.X.p, pf.Xt.p,
+                                   pf.n, pf.d);
+                chk(hipMemcpyAsync(&pf.bad_host, pf.bad.p, 4, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
+                chk(hipGetLastError(), "kernel launch");
+            }
+            chk(hipStreamSynchronize(pf.stream), "hipStreamSynchronize");
+            for (int q = 0; q < 2; ++q) (void)hipEventDestroy(ev[q]);
+        });
+        return (int)CC_OK;
+    });
 }
 
 int cc_points_upload_scaled(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* min_)

@@ -135,6 +135,13 @@ int cc_decay_downgrade(cc_handle* h, double factor);
  *                      2 new microcluster, |4 if the add promoted it
  *   cc_online        : the three of them in one call */
 int cc_points_upload(cc_handle* h, const double* x, int64_t n, int32_t d);
+/* Starts uploading the NEXT timepoint's points in the background (a worker thread copies them through page-locked
+ * staging buffers on a stream of its own, then scales / checks / transposes them), while the caller still works on
+ * the current timepoint (offline phase, trackers, writers - app.py:179-216).  scale / min_: as for
+ * cc_points_upload_scaled, or both NULL.  The next cc_points_upload / cc_points_upload_scaled (or cc_online) with the
+ * same pointer, shape and scaling adopts the result instead of copying; any other upload discards it.  x must stay
+ * valid and unchanged until then.  The clustering results do not depend on whether an upload was prefetched. */
+int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* min_);
 int cc_online_run(cc_handle* h);
 int cc_labels_download(cc_handle* h, int64_t* out_uid, int8_t* out_path);
 int cc_online(cc_handle* h, const double* x, int64_t n, int32_t d, int64_t* out_uid, int8_t* out_path);

@@ -301,3 +301,38 @@ def test_long_chains(g, window, lookahead):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
         _check_against_oracle(h, o)
+
+
+def test_prefetched_upload_changes_nothing():
+    """cc_points_prefetch: the next timepoint uploaded by a worker thread through page-locked staging while the current
+    one is processed.  Same labels / tables as plain uploads; a prefetch of other data is discarded; NaN in
+    prefetched data is reported by the upload that adopts it."""
+    sc = scenarios.BLOB_SCENARIOS["d20"]
+    cfg = scenarios.params_to_config(sc["params"])
+    Xs = scenarios.make_blob_timepoints(sc, raw=True)
+    plain, ahead = _hdd(cfg), _hdd(cfg)
+    held = ahead.prefetch(Xs[0])
+    for t in range(len(Xs)):
+        plain.online_microcluster_maintenance(Xs[t], t)
+        ahead.online_microcluster_maintenance(held, t)
+        if t + 1 < len(Xs):
+            held = ahead.prefetch(Xs[t + 1])
+            if t == 1:
+                ahead.prefetch(np.ascontiguousarray(Xs[0][:100]))  # replaced by another prefetch, never adopted
+                held = Xs[t + 1]                                     # plain upload of the right data
+        assert np.array_equal(plain.labels_uid, ahead.labels_uid)
+        for kind in (0, 1):
+            for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+                assert np.array_equal(plain.table(kind)[key], ahead.table(kind)[key])
+    bad = Xs[0].copy()
+    bad[17, 3] = np.nan
+    held = ahead.prefetch(bad)
+    with pytest.raises(ValueError):
+        ahead.online_microcluster_maintenance(held, 9)
+    scaled = ahead.prefetch(Xs[0] * 3.0, device_scaling=(np.full(20, 1 / 3.0), np.zeros(20)))
+    ahead._h.reset()
+    ahead.last_data_timestamp = 0
+    ahead.online_microcluster_maintenance(scaled, 0, device_scaling=(np.full(20, 1 / 3.0), np.zeros(20)))
+    ref = _hdd(cfg)
+    ref.online_microcluster_maintenance(Xs[0] * 3.0, 0, device_scaling=(np.full(20, 1 / 3.0), np.zeros(20)))
+    assert np.array_equal(ahead.labels_uid, ref.labels_uid)

@@ -131,3 +131,34 @@ def test_relaxed_group_of_one_rank_over_rccl():
     h._h.reset()
     h.online_microcluster_maintenance(X, 0)
     assert np.array_equal(h.labels_uid, exact.labels_uid)
+
+
+def test_c4_shaped_relaxed_two_ranks_against_exact():
+    """The WNV shape of BASELINE.json (d = 14, 2 000 microclusters) at 2 M points, events sharded over two ranks in
+    super-steps of up to 65 536 points per rank: ranks bit-identical, every point labelled, weights and label counts
+    conserved, and - blobs being well separated - the exact path's clusters."""
+    from chronoclust_amd import multi
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    n, d, g = 2_000_000, 14, 2000
+    X = scenarios.make_blobs(777, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    res = run_relaxed_group(2, [X], cfg, 65536)
+    _same_on_all_ranks(res)
+    r = res[0][0]
+    exact = HDDStream(cfg)
+    exact.online_microcluster_maintenance(X, 0)
+    assert (r["labels"] >= 0).all()
+    uid = np.concatenate([r["pcore"]["uid"], r["outlier"]["uid"]])
+    w = np.concatenate([r["pcore"]["w"], r["outlier"]["w"]])
+    u, counts = np.unique(r["labels"], return_counts=True)
+    order = np.argsort(uid)
+    assert np.array_equal(uid[order], u) and np.array_equal(w[order], counts.astype(np.float64)) and w.sum() == n
+    # a stale table lets a few early points fail a radius test the up-to-date MC would have passed: a handful of extra
+    # microclusters inside their blobs, the same clusters
+    assert g <= len(r["pcore"]["id"]) + len(r["outlier"]["id"]) <= 1.01 * g
+    by_cluster = multi.label_agreement(r["point_cluster"], exact.point_cluster_index())
+    by_mc = multi.label_agreement(r["labels"], exact.labels_uid)
+    print("C4-shaped, 2 ranks: agreement by cluster %.6f, by microcluster %.6f, microclusters %d (exact %d), set aside %d" % (
+        by_cluster, by_mc, len(r["pcore"]["id"]) + len(r["outlier"]["id"]), g, r["rstats"]["deferred_points"]))
+    assert by_cluster >= 0.999 and by_mc >= 0.99
+    assert r["rstats"]["deferred_points"] < 0.01 * n  # creation happens in the first, small super-steps only

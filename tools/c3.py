@@ -25,9 +25,12 @@ if __name__ == "__main__":
     tuning = {k.lower(): int(v) for k, v in os.environ.items() if k in ("WINDOW", "LOOKAHEAD", "SEGMENTS", "ROUNDS")}
     h = HDDStream(cfg, tuning=tuning or None)
     lineage, assoc = TrackByLineage(), TrackByHistoricalAssociation(handle=h._h)
+    prefetch = os.environ.get("PREFETCH", "1") != "0"
     for t, X in enumerate(Xs):
         a = time.perf_counter()
         h.online_microcluster_maintenance(X, t)
+        if prefetch and t + 1 < len(Xs):
+            h.prefetch(Xs[t + 1])  # uploaded in the background while this timepoint's records and trackers are built
         b = time.perf_counter()
         for cl in h.cluster_records():
             lineage.add_new_child_cluster(cl)
