@@ -213,33 +213,42 @@ class HDDStream(object):
         Cluster(list(id_set), centroid, weight rounded to one decimal place, preferred dimensions) plus the member
         pcores - assembled from the exported arrays (member centroids / preferred dimensions are gathered from the
         pcore table in one indexing operation instead of one object per pcore)."""
-        from ..objects.cluster import Cluster
+        from ..objects.cluster import Cluster, no_gc_pauses
         if getattr(self, "_cl_arrays", None) is None:
             return []
+        with no_gc_pauses():
+            return self._cluster_records(Cluster)
+
+    def _cluster_records(self, Cluster):
         mem, off, w, _, _, cen, pref = self._cl_arrays
         pc = self.table(_lib.PCORE)
         order = np.argsort(pc["id"], kind="stable")
         pos = order[np.searchsorted(pc["id"][order], mem)] if len(mem) else np.empty(0, np.int64)
         weights = rounded_weights(w)
         mem_list, off_list = mem.tolist(), off.tolist()
-        m_cen, m_pref, m_uid = pc["cen"][pos], pc["pref"][pos], pc["uid"][pos]  # member pcores, merge order
+        base = (pc["cen"][pos], pc["pref"][pos], pc["uid"][pos])  # member pcores of all clusters, merge order
+        cen_rows, pref_rows = list(cen), list(pref)
+        new_cluster = Cluster.__new__
         out = []
         for c in range(len(w)):
             a, b = off_list[c], off_list[c + 1]
             merged = mem_list[a:b]
-            cl_cen, cl_pref, cl_uid = m_cen[a:b], m_pref[a:b], m_uid[a:b]
             if b - a == 1:
-                ids = merged
+                ids, rows = merged, range(a, b)
             else:
                 id_set = set()
                 for m in merged:  # predecon_mc.py:67: the set is filled in merge order (CPython iteration order depends on it)
                     id_set.add(m)
                 ids = list(id_set)  # app.py:186
-                where = {m: i for i, m in enumerate(merged)}
-                perm = [where[m] for m in ids]
-                cl_cen, cl_pref, cl_uid = cl_cen[perm], cl_pref[perm], cl_uid[perm]
-            cl = Cluster(ids, cen[c], weights[c], pref[c])
-            cl.set_pcore_arrays(cl_cen, cl_pref, cl_uid)
+                where = {m: a + i for i, m in enumerate(merged)}
+                rows = [where[m] for m in ids]  # the member rows in pcore_ids order
+            # Cluster(ids, centroid, weight, preferred dimensions) + set_pcore_rows(base, rows), the fields filled in one
+            # go (5 000 constructor calls cost as much as the offline phase they follow)
+            cl = new_cluster(Cluster)
+            cl.__dict__ = {"pcore_ids": ids, "id": set(), "parents": set(), "centroid": cen_rows[c],
+                           "cumulative_weight": weights[c], "preferred_dimensions": pref_rows[c], "_pcore_objects": None,
+                           "_pc_cen": None, "_pc_pref": None, "_pc_uid": None, "_pc_base": base, "_pc_rows": rows,
+                           "historical_associates": set(), "historical_associates_pcores": set()}
             out.append(cl)
         return out
 

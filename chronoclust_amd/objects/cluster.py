@@ -5,6 +5,24 @@ dimensions) taken when the cluster is built, instead of deep copies of whole Mic
 their points (cluster.py:57)."""
 
 
+import contextlib
+import gc
+
+
+@contextlib.contextmanager
+def no_gc_pauses():
+    """Building the records of a timepoint allocates tens of thousands of small containers (sets, dicts, lists) that all
+    stay alive; the cyclic collector's threshold-triggered passes over them (2-20 ms each at 5 000 clusters) find nothing
+    to free.  Collection is suspended for the duration and left as it was afterwards."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class PcoreSnapshot(object):
     """What the trackers need of a member pcore, frozen at the timepoint the cluster was formed."""
 
@@ -29,6 +47,8 @@ class Cluster(object):
         self._pc_cen = None          # [members, d] centroids / preferred dimensions of the member pcores as arrays
         self._pc_pref = None         # (set_pcore_arrays: the vectorised form of add_pcore_objects)
         self._pc_uid = None
+        self._pc_base = None         # set_pcore_rows: (centroids, preferred dimensions, uids) shared by all clusters of a
+        self._pc_rows = None         # timepoint + this cluster's rows of them (a range, or a list in pcore_ids order)
         self.historical_associates = set()
         self.historical_associates_pcores = set()
 
@@ -54,6 +74,7 @@ class Cluster(object):
         the arrays of set_pcore_arrays on first use."""
         if self._pcore_objects is None:
             self._pcore_objects = []
+            self._materialise_rows()
             if self._pc_cen is not None:
                 for i, pcore_id in enumerate(self.pcore_ids):
                     self._pcore_objects.append(PcoreSnapshot(pcore_id, self._pc_cen[i], self._pc_pref[i],
@@ -69,11 +90,28 @@ class Cluster(object):
     def set_pcore_arrays(self, centroids, preferred_dimensions, uids=None):
         """add_pcore_objects from arrays: row i belongs to pcore_ids[i]."""
         self._pc_cen, self._pc_pref, self._pc_uid = centroids, preferred_dimensions, uids
+        self._pc_base = self._pc_rows = None
         self._pcore_objects = None
+
+    def set_pcore_rows(self, base, rows):
+        """add_pcore_objects without touching any array: `base` = (centroids, preferred dimensions, uids) of all member
+        pcores of the timepoint's clusters, `rows` = this cluster's rows of them in pcore_ids order (a range or a list).
+        The per-cluster arrays are sliced on demand; the association tracker reads `base` directly."""
+        self._pc_base, self._pc_rows = base, rows
+        self._pc_cen = self._pc_pref = self._pc_uid = None
+        self._pcore_objects = None
+
+    def _materialise_rows(self):
+        if self._pc_cen is None and self._pc_base is not None:
+            r = self._pc_rows
+            idx = slice(r.start, r.stop) if isinstance(r, range) else r
+            self._pc_cen, self._pc_pref, self._pc_uid = (self._pc_base[0][idx], self._pc_base[1][idx], self._pc_base[2][idx])
 
     def pcore_arrays(self):
         """(ids, centroids [n, d], preferred dimensions [n, d]) of the member pcores, in pcore_ids order."""
         import numpy as np
+        if self._pcore_objects is None:
+            self._materialise_rows()
         if self._pcore_objects is None and self._pc_cen is not None:
             return list(self.pcore_ids), self._pc_cen, self._pc_pref
         objs = self.pcore_objects
@@ -83,10 +121,15 @@ class Cluster(object):
                 np.array([np.asarray(p.preferred_dimension_vector, dtype=np.float64) for p in objs]))
 
     def __getstate__(self):
-        return self.__dict__
+        self._materialise_rows()  # a checkpoint holds this cluster's rows, not the whole timepoint's arrays
+        state = dict(self.__dict__)
+        state["_pc_base"] = state["_pc_rows"] = None
+        return state
 
     def __setstate__(self, state):
         self.__dict__.update(state)
+        self.__dict__.setdefault("_pc_base", None)
+        self.__dict__.setdefault("_pc_rows", None)
         if "pcore_objects" in state:  # images written before the arrays existed
             self._pcore_objects = self.__dict__.pop("pcore_objects")
             self._pc_cen = self._pc_pref = self._pc_uid = None

@@ -90,3 +90,29 @@ def test_two_rank_partition_arithmetic_gloo():
         out = mgr.dict()
         mp.spawn(_partition_worker, args=(world, port, out), nprocs=world, join=True)
         assert out[0] == [(0, 500)] and out[1] == [(500, 1000)]
+
+
+def _id_worker(rank, world, port, out):
+    """The channel that carries the 128-byte RCCL id from rank 0 to the other ranks (multi.broadcast_bytes), and the
+    all-ranks-equal check bench.py applies to the digests of the ranks' final states, over gloo."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        payload = bytes(range(128)) if rank == 0 else None
+        got = multi.broadcast_bytes(payload, dist)
+        assert got == bytes(range(128)) and len(got) == 128
+        assert multi.all_ranks_equal("same-digest", dist)
+        assert not multi.all_ranks_equal("digest-of-rank-%d" % rank, dist)
+        out[rank] = multi.one_stream_rate(1000, 2, 0.5)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_id_broadcast_and_digest_check_gloo():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_id_worker, args=(world, port, out), nprocs=world, join=True)
+        assert out[0] == out[1] == 4000.0
