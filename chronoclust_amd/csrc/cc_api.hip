@@ -1769,9 +1769,17 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                            p.pi, p.k, c.inv_k, c.pow2, h->core.p);
         const int my_rows = p_hi - p_lo;
         if (my_rows > 0) {
-            hipLaunchKernelGGL(k_eps_neighbours, dim3(words, (my_rows + 63) / 64), dim3(256),
-                               (size_t)2 * 64 * (d + 1) * sizeof(double), h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words,
-                               p_lo);
+            {
+                const dim3 grid((words + 3) / 4, (my_rows + CC_EPS_PCH - 1) / CC_EPS_PCH), block(256);
+#define CC_EPS(DP) hipLaunchKernelGGL((k_eps_neighbours<DP>), grid, block, 0, h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words, p_lo, p_hi)
+                if (d <= 4) CC_EPS(4);
+                else if (d <= 8) CC_EPS(8);
+                else if (d <= 16) CC_EPS(16);
+                else if (d <= 24) CC_EPS(24);
+                else if (d <= 40) CC_EPS(40);
+                else CC_EPS(64);
+#undef CC_EPS
+            }
             hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)(((size_t)my_rows * d + 255) / 256)), dim3(256), 0, h->stream,
                                pv.cen, h->adj.p, words, mp, d, p.delta, p.k, h->wvec.p, h->nn.p, p_lo, p_hi);
         }

@@ -118,43 +118,52 @@ __global__ void k_core_flags(PcoreView pv, int mp, int d, double eps_sq, double 
     core[r] = (r2 <= eps_sq && w >= mu && cnt <= pi) ? 1 : 0;
 }
 
-// K6: predecon.py:161-188.  A workgroup takes a 64 x 64 block of the (p, q) pair matrix: both centroid tiles are
-// staged through LDS (row stride d + 1 doubles, conflict-free for the per-lane q rows), lane = q, each of the four
-// waves walks 16 values of p; ballot -> one word of the adjacency bitmask per (p, 64 q).
+// K6: predecon.py:161-188.  Lane = q with its centroid in registers; a workgroup is four waves = four words of 64 q's and
+// walks a chunk of CC_EPS_PCH p rows, staged 32 at a time in LDS with coalesced loads and read back as broadcasts (the
+// shape of k_scan and k_assoc_tiled: per (p, q, dim) a subtraction, a square and an addition, one LDS broadcast per two
+// dimensions and wave).  ballot -> one word of the adjacency bitmask per (p, 64 q).
 // Euclidean distance = sqrt of the left-to-right sum of squares (the reference's np.linalg.norm is
 // platform-defined in the last ulp: nrm2 under numba, sqrt(dot) under numpy).
-// (p_base: first p row of this launch - on the multi-GPU path a rank takes a block of p rows)
+// (p_base / p_end: the p rows of this launch - on the multi-GPU path a rank takes a block of p rows)
+#define CC_EPS_PCH 256
+#define CC_EPS_TP 32
+
+template <int DP>
 __global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
-                                                        unsigned long long* __restrict__ adj, int words, int p_base)
+                                                        unsigned long long* __restrict__ adj, int words, int p_base,
+                                                        int p_end)
 {
-    extern __shared__ double s_tiles[];  // [64][d + 1] q rows, then [64][d + 1] p rows
-    const int ld = d + 1;
-    double* sq = s_tiles;
-    double* sp = s_tiles + 64 * ld;
-    const int q0 = blockIdx.x * 64, p0 = p_base + blockIdx.y * 64;
-    for (int e = threadIdx.x; e < 64 * d; e += 256) {
-        const int r = e / d, i = e - r * d;
-        sq[r * ld + i] = (q0 + r < mp) ? cen[(size_t)(q0 + r) * d + i] : 0.0;
-        sp[r * ld + i] = (p0 + r < mp) ? cen[(size_t)(p0 + r) * d + i] : 0.0;
-    }
-    __syncthreads();
+    __shared__ __attribute__((aligned(16))) double s_p[CC_EPS_TP * DP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int q = q0 + lane;
-    for (int pp = wv * 16; pp < wv * 16 + 16; ++pp) {
-        const int p = p0 + pp;
-        if (p >= mp) break;
-        bool in = false;
-        if (q < mp) {
+    const int qword = blockIdx.x * 4 + wv;
+    const int q = qword * 64 + lane;
+    const bool qvalid = qword < words && q < mp;
+    double cq[DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i) cq[i] = (qvalid && i < d) ? cen[(size_t)q * d + i] : 0.0;
+    const int p0 = p_base + blockIdx.y * CC_EPS_PCH;
+    const int p1 = min(p_end, p0 + CC_EPS_PCH);
+    for (int pt = p0; pt < p1; pt += CC_EPS_TP) {
+        const int tp = min(CC_EPS_TP, p1 - pt);
+        __syncthreads();
+        for (int e = threadIdx.x; e < CC_EPS_TP * DP; e += 256) {
+            const int m = e / DP, i = e - m * DP;
+            s_p[e] = (m < tp && i < d) ? cen[(size_t)(pt + m) * d + i] : 0.0;
+        }
+        __syncthreads();
+        if (qword >= words) continue;  // (a wave without a word of its own still helps staging)
+        for (int m = 0; m < tp; ++m) {
             double acc = 0.0;
-            for (int i = 0; i < d; ++i) {
-                double t = sq[lane * ld + i] - sp[pp * ld + i];
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                double t = cq[i] - s_p[m * DP + i];  // predeconmc_functions.py:4-17 (padded dimensions: 0 - 0)
                 t = t * t;
                 acc = acc + t;
             }
-            in = sqrt(acc) <= eps;
+            const bool in = qvalid && sqrt(acc) <= eps;
+            const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
+            if (lane == 0) adj[(size_t)(pt + m) * words + qword] = mask;
         }
-        const unsigned long long mask = __builtin_amdgcn_ballot_w64(in);
-        if (lane == 0) adj[(size_t)p * words + blockIdx.x] = mask;
     }
 }
 
