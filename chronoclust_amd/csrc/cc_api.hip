@@ -2044,6 +2044,7 @@ int cc_comm_init_local(cc_handle** handles, int world)
     for (int r = 0; r < world; ++r)
         if (!handles[r] || handles[r]->comm.active()) return CC_ERR_BAD_ARG;
     auto grp = std::make_shared<cc::LocalGroup>(world);
+    // every member's events first: a failure leaves no handle half inside a group
     for (int r = 0; r < world; ++r) {
         cc_handle* h = handles[r];
         int rc = guarded(h, [&]() {
@@ -2051,10 +2052,15 @@ int cc_comm_init_local(cc_handle** handles, int world)
             HIPCHK(hipEventCreateWithFlags(&h->comm.ev_done, hipEventDisableTiming));
             return (int)CC_OK;
         });
-        if (rc != CC_OK) return rc;
-        h->comm.local = grp;
-        h->comm.rank = r;
-        h->comm.world = world;
+        if (rc != CC_OK) {
+            for (int q = 0; q <= r; ++q) handles[q]->comm.destroy();
+            return rc;
+        }
+    }
+    for (int r = 0; r < world; ++r) {
+        handles[r]->comm.local = grp;
+        handles[r]->comm.rank = r;
+        handles[r]->comm.world = world;
     }
     return CC_OK;
 }

@@ -72,7 +72,7 @@ def _same_on_all_ranks(res):
                     assert np.array_equal(a[kind][key], b[kind][key]), (kind, key)
 
 
-@pytest.mark.parametrize("world,minibatch", [(2, 1000), (4, 700), (3, 4096)])
+@pytest.mark.parametrize("world,minibatch", [(2, 1000), (4, 700), (3, 4096), (8, 512)])
 def test_relaxed_group_conserves_and_agrees_with_exact(world, minibatch):
     from chronoclust_amd import multi
     from chronoclust_amd.clustering.hddstream import HDDStream

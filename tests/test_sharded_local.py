@@ -132,3 +132,15 @@ def test_rccl_transport_with_one_rank():
     assert all(r["stats"]["sharded_windows"] == r["stats"]["windows"] > 0 for r in res)
     h._h.comm_destroy()
     assert h._h.comm_info()["transport"] == "none"
+
+
+def test_eight_ranks_with_tiny_shares():
+    """The rank count of the target node.  30 - 140 microclusters over eight ranks: shares of a handful of rows, empty
+    shares at the start, offline blocks that are mostly padding - the same results as one GPU."""
+    for name in ("d40", "d20"):
+        sc = scenarios.BLOB_SCENARIOS[name]
+        cfg = scenarios.params_to_config(sc["params"])
+        Xs = scenarios.make_blob_timepoints(sc)
+        single = P.run_pipeline(Xs, cfg)
+        for res in run_group(8, Xs, cfg, tuning=dict(window=1024)):
+            P.same_results(res, single)
