@@ -11,7 +11,7 @@ def per_launch(d, counter):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     df = pd.read_csv(f)
     df = df[df["Counter_Name"] == counter]
-    df = df[df["Kernel_Name"].str.contains("k_scan") & df["Kernel_Name"].str.contains("false, 4>")]
+    df = df[df["Kernel_Name"].str.contains("k_scan<20, false", regex=False) & df["Kernel_Name"].str.contains("false, 4>", regex=False)]
     g = df.groupby("Dispatch_Id")["Counter_Value"].sum()
     name = df["Kernel_Name"].iloc[0].split("(")[0]
     # every launch of the kernel, like bench.py's avg_launch_us and algorithmic_bytes_per_launch (lookahead batches

@@ -11,7 +11,7 @@ import pandas as pd
 def full_launches(d):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     df = pd.read_csv(f)
-    df = df[df["Kernel_Name"].str.contains("k_scan") & df["Kernel_Name"].str.contains("false, 4>")]
+    df = df[df["Kernel_Name"].str.contains("k_scan<20, false", regex=False) & df["Kernel_Name"].str.contains("false, 4>", regex=False)]
     g = df.groupby(["Dispatch_Id", "Counter_Name"])["Counter_Value"].sum().unstack()
     t = df.groupby("Dispatch_Id").agg(s=("Start_Timestamp", "first"), e=("End_Timestamp", "first"), grid=("Grid_Size", "first"))
     g["us"] = (t["e"] - t["s"]) / 1e3
