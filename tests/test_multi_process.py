@@ -116,3 +116,15 @@ def test_two_rank_id_broadcast_and_digest_check_gloo():
         out = mgr.dict()
         mp.spawn(_id_worker, args=(world, port, out), nprocs=world, join=True)
         assert out[0] == out[1] == 4000.0
+
+
+def test_bench_command_line_parses_without_a_gpu():
+    """`python bench.py --help` (argument surface of the driver contract: --gpus / --steps / --warmup) needs neither a
+    GPU nor torch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--no-one-stream", "--no-relaxed", "--relaxed-minibatch"):
+        assert flag in out.stdout
