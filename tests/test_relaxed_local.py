@@ -162,3 +162,18 @@ def test_c4_shaped_relaxed_two_ranks_against_exact():
         by_cluster, by_mc, len(r["pcore"]["id"]) + len(r["outlier"]["id"]), g, r["rstats"]["deferred_points"]))
     assert by_cluster >= 0.999 and by_mc >= 0.99
     assert r["rstats"]["deferred_points"] < 0.01 * n  # creation happens in the first, small super-steps only
+
+
+def test_relaxed_group_with_tiny_and_uneven_timepoints():
+    """Fewer points than ranks, one point, shards of unequal length, an empty last shard: every rank still takes part
+    in every collective and ends with the same state; all points get labels."""
+    rng = np.random.default_rng(3)
+    centres = rng.uniform(0.2, 0.8, (4, 5))
+    sizes = [1, 3, 1000, 7, 2]
+    Xs = [np.ascontiguousarray(np.clip(centres[rng.integers(0, 4, n)] + rng.normal(0, 0.01, (n, 5)), 0, 1)) for n in sizes]
+    cfg = scenarios.params_to_config(scenarios.blob_params(1000, param_lambda=0.1))
+    res = run_relaxed_group(4, Xs, cfg, 256)
+    _same_on_all_ranks(res)
+    for t, n in enumerate(sizes):
+        r = res[0][t]
+        assert len(r["labels"]) == n and (r["labels"] >= 0).all()

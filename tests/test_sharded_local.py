@@ -144,3 +144,16 @@ def test_eight_ranks_with_tiny_shares():
         single = P.run_pipeline(Xs, cfg)
         for res in run_group(8, Xs, cfg, tuning=dict(window=1024)):
             P.same_results(res, single)
+
+
+def test_sharded_group_with_tiny_timepoints():
+    """One-point and few-point timepoints between normal ones (windows of a single point, empty row shares): the ranks
+    still agree with the single-GPU run."""
+    rng = np.random.default_rng(4)
+    centres = rng.uniform(0.2, 0.8, (6, 8))
+    sizes = [1, 2, 1500, 5, 1, 800]
+    Xs = [np.ascontiguousarray(np.clip(centres[rng.integers(0, 6, n)] + rng.normal(0, 0.01, (n, 8)), 0, 1)) for n in sizes]
+    cfg = scenarios.params_to_config(scenarios.blob_params(1500, param_lambda=0.3, param_omicron=0.0005))
+    single = P.run_pipeline(Xs, cfg)
+    for res in run_group(3, Xs, cfg):
+        P.same_results(res, single)
