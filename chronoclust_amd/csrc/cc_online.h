@@ -33,6 +33,16 @@
 // Lookahead scans read one of two scan copies of the table (struct ScanCopy), kept
 // up to date by k_apply_carry and k_commit_b, so that a commit never waits for them.
 //
+// Beside the window pipeline:
+//   k_chain_long      long chains on small tables (few MCs absorb every point): sequential CF additions per
+//                     dimension, radius tests of a batch of steps in parallel, resume after the first rejected one
+//   k_seq             no speculation: one wavefront walks the points in order on an LDS image of the table; the host
+//                     switches to it while windows keep being cut short and it measures faster
+//   k_merge_partials  exact multi-GPU path: a rank's partials per point -> the 64-byte record the ranks all-gather
+//                     (k_scan then scans only the rank's share of the table rows, k_decide merges the records)
+//   k_rel_*           relaxed multi-GPU mode (events sharded over the ranks): CF deltas, merge, promotions,
+//                     set-aside points
+//
 // Arithmetic: IEEE double, no contraction by the compiler (-ffp-contract=off), sums
 // over dimensions left to right as in utilities/mc_functions.py under numba; the one
 // hand-written fusion (distance terms of the scans when k is a power of two) is
