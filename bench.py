@@ -23,6 +23,7 @@ import argparse
 import hashlib
 import json
 import os
+import signal
 import sys
 import threading
 import time
@@ -35,6 +36,67 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+
+
+class LineGuard:
+    """Keeper of the ONE line on stdout.  A small child process, forked before anything touches the GPU, holds the
+    real stdout and reads what this process sends it: the headline as soon as it is measured (provisional), the
+    complete line at the end (final).  When the pipe closes it prints the last thing it was given - so the headline
+    also reaches stdout when a later leg takes the process down (a fault inside a collective, the launcher ending
+    the rank after a peer died), marked as incomplete.  The child never uses the GPU, the oracle or torch."""
+
+    def __init__(self, out_fd):
+        r, w = os.pipe()
+        # a group-wide signal must not end the keeper before the line is out: blocked across the fork, ignored in the child
+        sigs = (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)
+        before = signal.pthread_sigmask(signal.SIG_BLOCK, sigs)
+        pid = os.fork()
+        if pid == 0:
+            status = 0
+            try:
+                os.close(w)
+                for sig in sigs:
+                    signal.signal(sig, signal.SIG_IGN)
+                signal.pthread_sigmask(signal.SIG_SETMASK, before)
+                buf = b""
+                while True:
+                    chunk = os.read(r, 1 << 16)
+                    if not chunk:
+                        break
+                    buf += chunk
+                lines = [x for x in buf.split(b"\n") if x]
+                if lines:
+                    kind, payload = lines[-1][:1], lines[-1][1:]
+                    if kind != b"F":
+                        obj = json.loads(payload)
+                        obj["incomplete"] = "the process ended before the remaining legs of the run had finished"
+                        payload = json.dumps(obj).encode()
+                    os.write(out_fd, payload + b"\n")
+            except BaseException:  # noqa: BLE001 - nothing to report to
+                status = 1
+            os._exit(status)
+        signal.pthread_sigmask(signal.SIG_SETMASK, before)
+        os.close(r)
+        self._w, self._pid = w, pid
+
+    def _send(self, kind, obj):
+        data = kind + json.dumps(obj).encode() + b"\n"
+        while data:
+            data = data[os.write(self._w, data):]
+
+    def provisional(self, obj):
+        self._send(b"P", obj)
+
+    def final(self, obj):
+        self._send(b"F", obj)
+        self.close()
+
+    def close(self):
+        """Ends the keeper (it prints what it holds) and waits until the line is out."""
+        if self._w is not None:
+            os.close(self._w)
+            self._w = None
+            os.waitpid(self._pid, 0)
 
 
 def make_blobs(seed, n, d, g, sigma=0.01):
@@ -288,12 +350,13 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-
-    def emit(obj):
-        os.write(json_fd, (json.dumps(obj) + "\n").encode())
-
     from chronoclust_amd import multi
     rank, world, local_rank = multi.rank_info()
+    guard = LineGuard(json_fd) if rank == 0 else None  # (before torch, HIP or RCCL exist in this process)
+
+    def emit(obj):
+        guard.final(obj)
+
     import torch
     dist = None
     if world > 1:
@@ -413,6 +476,8 @@ def main():
             out["cpu_baseline"]["host_cpu_count"] = os.cpu_count()
     h.close()
     del X
+    if rank == 0:
+        guard.provisional(out)  # from here on the headline is safe whatever happens to the legs below
 
     legs = []
     if not args.no_one_stream:

@@ -128,3 +128,41 @@ def test_bench_command_line_parses_without_a_gpu():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup", "--no-one-stream", "--no-relaxed", "--relaxed-minibatch"):
         assert flag in out.stdout
+
+
+_GUARD_SCRIPT = """
+import os, signal, sys
+sys.path.insert(0, %r)
+import bench
+fd = os.dup(1)
+os.dup2(2, 1)
+g = bench.LineGuard(fd)
+print("noise on fd 1 from a native library")
+g.provisional({"metric": "m", "value": 1.0})
+mode = sys.argv[1]
+if mode == "final":
+    g.final({"metric": "m", "value": 1.0, "one_stream_exact": {"value": 2.0}})
+elif mode == "killed":
+    os.kill(os.getpid(), signal.SIGKILL)
+elif mode == "terminated":
+    os.killpg(os.getpgid(0), signal.SIGTERM)  # the launcher ends the whole group: the keeper still prints
+"""
+
+
+def test_bench_line_survives_the_death_of_the_process():
+    """bench.py's stdout line is held by a keeper process: one line in every case - the complete one after a normal
+    end, the headline marked incomplete when the process is killed after the headline was measured."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("final", "killed", "terminated"):
+        p = subprocess.Popen([sys.executable, "-c", _GUARD_SCRIPT % root, mode], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, start_new_session=True)
+        out, _ = p.communicate(timeout=60)
+        lines = [x for x in out.splitlines() if x.strip()]
+        assert len(lines) == 1, (mode, out)
+        obj = json.loads(lines[0])
+        assert obj["value"] == 1.0
+        assert ("incomplete" in obj) == (mode != "final")
+        assert ("one_stream_exact" in obj) == (mode == "final")
