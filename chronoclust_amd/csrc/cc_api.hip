@@ -119,6 +119,7 @@ struct cc_handle {
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
+    bool allow_scan_u = true;  // k_scan_u where it applies (CHRONOCLUST_HIP_SCANU=0: always k_scan)
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
@@ -375,6 +376,9 @@ Versions versions_view(cc_handle* h)
 
 // ---- scan dispatch over the padded dimensionality ---------------------------------
 
+// does the snapshot scan of this handle's stream run as k_scan_u? (decided per launch by the same test)
+bool scan_u_applies(const cc_handle* h, int DP) { return h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 && h->d == DP; }
+
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
                     int mode, int shard_rank, int shard_world)
@@ -389,6 +393,15 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 #define CC_LAUNCH_SCAN(F, P)                                                                                   \
     hipLaunchKernelGGL((k_scan<DP, F, P, DIRTY, NW>), grid, block, 0, st, h->ctl.p, h->X.p, h->Xt.p, rows, clean, \
                        part, round, mode, h->part_stride, shard_rank, shard_world)
+    if constexpr (!DIRTY) {
+        // the common case (k a power of two, no pdim filter, no padded dimensions): rows as scalar operands
+        static_assert(ScanShape<DP, false>::PT == 1, "k_scan_u holds one window point per lane");
+        if (scan_u_applies(h, DP)) {
+            hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
+                               rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
+            return;
+        }
+    }
     if (filter) {
         if (h->hc.pow2) CC_LAUNCH_SCAN(true, true);
         else CC_LAUNCH_SCAN(true, false);
@@ -421,9 +434,30 @@ void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* c
 }
 
 // workgroups of the clean scan that are resident at once (compute units x workgroups per CU it is compiled for)
+template <int DP>
+int scan_u_wgs_per_cu()
+{
+    static const int n = []() {
+        int blocks = 0;
+        constexpr int NW = ScanShape<DP, false>::NW;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, k_scan_u<DP, NW>, 64 * NW, 0) != hipSuccess || blocks < 1)
+            blocks = ScanUShape<DP>::WGS;
+        return blocks;
+    }();
+    return n;
+}
+
 int scan_resident_wgs(const cc_handle* h)
 {
     const int d = h->d;
+    if (d == 4 && scan_u_applies(h, 4)) return h->n_cus * scan_u_wgs_per_cu<4>();
+    if (d == 8 && scan_u_applies(h, 8)) return h->n_cus * scan_u_wgs_per_cu<8>();
+    if (d == 14 && scan_u_applies(h, 14)) return h->n_cus * scan_u_wgs_per_cu<14>();
+    if (d == 16 && scan_u_applies(h, 16)) return h->n_cus * scan_u_wgs_per_cu<16>();
+    if (d == 20 && scan_u_applies(h, 20)) return h->n_cus * scan_u_wgs_per_cu<20>();
+    if (d == 32 && scan_u_applies(h, 32)) return h->n_cus * scan_u_wgs_per_cu<32>();
+    if (d == 40 && scan_u_applies(h, 40)) return h->n_cus * scan_u_wgs_per_cu<40>();
+    if (d == 64 && scan_u_applies(h, 64)) return h->n_cus * scan_u_wgs_per_cu<64>();
     int per_cu;
     if (d <= 4) per_cu = ScanShape<4, false>::WGS;
     else if (d <= 8) per_cu = ScanShape<8, false>::WGS;
@@ -535,6 +569,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_nodirty = !(nd && nd[0] == '0');
         const char* cl = getenv("CHRONOCLUST_HIP_CLAIMS");
         h->allow_claims = !(cl && cl[0] == '0');
+        const char* su = getenv("CHRONOCLUST_HIP_SCANU");
+        if (su) h->allow_scan_u = atoi(su) != 0;
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
         push_ctl(h);
@@ -1396,8 +1432,12 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     ++h->since_shrink;
                     if (trunc_batch == 0) ++h->clean_batches;
                     const int need = (h->since_shrink > 8 || want < fast_below) ? 1 : 2;
-                    if (trunc_batch == 0 && h->clean_batches >= need)
-                        want = std::min(target, std::max(want, 64) * (want < fast_below ? 4 : 2));  // small windows: fast start
+                    if (trunc_batch == 0 && h->clean_batches >= need) {
+                        // a batch in which no window was cut short and no point tile needed its dirty scan (the table has
+                        // settled: nothing created or promoted any more) goes straight to the full size
+                        const bool settled = tiles > 0 && dtiles == 0 && grew == 0;
+                        want = settled ? target : std::min(target, std::max(want, 64) * (want < fast_below ? 4 : 2));  // small windows: fast start
+                    }
                 }
                 want = std::min(want, target);
                 h->adapt_win = want;
@@ -1420,12 +1460,13 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     push_ctl(h);
                 }
                 if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
-                            done, h->hc.m_rows, wins, pts, trunc_batch, unk_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
+                    fprintf(stderr, "[cc] %.2f ms done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
+                            now_ms() - batch_t0, done, h->hc.m_rows, wins, pts, trunc_batch, unk_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
                             (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, want, Rcur);
                 // settle quickly at the start of a call and whenever windows are being truncated
-                batch_windows = (trunc_batch > 0 || first_batch || want < target) ? std::max(2, h->tun.windows_per_sync / 4)
-                                                                                  : h->tun.windows_per_sync;
+                // ... and while the window is held at the start-up size: the end of that phase is only seen at a batch boundary
+                batch_windows = (trunc_batch > 0 || first_batch || want < target || target < win) ? std::max(2, h->tun.windows_per_sync / 4)
+                                                                                                  : h->tun.windows_per_sync;
                 if (want < fast_below && trunc_batch == 0) batch_windows = 2;
                 first_batch = false;
                 // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back

@@ -745,6 +745,276 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
 }
 
 // ---------------------------------------------------------------------------------
+// k_scan_u: the snapshot scan with the MC rows as scalar operands.  Same result as k_scan<DP, false, true, false>
+// for d == DP (no pdim filter, k a power of two).  A row's centroid is the same for all 64 points of a wave: it is
+// read with scalar loads (through the scalar cache, into SGPRs) and enters the FP64 instructions as their scalar
+// operand; nothing of the row loop goes through LDS, whose data return rate k_scan's wave-uniform reads are bound by.
+// The loads run one chunk (up to ten dimensions) ahead of the arithmetic: a chunk is requested right after the first
+// use of the one before it, the first chunk of the next row after the first use of a row's last one (scalar loads
+// return out of order, so a wait is always for everything outstanding: at each wait exactly one chunk is).
+// Per tile of 16 rows the wave still reads the tile's 1/pref values (and the centroids, for the CC_TINY test) with
+// coalesced vector loads: the ballots of `!= 1` give every row's bit mask, from which the scaled operands of two
+// dimensions at a time are selected (scalar instructions), as in k_scan.
+// ---------------------------------------------------------------------------------
+// workgroups per CU the kernel is compiled for (register budget): the points of a lane alone are 2 * DP registers
+#ifndef CC_SCANU_WGS40
+#define CC_SCANU_WGS40 4  // (d = 40 at four per CU spills two registers and still measured 6 % faster than three per CU)
+#endif
+template <int DP>
+struct ScanUShape {
+    static constexpr int WGS = DP <= 32 ? 4 : (DP <= 40 ? CC_SCANU_WGS40 : 2);
+};
+// operands of dimensions BIT and BIT + 1 from a row's bit mask
+template <int BIT>
+__device__ __forceinline__ void cc_sel_scale2(unsigned mask, double scaled, double one, double& o0, double& o1)
+{
+    asm("s_bitcmp1_b32 %2, %3\n\ts_cselect_b64 %0, %5, %6\n\ts_bitcmp1_b32 %2, %4\n\ts_cselect_b64 %1, %5, %6"
+        : "=&s"(o0), "=&s"(o1)
+        : "s"(mask), "n"(BIT), "n"(BIT + 1), "s"(scaled), "s"(one)
+        : "scc");
+}
+
+// `row`, usable only once `dep` has been computed: orders a scalar load after the first use of the previous one's data
+__device__ __forceinline__ int cc_after(int row, double dep)
+{
+    asm("" : "+s"(row) : "v"(dep));
+    return row;
+}
+
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                                 const double* __restrict__ g_cen,
+                                                                 const double* __restrict__ g_scl,
+                                                                 const int* __restrict__ g_kind,
+                                                                 const int* __restrict__ g_key, Cand* __restrict__ part,
+                                                                 int round, int mode, size_t part_stride, int shard_rank,
+                                                                 int shard_world)
+{
+    static_assert(DP % 2 == 0 && DP >= 4 && DP <= 64, "padded dimensionalities are even");
+    // a row is read in NC chunks of whole pairs of dimensions (at most ten dimensions: 20 SGPRs), alternately into two
+    // buffers; NC is even, so the first chunk of the next row follows the last one of a row in the other buffer
+    constexpr int NP = DP / 2;
+    constexpr int NC = 2 * ((NP + 9) / 10);
+    constexpr int CH_MAX = 2 * ((NP + NC - 1) / NC);
+    int B, m_rows_scan;
+    long long cursor;
+    if (mode == 1) {
+        const int q = round & 1;
+        B = ctl->la_b[q];
+        m_rows_scan = ctl->la_rows[q];
+        cursor = ctl->la_cursor[q];
+        part += (size_t)q * part_stride;
+    } else {
+        B = ctl->win_b;
+        m_rows_scan = ctl->m_rows;
+        cursor = ctl->cursor;
+        if (ctl->mode != 0) return;  // this window's snapshot scan ran ahead
+        part += (size_t)(ctl->window_seq & 1ull) * part_stride;
+    }
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 64;
+    if (j0 >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    int row_lo = 0, row_hi = m_rows_scan;
+    if (shard_world > 1) cc_shard_range(m_rows_scan, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int nrows = row_hi - row_lo;
+    const int per = (nrows + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const double k = ctl->k;
+    const double inv_k = ctl->inv_k;
+    const int jj = j0 + lane;
+    const bool valid = jj < B;
+
+    double p[DP];
+    {
+        const double* xp = Xt + cursor + (valid ? jj : 0);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    bool fuse_wave = k >= 0x1p-64 && k <= 0x1p64;
+    {
+        bool tn = false;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) tn = tn || cc_is_tiny(p[i]);
+        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+    }
+    // running best-two per kind: distances and rows ([kind][rank]); lanes without a point never enter
+    double bd[2][2];
+    int bs[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bd[kd][r] = valid ? CC_INF : -CC_INF;
+            bs[kd][r] = -1;
+        }
+
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        // first half of the tile's first row (in flight during the tile's vector loads; the row loop then keeps half a
+        // row ahead)
+        double buf[2][CH_MAX];
+        {
+            const double* __restrict__ c0 = g_cen + (size_t)rt * DP;
+#pragma unroll
+            for (int i = 0; i < 2 * (NP / NC); ++i) buf[0][i] = c0[i];
+        }
+        // the tile's 1/pref values and centroids, coalesced: bit masks of the rows, CC_TINY test
+        constexpr int NL = (CC_SCAN_TM * DP + 63) / 64;
+        int rm_lo = 0, rm_hi = 0;
+        bool fuse_tile;
+        {
+            const double* gc = g_cen + (size_t)rt * DP;
+            const double* gs = g_scl + (size_t)rt * DP;
+            unsigned long long rmask = 0ull;
+            bool tn = false;
+            const int off = (lane & (CC_SCAN_TM - 1)) * DP;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;
+                const bool in = e < tm * DP;
+                const double tc = in ? gc[e] : 0.0;
+                const double ts = in ? gs[e] : 1.0;
+                tn = tn || cc_is_tiny(tc);
+                const unsigned long long w = __builtin_amdgcn_ballot_w64(ts != 1.0);
+                const int rel = off - 64 * q;
+                const unsigned long long a = (rel >= 0 && rel < 64) ? (w >> (rel & 63)) : 0ull;
+                const unsigned long long b = (rel < 0 && rel > -DP) ? (w << ((-rel) & 63)) : 0ull;
+                rmask |= a | b;
+            }
+            if (DP < 64) rmask &= (1ull << (DP & 63)) - 1ull;
+            rm_lo = (int)(unsigned)(rmask & 0xFFFFFFFFull);
+            rm_hi = (int)(unsigned)(rmask >> 32);
+            fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+        }
+        unsigned pmask, omask;
+        {
+            const int kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+            pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
+            omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
+        }
+        auto rows_of_tile = [&](auto FUSEC, auto KSELC) {
+            constexpr bool FUSE = decltype(FUSEC)::value;
+            constexpr int KSEL = decltype(KSELC)::value;
+            for (int m = 0; m < tm; ++m) {
+                const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(rm_lo, m);
+                const unsigned mhi = (DP > 32) ? (unsigned)__builtin_amdgcn_readlane(rm_hi, m) : 0u;
+                const int rowg = rt + m;
+                const int rown = min(rowg + 1, rt + tm - 1);  // (the last row of a tile requests its own first half again)
+                const double one = 1.0;
+                double acc = 0.0;
+                // one pair of dimensions: mc_functions.py:37-41, left to right
+                auto pair_step = [&](auto IC, double c0, double c1, double x0) {
+                    constexpr int i = decltype(IC)::value;
+                    double s0, s1;
+                    cc_sel_scale2<(i & 31)>(i < 32 ? mlo : mhi, inv_k, one, s0, s1);
+                    double x = x0;            // p[i] - c0, made by the caller
+                    double y = p[i + 1] - c1;
+                    x = x * x;
+                    y = y * y;
+                    if (FUSE) {
+                        acc = (i == 0) ? x * s0 : __builtin_fma(x, s0, acc);  // :39 + :41 in one rounding, see CC_TINY
+                        acc = __builtin_fma(y, s1, acc);
+                    } else {
+                        x = x * s0;  // :39 (the divisor is a power of two)
+                        y = y * s1;
+                        acc = (i == 0) ? x : acc + x;  // :41
+                        acc = acc + y;
+                    }
+                };
+                cc_static_for<NC>([&](auto CC) {
+                    constexpr int c = decltype(CC)::value;
+                    constexpr int lo = 2 * (c * NP / NC), hi = 2 * ((c + 1) * NP / NC);        // this chunk's dimensions
+                    constexpr int cn = (c + 1) % NC;                                          // the chunk requested now
+                    constexpr int nlo = 2 * (cn * NP / NC), nhi = 2 * ((cn + 1) * NP / NC);
+                    // first use of the chunk requested one chunk ago: the wait is here, with nothing else outstanding
+                    const double x0 = p[lo] - buf[c & 1][0];
+                    // wave-uniform address: scalar loads; of this row, or of the next one after the last chunk
+                    const double* __restrict__ nx = g_cen + (size_t)cc_after(c + 1 < NC ? rowg : rown, x0) * DP;
+#pragma unroll
+                    for (int i = 0; i < nhi - nlo; ++i) buf[cn & 1][i] = nx[nlo + i];
+                    cc_static_for<(hi - lo) / 2>([&](auto QC) {
+                        constexpr int i = 2 * decltype(QC)::value;
+                        pair_step(std::integral_constant<int, lo + i>{}, buf[c & 1][i], buf[c & 1][i + 1],
+                                  (i == 0) ? x0 : p[lo + i] - buf[c & 1][i]);
+                    });
+                });
+                auto update = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+                    const double a = acc;
+                    double& d0 = bd[K][0];
+                    double& d1 = bd[K][1];
+                    int& s0 = bs[K][0];
+                    int& s1 = bs[K][1];
+                    bool ins = a < d1;
+                    bool first = a < d0;
+                    // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+                    const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                    const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                    if ((e1 | e0) != 0ull) {
+                        if (a == d1 || a == d0) {
+                            const int key = g_key[rowg];
+                            if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                            if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                        }
+                    }
+                    d1 = cc_vmin(d1, cc_vmax(d0, a));
+                    d0 = cc_vmin(d0, a);
+                    s1 = first ? s0 : (ins ? rowg : s1);
+                    s0 = first ? rowg : s0;
+                };
+                if constexpr (KSEL == 0) update(std::integral_constant<int, 0>{});
+                else if constexpr (KSEL == 1) update(std::integral_constant<int, 1>{});
+                else {
+                    if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+                    else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+                }
+            }
+        };
+        const unsigned full = (1u << tm) - 1u;
+        if (fuse_tile) {
+            if (pmask == full) rows_of_tile(std::true_type{}, std::integral_constant<int, 0>{});
+            else if (omask == full) rows_of_tile(std::true_type{}, std::integral_constant<int, 1>{});
+            else rows_of_tile(std::true_type{}, std::integral_constant<int, -1>{});
+        } else rows_of_tile(std::false_type{}, std::integral_constant<int, -1>{});
+    }
+
+    // the list-order keys of the survivors, then the waves' candidates merged through LDS as in k_scan
+    int bk[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bk[kd][r] = bs[kd][r] >= 0 ? g_key[bs[kd][r]] : CC_IDX_INF;
+    __shared__ Cand s_m[(NW > 1 ? NW - 1 : 1) * 4 * 64];
+    auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 4 + c) * 64 + lane]; };
+    if (wv > 0) {
+        s_m_at(wv - 1, 0) = Cand{bd[0][0], bk[0][0], bs[0][0]};
+        s_m_at(wv - 1, 1) = Cand{bd[0][1], bk[0][1], bs[0][1]};
+        s_m_at(wv - 1, 2) = Cand{bd[1][0], bk[1][0], bs[1][0]};
+        s_m_at(wv - 1, 3) = Cand{bd[1][1], bk[1][1], bs[1][1]};
+    }
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+    Cand c0{bd[0][0], bk[0][0], bs[0][0]}, c1{bd[0][1], bk[0][1], bs[0][1]};
+    Cand c2{bd[1][0], bk[1][0], bs[1][0]}, c3{bd[1][1], bk[1][1], bs[1][1]};
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        cc_top2_push(c0, c1, s_m_at(w, 0));
+        cc_top2_push(c0, c1, s_m_at(w, 1));
+        cc_top2_push(c2, c3, s_m_at(w, 2));
+        cc_top2_push(c2, c3, s_m_at(w, 3));
+    }
+    Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
 // k_merge_partials (exact multi-GPU path): the S partials a rank's snapshot scan left per window point -> ONE record
 // of four candidates per point, the unit the ranks all-gather (64 B per point instead of S x 64 B).  Candidates are
 // totally ordered by (distance, list-order key), so the best two of a union do not depend on the merge order and
@@ -891,13 +1161,26 @@ __device__ inline GroupAdd cc_group_add(const double* bcf1, const double* bcf2, 
     return cc_group_add_regs(b1, b2, bw, px, d, c);
 }
 
-__device__ __forceinline__ Cand cc_shfl_xor_cand(const Cand& c, int off)
+// The same candidate from another lane of this lane's row of 16 (DPP: no trip through the LDS crossbar, which the
+// co-running snapshot scan keeps busy)
+template <int CTRL>
+__device__ __forceinline__ Cand cc_dpp_cand(const Cand& c)
 {
     Cand o;
-    o.dist = __shfl_xor(c.dist, off, 32);
-    o.key = __shfl_xor(c.key, off, 32);
-    o.slot = __shfl_xor(c.slot, off, 32);
+    o.dist = cc_dpp_f64<CTRL>(c.dist);
+    o.key = __builtin_amdgcn_update_dpp(0, c.key, CTRL, 0xF, 0xF, false);
+    o.slot = __builtin_amdgcn_update_dpp(0, c.slot, CTRL, 0xF, 0xF, false);
     return o;
+}
+// All-to-all merge inside every row of 16 lanes in four exchanges with disjoint holdings: neighbours, pairs of a
+// quad, the two quads of a half row (half mirror), the two half rows (mirror).  `f(ctrl_constant)` does one exchange.
+template <typename F>
+__device__ __forceinline__ void cc_row16_exchanges(F&& f)
+{
+    f(std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    f(std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    f(std::integral_constant<int, 0x141>{});  // row_half_mirror
+    f(std::integral_constant<int, 0x140>{});  // row_mirror
 }
 
 // ---------------------------------------------------------------------------------
@@ -1190,8 +1473,8 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
 }
 
 // ---------------------------------------------------------------------------------
-// k_decide: one 32-lane group per window point.  Segment partials are merged with a shuffle butterfly
-// (per-point argmin over the MC range), then the reference's decision procedure runs group-uniformly.
+// k_decide: one 32-lane group per window point.  Segment partials are merged inside each row of 16 lanes with DPP
+// exchanges (per-point argmin over the MC range), then the reference's decision procedure runs group-uniformly.
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
@@ -1223,21 +1506,24 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         // partial s of point j: one launch wrote S partials per point (part_inner = S, part_outer unused); on the
         // exact multi-GPU path every rank contributed one merged record (part_inner = 1, part_outer = the distance
         // between the ranks' blocks in the gathered buffer)
-        for (int s = gl; s < S; s += 32) {
+        // both rows of 16 lanes of the group merge all S partials (lane l of a row takes l, l + 16, ..), so the two
+        // rows end with the same result and nothing crosses between them
+        for (int s = gl & 15; s < S; s += 16) {
             const Cand* q = part + (size_t)(s / part_inner) * part_outer + ((size_t)j * part_inner + (s % part_inner)) * 4;
             cc_top2_push(p1, p2, q[0]);
             cc_top2_push(p1, p2, q[1]);
             cc_top2_push(o1, o2, q[2]);
             cc_top2_push(o1, o2, q[3]);
         }
-        for (int off = 16; off >= 1; off >>= 1) {
-            const Cand a0 = cc_shfl_xor_cand(p1, off), a1 = cc_shfl_xor_cand(p2, off);
-            const Cand a2 = cc_shfl_xor_cand(o1, off), a3 = cc_shfl_xor_cand(o2, off);
+        cc_row16_exchanges([&](auto CT) {
+            constexpr int C = decltype(CT)::value;
+            const Cand a0 = cc_dpp_cand<C>(p1), a1 = cc_dpp_cand<C>(p2);
+            const Cand a2 = cc_dpp_cand<C>(o1), a3 = cc_dpp_cand<C>(o2);
             cc_top2_push(p1, p2, a0);
             cc_top2_push(p1, p2, a1);
             cc_top2_push(o1, o2, a2);
             cc_top2_push(o1, o2, a3);
-        }
+        });
         if (gl == 0) {
             Cand* out = clean + (size_t)j * 4;
             out[0] = p1; out[1] = p2; out[2] = o1; out[3] = o2;
@@ -1253,11 +1539,11 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
         const bool ran = nodirty == 0 && ver.skip[j >> 6] == 0;
         const bool ran_car = nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
-        if (gl == 0 && !(ran && (ran_car || !la_mode))) {
+        if ((gl & 15) == 0 && !(ran && (ran_car || !la_mode))) {
             dvp = dseed[(size_t)j * 4 + 0];
             dvo = dseed[(size_t)j * 4 + 2];
         }
-        for (int s = gl; s < Sd; s += 32) {
+        for (int s = gl & 15; s < Sd; s += 16) {  // (per row of 16 lanes, as in round 0)
             if (ran) {
                 const Cand* q = dpart + ((size_t)j * Sd + s) * 2;
                 cc_top2_push(dvp, dummy, q[0]);
@@ -1269,11 +1555,12 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                 cc_top2_push(dvo, dummy, q2[1]);
             }
         }
-        for (int off = 16; off >= 1; off >>= 1) {
-            const Cand b0 = cc_shfl_xor_cand(dvp, off), b1 = cc_shfl_xor_cand(dvo, off);
+        cc_row16_exchanges([&](auto CT) {
+            constexpr int C = decltype(CT)::value;
+            const Cand b0 = cc_dpp_cand<C>(dvp), b1 = cc_dpp_cand<C>(dvo);
             cc_top2_push(dvp, dummy, b0);
             cc_top2_push(dvo, dummy, b1);
-        }
+        });
     }
 
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;

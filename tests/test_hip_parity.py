@@ -144,16 +144,17 @@ def test_lookahead_across_batches_and_table_growth(wps, window, sigma, eps):
     assert len(o.table(1)["id"]) + len(o.table(0)["id"]) > 1100  # the table was reallocated at least once
 
 
+@pytest.mark.parametrize("d", [6, 8, 14])  # 6: padded to 8 columns (k_scan); 8, 14: rows as scalar operands (k_scan_u)
 @pytest.mark.parametrize("scale,k,all_dims", [(1e-154, 4.0, False), (1e-158, 2.0, False), (1e-200, 4.0, False),
                                               (3e-121, 16.0, False), (1e-153, 4.0, True), (2e-154, 2.0, True)])
-def test_subnormal_distance_terms(scale, k, all_dims):
+def test_subnormal_distance_terms(scale, k, all_dims, d):
     """The scans fuse `acc + x2 / pref` into one fma when k is a power of two, which is only the same double while
     x2 / pref stays a normal number; waves / tiles that hold a nonzero coordinate below 2^-400 must take the
     unfused path (CC_TINY in cc_online.h).  Some dimensions are scaled so that squared differences are subnormal
     (or flush to zero), others stay ordinary; at scale 3e-121 the tiny coordinates sit just above the threshold.
     all_dims: every coordinate (and epsilon) is scaled, so whole distances and radii are subnormal."""
     from oracle import oracle as O
-    n, d, g = 3000, 6, 12
+    n, g = 3000, 12
     cfg = scenarios.params_to_config(scenarios.blob_params(n, param_k=k, param_epsilon=0.06 * (scale if all_dims else 1.0),
                                                            param_delta=0.05 * (scale if all_dims else 1.0)))
     h, o = _hdd(cfg, window=512, lookahead=3), O.OracleHDDStream(cfg)
