@@ -119,6 +119,9 @@ struct cc_handle {
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
+    // threads per workgroup of the validation kernels (32-lane groups x 32).  k_chain in workgroups of one wave: beside a
+    // lookahead scan a small workgroup finds room on a single SIMD (measured: 4 % per window in steady state)
+    int chain_threads = 64, decide_threads = 256, commit_threads = 256;
     bool allow_scan_u = true;  // k_scan_u where it applies (CHRONOCLUST_HIP_SCANU=0: always k_scan)
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
@@ -569,6 +572,12 @@ int cc_create(int device, cc_handle** out)
         h->allow_nodirty = !(nd && nd[0] == '0');
         const char* cl = getenv("CHRONOCLUST_HIP_CLAIMS");
         h->allow_claims = !(cl && cl[0] == '0');
+        const char* ct = getenv("CHRONOCLUST_HIP_CHAIN_THREADS");
+        if (ct && (atoi(ct) == 64 || atoi(ct) == 128 || atoi(ct) == 256)) h->chain_threads = atoi(ct);
+        const char* dt = getenv("CHRONOCLUST_HIP_DECIDE_THREADS");
+        if (dt && (atoi(dt) == 64 || atoi(dt) == 128 || atoi(dt) == 256)) h->decide_threads = atoi(dt);
+        const char* mt = getenv("CHRONOCLUST_HIP_COMMIT_THREADS");
+        if (mt && (atoi(mt) == 64 || atoi(mt) == 128 || atoi(mt) == 256)) h->commit_threads = atoi(mt);
         const char* su = getenv("CHRONOCLUST_HIP_SCANU");
         if (su) h->allow_scan_u = atoi(su) != 0;
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
@@ -1253,9 +1262,12 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // partials per point of this batch's clean scans (a pending lookahead scan was launched with the same value:
             // it only depends on the window size, and a change of that restarts the lookahead chain)
             const int S = scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h));
-            const int dblocks = (gw + 7) / 8;   // one 32-lane group per point, 8 groups per workgroup
-            const int cblocks = (gw + 7) / 8;
-            const int rblocks = std::min((gw + 7) / 8, 1024);
+            const int decide_threads = h->decide_threads;
+            const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
+            const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
+            const int cblocks = (gw + chain_threads / 32 - 1) / (chain_threads / 32);
+            const int commit_threads = h->commit_threads;
+            const int rblocks = std::min((gw + commit_threads / 32 - 1) / (commit_threads / 32), 1024 * (256 / commit_threads));
             // few MCs: the claims of a window are gathered per MC by k_claims (rows beyond scan_rows, e.g. rows created
             // during the batch, keep k_decide's atomics)
             const int scan_rows = (h->allow_claims && h->hc.m_rows > 0 && h->hc.m_rows <= 1024) ? h->hc.m_rows : 0;
@@ -1322,7 +1334,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 } else {
                     timed_scan(sA, 0, 0);
                 }
-                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                    dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
                                    h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer);
                 if (scan_rows > 0)
@@ -1332,11 +1344,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 // this window's own
                 const ScanCopy sc_now = scopy[seq_host & 1ull];
                 if (la_on)
-                    hipLaunchKernelGGL(k_apply_carry, dim3(rblocks), dim3(256), 0, sA, h->rec.p, car, sc_now, h->d, h->hc.filter);
+                    hipLaunchKernelGGL(k_apply_carry, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, car, sc_now, h->d, h->hc.filter);
                 for (int r = 1; r <= Rcur; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
-                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(256), 0, sA,
+                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(chain_threads), 0, sA,
                                        h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
                     if (long_rows > 0)
                         hipLaunchKernelGGL(k_chain_long, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
@@ -1347,7 +1359,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
                     }
-                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
+                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
                                        dec_inner, dec_outer);
                     if (scan_rows > 0)
@@ -1355,7 +1367,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                    h->rk.p, h->rec.p);
-                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(256), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
+                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
                                    h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
                 if (la_on) {
                     evCommit = get_event(h, ev_sync++);
