@@ -173,7 +173,8 @@ struct cc_handle {
     DevBuf<int> a_idx, a_pidx;
     DevBuf<int> flags;
 
-    std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pool, sync_pool;
+    bool light_sync_events = true;
 
     // exact multi-GPU path: this handle is rank comm.rank of comm.world replicas of one stream
     cc::Comm comm;
@@ -505,6 +506,18 @@ hipEvent_t get_event(cc_handle* h, size_t i)
     return h->ev_pool[i];
 }
 
+// events that only order the two streams (never read back): no timestamp, device-scope release
+hipEvent_t get_sync_event(cc_handle* h, size_t i)
+{
+    if (!h->light_sync_events) return get_event(h, i);
+    while (h->sync_pool.size() <= i) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventReleaseToDevice));
+        h->sync_pool.push_back(e);
+    }
+    return h->sync_pool[i];
+}
+
 struct RowList {
     std::vector<int> pcore, outlier;  // table rows in Python list order
 };
@@ -578,6 +591,8 @@ int cc_create(int device, cc_handle** out)
         if (dt && (atoi(dt) == 64 || atoi(dt) == 128 || atoi(dt) == 256)) h->decide_threads = atoi(dt);
         const char* mt = getenv("CHRONOCLUST_HIP_COMMIT_THREADS");
         if (mt && (atoi(mt) == 64 || atoi(mt) == 128 || atoi(mt) == 256)) h->commit_threads = atoi(mt);
+        const char* se = getenv("CHRONOCLUST_HIP_LIGHT_EVENTS");
+        if (se) h->light_sync_events = atoi(se) != 0;
         const char* su = getenv("CHRONOCLUST_HIP_SCANU");
         if (su) h->allow_scan_u = atoi(su) != 0;
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
@@ -614,6 +629,7 @@ void cc_destroy(cc_handle* h)
         (void)hipStreamDestroy(h->stream2);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->sync_pool) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -1326,7 +1342,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     // parity (= the table as the previous commit left it), while this window is validated on the first
                     HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
                     timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
-                    evScan = get_event(h, ev_sync++);
+                    evScan = get_sync_event(h, ev_sync++);
                     HIPCHK(hipEventRecord(evScan, sB));
                     // only the first window of a lookahead batch can need an in-place scan (the device idles the
                     // rest of a batch whose lookahead chain breaks, see Ctl::stall_b)
@@ -1370,7 +1386,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
                                    h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
                 if (la_on) {
-                    evCommit = get_event(h, ev_sync++);
+                    evCommit = get_sync_event(h, ev_sync++);
                     HIPCHK(hipEventRecord(evCommit, sA));
                 }
             }
