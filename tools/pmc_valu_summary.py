@@ -1,4 +1,4 @@
-"""VALU utilisation of the clean k_scan from two rocprofv3 --pmc passes over tools/steady.py (LA=2: scans run alone).
+"""VALU utilisation of the snapshot scan (k_scan_u) from two rocprofv3 --pmc passes over tools/steady.py (LA=2: scans run alone).
 Usage: pmc_valu_summary.py <dir of pass a: GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU>
                            <dir of pass b: GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES>"""
 import glob
@@ -11,7 +11,7 @@ import pandas as pd
 def full_launches(d):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     df = pd.read_csv(f)
-    df = df[df["Kernel_Name"].str.contains("k_scan<20, false", regex=False) & df["Kernel_Name"].str.contains("false, 4>", regex=False)]
+    df = df[df["Kernel_Name"].str.contains("k_scan_u<20, 4>", regex=False)]
     g = df.groupby(["Dispatch_Id", "Counter_Name"])["Counter_Value"].sum().unstack()
     t = df.groupby("Dispatch_Id").agg(s=("Start_Timestamp", "first"), e=("End_Timestamp", "first"), grid=("Grid_Size", "first"))
     g["us"] = (t["e"] - t["s"]) / 1e3
@@ -24,7 +24,7 @@ a, na = full_launches(sys.argv[1])
 b, nb = full_launches(sys.argv[2])
 cycles = a["GRBM_GUI_ACTIVE"] / 8.0  # the counter sums the 8 XCDs
 out = {
-    "kernel": "k_scan<20, false, true, false, 4>, 24576 points x 5000 microclusters, running alone",
+    "kernel": "k_scan_u<20, 4>, 24576 points x 5000 microclusters, running alone",
     "launches": [na, nb],
     "avg_us_under_pmc": [float(a["us"]), float(b["us"])],
     "effective_clock_ghz": float(cycles / (a["us"] * 1e3)),
