@@ -500,7 +500,8 @@ hipEvent_t get_event(cc_handle* h, size_t i)
 {
     while (h->ev_pool.size() <= i) {
         hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
+        // (timestamps are all the host reads from these: no system-scope release when one is recorded)
+        HIPCHK(hipEventCreateWithFlags(&e, h->light_sync_events ? hipEventReleaseToDevice : hipEventDefault));
         h->ev_pool.push_back(e);
     }
     return h->ev_pool[i];
@@ -1301,9 +1302,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
+                hipEvent_t scan_end = nullptr;  // the event recorded right behind the last timed scan (nothing after it yet)
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
                     const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
                     const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
+                    scan_end = nullptr;
                     if (timing) {
                         hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
                         HIPCHK(hipEventRecord(a, st));
@@ -1311,6 +1314,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         HIPCHK(hipEventRecord(b, st));
                         timed.push_back({ev_used, 0.0});
                         ev_used += 2;
+                        if (!shard_on) scan_end = b;
                     } else {
                         launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
                     }
@@ -1342,8 +1346,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     // parity (= the table as the previous commit left it), while this window is validated on the first
                     HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
                     timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
-                    evScan = get_sync_event(h, ev_sync++);
-                    HIPCHK(hipEventRecord(evScan, sB));
+                    if (scan_end) evScan = scan_end;  // the timing event already marks the end of the scan: no second record
+                    else {
+                        evScan = get_sync_event(h, ev_sync++);
+                        HIPCHK(hipEventRecord(evScan, sB));
+                    }
                     // only the first window of a lookahead batch can need an in-place scan (the device idles the
                     // rest of a batch whose lookahead chain breaks, see Ctl::stall_b)
                     if (wv == 0 && h->hc.mode == 0) timed_scan(sA, 0, 0);
