@@ -1539,6 +1539,12 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
         const bool ran = nodirty == 0 && ver.skip[j >> 6] == 0;
         const bool ran_car = nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
+        if (!ran && !ran_car) {
+            // no dirty scan ran for this point's tile (the steady state): the seeds are the whole result, every lane
+            // reads them itself and nothing has to be merged
+            dvp = dseed[(size_t)j * 4 + 0];
+            dvo = dseed[(size_t)j * 4 + 2];
+        } else {
         if ((gl & 15) == 0 && !(ran && (ran_car || !la_mode))) {
             dvp = dseed[(size_t)j * 4 + 0];
             dvo = dseed[(size_t)j * 4 + 2];
@@ -1561,6 +1567,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             cc_top2_push(dvp, dummy, b0);
             cc_top2_push(dvo, dummy, b1);
         });
+        }
     }
 
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
