@@ -1723,10 +1723,7 @@ __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Tab
 // group of the first point that targets a MC walks that MC's chain, every step dimension-parallel.
 // ---------------------------------------------------------------------------------
 
-#ifndef CC_CHAIN_WGS
-#define CC_CHAIN_WGS 1
-#endif
-__global__ __launch_bounds__(256, CC_CHAIN_WGS) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+__global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                Versions ver, Carry car, const int* __restrict__ T, int round,
                                                int long_rows)
 {
