@@ -104,6 +104,9 @@ SEEDED = [
     (6, 3000, 64, 20, 0.01, {}, 512),                                                   # CC_MAX_DIM
     (7, 5000, 8, 30, 0.03, dict(param_k=1), 1024),                                      # API default k = 1
     (8, 2500, 5, 10, 0.2, dict(param_epsilon=0.05), 1024),                              # almost everything is noise
+    (9, 3000, 4, 15, 0.02, dict(param_k=2), 512),       # the remaining widths k_scan_u is compiled for: 4, 16, 32
+    (10, 3000, 16, 40, 0.01, dict(param_k=8), 1024),
+    (11, 3000, 32, 30, 0.01, {}, 512),
 ]
 
 
