@@ -401,6 +401,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
         // the common case (k a power of two, no pdim filter, no padded dimensions): rows as scalar operands
         static_assert(ScanShape<DP, false>::PT == 1, "k_scan_u holds one window point per lane");
         if (scan_u_applies(h, DP)) {
+            ++h->stats.scan_u_launches;
             hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
             return;

@@ -93,7 +93,7 @@ typedef struct cc_stats {
     int64_t windows;         /* windows committed                                 */
     int64_t rounds;          /* validation rounds executed                        */
     int64_t truncated;       /* windows committed short of their full size       */
-    int64_t scan_launches;   /* k_scan launches timed (time_kernels = 1)         */
+    int64_t scan_launches;   /* snapshot-scan launches timed (time_kernels = 1)  */
     double  scan_ms;         /* sum of their HIP-event durations                  */
     double  scan_pair_dims;  /* (point, microcluster, dim) triples they covered   */
     double  run_ms;          /* HIP-event time of the whole cc_online_run         */
@@ -104,7 +104,8 @@ typedef struct cc_stats {
     int64_t comm_launches;   /* merge + all-gather steps timed (time_kernels = 1)  */
     double  comm_ms;         /* sum of their HIP-event durations                  */
     int64_t seq_points;      /* points taken by the sequential kernel             */
-    int64_t reserved[1];
+    int64_t scan_u_launches; /* snapshot scans launched as k_scan_u (rows as scalar
+                              * operands) rather than the LDS-staged k_scan          */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

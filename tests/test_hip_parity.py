@@ -127,6 +127,14 @@ def test_seeded_against_oracle(seed, n, d, g, sigma, over, window):
         _check_against_oracle(h, o)
     s = h.stats()
     assert s["points"] == len(X)
+    # which snapshot scan ran: rows as scalar operands (k_scan_u) exactly when k is a power of two, the pdim filter is
+    # off and d is one of the compiled widths; the LDS-staged k_scan otherwise (division path, filter, padded d)
+    k = float(cfg["k"])
+    pow2 = k > 0 and np.log2(k) == round(np.log2(k))
+    filter_on = 0 < float(cfg["pi"]) < d
+    expect_u = pow2 and not filter_on and d in (4, 8, 14, 16, 20, 32, 40, 64)
+    if s["windows"] > 0:  # (a small table may have gone to the sequential kernel altogether: no scans at all)
+        assert (s["scan_u_launches"] > 0) == expect_u, (s["scan_u_launches"], k, cfg["pi"], d)
 
 
 @pytest.mark.parametrize("wps,window,sigma,eps", [(1, 64, 0.2, 0.05), (1, 96, 0.08, 0.06), (3, 64, 0.2, 0.05)])
