@@ -448,7 +448,7 @@ def main():
             hbm = alg_bytes / secs / 1e9
             issued = 3.0 * pair_dims / secs / 1e12
             out["roofline"] = {
-                "bound": "fp64_valu", "kernel": "k_scan_u<20, 4> (snapshot scan)", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
+                "bound": "fp64_valu", "kernel": ("k_scan_u<%d, 4> (snapshot scan)" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<DIRTY=false> (snapshot scan)", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
                 "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
                 "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
                 "instr_per_pair_dim": 3.0, "pair_dims_per_launch": pair_dims / scan_launches,
