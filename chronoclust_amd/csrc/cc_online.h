@@ -4,9 +4,13 @@
 // read-modify-write chain over the microcluster (MC) table.  The kernels below
 // keep those semantics exactly while processing a window of B points at a time:
 //
-//   k_scan<DIRTY=false>  every window point against every MC of the window-start
-//                        snapshot: per point the two best pcore and the two best
-//                        outlier candidates by (projected distance, list order)
+//   k_scan_u             every window point against every MC of the window-start
+//   (k_scan<DIRTY=false>) snapshot: per point the two best pcore and the two best
+//                        outlier candidates by (projected distance, list order).
+//                        k_scan_u reads the MC rows as scalar operands (scalar loads,
+//                        nothing through LDS) and serves k = 2^e, pi >= d and the
+//                        compiled widths of d; k_scan stages rows in LDS and serves
+//                        the rest (pdim filter, other k, padded d)
 //   k_decide (round 0)   the decision each point would take if no earlier window
 //                        point existed (exact for the first point of the window)
 //   k_chain              replays the claimed decisions per MC in arrival order ->
