@@ -43,3 +43,26 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no oracle", ""), "%s mentions the oracle" % f
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every structure that crosses the boundary, field by field: a C program compiled against include/chronoclust_hip.h
+    (plain gcc: the header is C) prints sizeof and the offset of every member; the ctypes mirrors must say the same."""
+    import subprocess
+    pairs = [("cc_params", _lib.CcParams), ("cc_tuning", _lib.CcTuning), ("cc_stats", _lib.CcStats),
+             ("cc_relaxed_stats", _lib.CcRelaxedStats)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "chronoclust_hip.h"', 'int main(void) {']
+    for cname, ctype in pairs:
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for field, _ in ctype._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, field, cname, field))
+    lines += ['return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ctype in pairs:
+        assert int(out[cname]) == ctypes.sizeof(ctype), cname
+        for field, _ in ctype._fields_:
+            assert int(out["%s.%s" % (cname, field)]) == getattr(ctype, field).offset, (cname, field)
