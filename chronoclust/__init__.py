@@ -1,0 +1,23 @@
+"""`chronoclust` — the reference's import path, served by the MI355X build.
+
+`from chronoclust import app; app.run(...)` (sample_run_script/sample_run.py:1, chronoclust/setup.py: package name
+`chronoclust`) resolves to `chronoclust_amd.app`; the sub-modules a user of the reference imports
+(`chronoclust.clustering.hddstream`, `chronoclust.tracking.cluster_tracker`, `chronoclust.scaling.scaler`,
+`chronoclust.objects.cluster`, `chronoclust.objects.microcluster`) are the very module objects of `chronoclust_amd`
+(registered in sys.modules below), so state and classes are shared whichever name was used for the import.
+
+The per-vector numba helpers of the reference (`chronoclust.utilities.*`, `chronoclust.clustering.predecon`,
+`chronoclust.objects.predecon_mc`) have no counterpart: that arithmetic lives in the HIP kernels behind
+include/chronoclust_hip.h (seam B4)."""
+import importlib
+import sys
+
+_ALIASES = ("app", "clustering", "clustering.hddstream", "tracking", "tracking.cluster_tracker", "scaling",
+            "scaling.scaler", "objects", "objects.cluster", "objects.microcluster")
+
+for _name in _ALIASES:
+    _mod = importlib.import_module("chronoclust_amd." + _name)
+    sys.modules[__name__ + "." + _name] = _mod
+    if "." not in _name:
+        globals()[_name] = _mod
+del _name, _mod

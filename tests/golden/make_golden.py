@@ -15,6 +15,9 @@ Outputs
                 columns of the expected cluster_points_D*.csv, and per-timepoint
                 dumps of the reference HDDStream state (scaled inputs, per-point
                 MC uid, MC tables, clusters in merge order)
+  c1_sample_run/  the literal config 1 of BASELINE.json: sample_run_script/sample_run.py's call (no gating file,
+                omicron = 4.35e-6) on the same d0-d4 inputs as c1/: result.csv, the five
+                cluster_points_D*.csv (gzip) and the per-timepoint state dumps
   nocluster/    the 10-row subset inputs + what the reference writes for them
   tracker_scenarios.json   every scenario of the reference's two tracking
                 unit-test files, recorded as call sequences + observed ids
@@ -197,6 +200,40 @@ def gen_c1():
 
 
 # --------------------------------------------------------------------------
+# literal config 1: sample_run_script/sample_run.py:5-22 (same inputs as c1, no gating file, omicron 4.35e-6)
+# --------------------------------------------------------------------------
+
+def gen_c1_sample_run():
+    from chronoclust import app
+    src = os.path.join(HERE, "c1")  # synthetic_dataset/ == tests/.../full_dataset/ (verified by cmp below)
+    dst = os.path.join(HERE, "c1_sample_run")
+    os.makedirs(dst, exist_ok=True)
+    data = [os.path.join(src, "synthetic_d%d.csv.gz" % t) for t in range(5)]
+    for t in range(5):
+        a = gzip.open(os.path.join(refenv.REFERENCE_ROOT, "synthetic_dataset", "synthetic_d%d.csv.gz" % t), "rb").read()
+        assert a == gzip.open(data[t], "rb").read(), "synthetic_dataset differs from the integration test's inputs"
+    rec = Recorder()
+    rec.install()
+    out = tempfile.mkdtemp()
+    try:
+        app.run(data=data, output_directory=out, **scenarios.SAMPLE_RUN_PARAMS)
+    finally:
+        rec.uninstall()
+        reset_logging()
+    shutil.copyfile(os.path.join(out, "result.csv"), os.path.join(dst, "expected_result.csv"))
+    extra = {}
+    for t in range(5):
+        ids, cl = read_labels(os.path.join(out, "cluster_points_D%d.csv" % t))
+        assert (ids == np.arange(len(ids))).all()
+        extra["t%d_cluster_id" % t] = cl
+        extra["t%d_points_csv" % t] = np.frombuffer(
+            gzip.compress(open(os.path.join(out, "cluster_points_D%d.csv" % t), "rb").read(), mtime=0), dtype=np.uint8)
+    save_calls(os.path.join(dst, "hdd_state.npz"), rec.calls, extra, keep_x=False)
+    shutil.rmtree(out)
+    print("c1_sample_run: pcore/outlier per tp", [(len(c["pcore_id"]), len(c["outlier_id"])) for c in rec.calls])
+
+
+# --------------------------------------------------------------------------
 # no-cluster integration test (no_cluster_test.py:24-43)
 # --------------------------------------------------------------------------
 
@@ -342,9 +379,11 @@ def gen_blobs(names=None):
 
 if __name__ == "__main__":
     refenv.load()
-    what = sys.argv[1:] or ["c1", "nocluster", "tracker", "blobs"]
+    what = sys.argv[1:] or ["c1", "c1_sample_run", "nocluster", "tracker", "blobs"]
     if "c1" in what:
         gen_c1()
+    if "c1_sample_run" in what:
+        gen_c1_sample_run()
     if "nocluster" in what:
         gen_nocluster()
     if "tracker" in what:

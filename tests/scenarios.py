@@ -11,6 +11,9 @@ import numpy as np
 # chronoclust/tests/integration_test/normal_test.py:34-51
 C1_PARAMS = dict(param_beta=0.2, param_delta=0.05, param_epsilon=0.03, param_lambda=2, param_k=4, param_mu=0.01,
                  param_pi=3, param_omicron=0.000000435, param_upsilon=6.5)
+# sample_run_script/sample_run.py:6-22 (BASELINE.json config 1, literally): as C1 but omicron = 4.35e-6, no gating file
+SAMPLE_RUN_PARAMS = dict(param_beta=0.2, param_delta=0.05, param_epsilon=0.03, param_lambda=2, param_k=4, param_mu=0.01,
+                         param_pi=3, param_omicron=0.00000435, param_upsilon=6.5)
 # chronoclust/tests/integration_test/no_cluster_test.py:29-43
 NOCLUSTER_PARAMS = dict(param_beta=1.0, param_delta=0.05, param_epsilon=0.03, param_lambda=2, param_k=4,
                         param_mu=1.0, param_pi=3, param_omicron=0.000000435, param_upsilon=6.5)

@@ -54,6 +54,46 @@ def test_c1_integration_golden(tmp_path):
     # logs/Chronoclust.log: logging.basicConfig is a no-op under pytest (root handlers exist), as upstream
 
 
+def test_sample_run_script_verbatim(tmp_path, monkeypatch):
+    """BASELINE.json config 1: the reference's sample_run_script/sample_run.py:1-22, statement for statement - the
+    `chronoclust` import path, the bundled d0-d4 files addressed relative to the working directory, its config dict
+    (omicron 4.35e-6, no gating file) and its call - against the outputs of the reference itself."""
+    import shutil
+    c1 = os.path.join(GOLDEN, "c1")
+    os.makedirs(os.path.join(str(tmp_path), "synthetic_dataset"))
+    os.makedirs(os.path.join(str(tmp_path), "sample_run_script", "output"))
+    for t in range(5):
+        shutil.copyfile(os.path.join(c1, "synthetic_d%d.csv.gz" % t),
+                        os.path.join(str(tmp_path), "synthetic_dataset", "synthetic_d%d.csv.gz" % t))
+    monkeypatch.chdir(os.path.join(str(tmp_path), "sample_run_script"))
+    try:
+        from chronoclust import app
+
+        data_directory = '../synthetic_dataset'
+        data_files = ['{}/synthetic_d{}.csv.gz'.format(data_directory, x) for x in range(5)]
+        config = {"beta": 0.2, "delta": 0.05, "epsilon": 0.03, "lambda": 2, "k": 4, "mu": 0.01, "pi": 3,
+                  "omicron": 0.00000435, "upsilon": 6.5}
+        output_directory = 'output'
+        app.run(data=data_files, output_directory=output_directory, param_beta=config['beta'],
+                param_delta=config['delta'], param_epsilon=config['epsilon'], param_lambda=config['lambda'],
+                param_k=config['k'], param_mu=config['mu'], param_pi=config['pi'], param_omicron=config['omicron'],
+                param_upsilon=config['upsilon'])
+    finally:
+        _reset_logging()
+    import chronoclust_amd.app
+    assert app is chronoclust_amd.app
+    exp_dir = os.path.join(GOLDEN, "c1_sample_run")
+    assert open(os.path.join("output", "result.csv"), "rb").read() == \
+        open(os.path.join(exp_dir, "expected_result.csv"), "rb").read()
+    rec = np.load(os.path.join(exp_dir, "hdd_state.npz"))
+    for t in range(5):
+        assert open(os.path.join("output", "cluster_points_D%d.csv" % t), "rb").read() == \
+            gzip.decompress(rec["t%d_points_csv" % t].tobytes())
+    with open(os.path.join("output", "parameters.csv")) as f:
+        assert f.read().splitlines() == ["beta,delta,epsilon,lambda,k,mu,pi,omicron,upsilon",
+                                         "0.2,0.05,0.03,2,4,0.01,3,4.35e-06,6.5"]
+
+
 def test_nocluster_integration_golden(tmp_path):
     """chronoclust/tests/integration_test/no_cluster_test.py: no result rows, every point labelled None."""
     from chronoclust_amd import app

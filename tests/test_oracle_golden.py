@@ -137,6 +137,25 @@ def test_c1_state_matches_reference():
     _replay(dump, Xs, scenarios.params_to_config(scenarios.C1_PARAMS))
 
 
+def _c1_sample_run_inputs(dump):
+    """The scaled inputs are those of c1/ (same files, same scaler); the dump only keeps their hashes."""
+    import hashlib
+    c1 = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
+    Xs = [c1.get(t, "X") for t in range(c1.n_timepoints)]
+    for t, X in enumerate(Xs):
+        sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(X).tobytes()).digest(), dtype=np.uint8)
+        assert (sha == dump.get(t, "xsha")).all()
+    return Xs
+
+
+def test_c1_sample_run_state_matches_reference():
+    """BASELINE.json config 1 literally (sample_run_script/sample_run.py:6-22, omicron 4.35e-6: other microcluster
+    counts than c1/ from the fourth timepoint on - 10/99 and 15/124 instead of 10/101 and 15/128)."""
+    dump = StateDump(os.path.join(GOLDEN, "c1_sample_run", "hdd_state.npz"))
+    h = _replay(dump, _c1_sample_run_inputs(dump), scenarios.params_to_config(scenarios.SAMPLE_RUN_PARAMS))
+    assert (len(h.table(O.PCORE)["id"]), len(h.table(O.OUTLIER)["id"])) == (15, 124)
+
+
 def test_nocluster_state_matches_reference():
     dump = StateDump(os.path.join(GOLDEN, "nocluster", "hdd_state.npz"))
     Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
