@@ -7,17 +7,28 @@ PreDeCon phase (cc_offline) with the export of all clusters.
 
 At N GPUs the headline `value` is N independent event streams of the C2 shape, one per rank (weak scaling, no
 data-path collective: the online phase of one stream is a sequential chain over its points).  The same JSON line
-also carries `one_stream_exact`: ONE stream of the stress config's shape (d = 40, 50 000 microclusters) clustered by
-all N GPUs together - snapshot scans split by table rows, one RCCL all-gather of 64 B per window point, offline pair
-matrices split by rows - with a check that every rank ended with the same bytes, and
-`events_sharded_relaxed`: one stream of the WNV shape (d = 14, 2 000 microclusters) with its EVENTS sharded over the
-GPUs and an RCCL all-reduce of the CF deltas per super-step - relaxed semantics, reported with its agreement with the
-exact path.
+also carries, as side legs (strong scaling: ONE stream, all N GPUs):
+  one_stream_exact            the stress config's shape (d = 40, 50 000 microclusters), exact: snapshot scans split by
+                              table rows, one RCCL all-gather of 64 B per window point, offline pair matrices split by
+                              rows, with a check that every rank ended with the same bytes
+  events_sharded_relaxed      the WNV shape (d = 14, 2 000 microclusters), EVENTS sharded over the GPUs with an RCCL
+                              all-reduce of the CF deltas per super-step - relaxed semantics, reported with its agreement
+                              with the exact path
+  one_stream_exact_c2         the headline's own 20-dim shape (C2) as ONE stream on all GPUs, exact: at 5 000 x 20 the
+                              library does not split the scan (a window's scan is shorter than the all-gather that would
+                              follow it), so every rank repeats the work; the same leg with the split forced is beside it
+  events_sharded_relaxed_c2   the C2 shape, relaxed event-sharded, with its agreement
+Every leg carries `n_gpus`, `collective`, `rccl_ranks_seen` and a `roofline` object of its own scan kernel.
+
+No torch anywhere: the timing bracket is cc_sync (HIP stream synchronise through the C-ABI), barrier / max over
+ranks / the 128-byte RCCL id travel over chronoclust_amd.rendezvous (TCP on 127.0.0.1).  Any launcher that sets
+RANK / WORLD_SIZE / LOCAL_RANK will do:
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Exit status: 0 when every leg ran; 3 when a leg was abandoned (a collective that
+never completed) or failed - the line is still printed, with the error in that leg's object.
 """
 import argparse
 import hashlib
@@ -35,7 +46,20 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
+EXIT_LEG_FAILED = 3
+
+
+def csrc_digest():
+    """SHA-256 over the kernel sources: a PMC traffic figure is only quoted for the kernels it was measured on."""
+    m = hashlib.sha256()
+    d = os.path.join(ROOT, "chronoclust_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            with open(os.path.join(d, name), "rb") as f:
+                m.update(name.encode() + b"\0" + f.read())
+    return m.hexdigest()
 
 
 class LineGuard:
@@ -156,9 +180,11 @@ def cpu_baseline(cfg, X, sample, cores, gpu_uid):
                                     "core" % cores}
     # the Python reference itself, measured in the build container (1 core, d = 20, 100 - 400 microclusters;
     # BASELINE.md section 2): it cannot be imported on the GPU box
-    out["reference_py"] = {"value": [209, 571], "unit": "points/s", "cores": 1,
-                           "note": "ghar1821/Chronoclust (no-op numba stand-in), N = 10 k, d = 20, M = 400 / 100, "
-                                   "committed measurement, not re-run here"}
+    try:
+        with open(REFERENCE_RATE_FILE) as f:
+            out["reference_py"] = json.load(f)  # written by tools/time_reference.py in the build container
+    except (OSError, ValueError):
+        out["reference_py"] = None
     return out
 
 
@@ -177,16 +203,45 @@ def digest_of(h):
     return m.hexdigest()
 
 
-def one_stream_exact(args, rank, world, local_rank, dist, sync):
-    """ONE stream on all ranks (exact multi-GPU path).  Every rank generates the same input."""
+def scan_roofline(acc, d, kernel):
+    """The `roofline` object of a leg's snapshot scan from the library's own HIP-event timing of every launch
+    (cc_stats, time_kernels = 1): 3 fp64 VALU instructions per (point, microcluster, dim), see the headline's comment."""
+    secs = acc["scan_ms"] * 1e-3
+    if not secs or not acc["scan_launches"]:
+        return None
+    issued = 3.0 * acc["scan_pair_dims"] / secs / 1e12
+    return {"bound": "fp64_valu", "kernel": kernel, "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
+            "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
+            "launches": int(acc["scan_launches"]), "avg_launch_us": 1e3 * acc["scan_ms"] / acc["scan_launches"],
+            "pair_dims_per_launch": acc["scan_pair_dims"] / acc["scan_launches"], "instr_per_pair_dim": 3.0}
+
+
+def scan_kernel_name(s, d):
+    return ("k_scan_u<%d, 4>" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<%d, DIRTY=false>" % d
+
+
+def join_group(h, rank, world, group):
+    """Makes `h` a member of the RCCL group of all ranks (one rank alone: a communicator of one, the same code path)."""
     from chronoclust_amd import _lib, multi
-    n, d, g = args.stream_points, args.stream_dim, args.stream_blobs
-    X = make_blobs(4242, n, d, g)
+    if world > 1:
+        multi.join_stream_group(h, group)
+    else:
+        h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)
+    seen = group.all_gather_bytes(b"%d" % h.comm_info()["world"])
+    return [int(x) for x in seen]
+
+
+def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, force_split=False):
+    """ONE stream on all ranks (exact multi-GPU path).  Every rank generates the same input."""
+    from chronoclust_amd import multi
+    from chronoclust_amd import _lib
+    X = make_blobs(seed, n, d, g)
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
     h.set_tuning(time_kernels=1)
-    if world > 1:
-        multi.join_stream_group(h, dist)
+    seen = join_group(h, rank, world, group) if (world > 1 or force_split) else [1]
+    if force_split:
+        h.set_shard_thresholds(0, 0)
     set_params(h, cfg, n, d)
     h.points_upload(X)
     del X
@@ -200,56 +255,72 @@ def one_stream_exact(args, rank, world, local_rank, dist, sync):
 
     for _ in range(args.stream_warmup):
         step()
-    sync()
+    sync(h)
     t0 = time.perf_counter()
     acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0)
     for _ in range(args.stream_steps):
         s, n_clusters = step()
         for k in acc:
             acc[k] += s[k]
-    sync()
+    sync(h)
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    elapsed = multi.max_over_ranks(elapsed, group)
     dg = digest_of(h)
-    agree = multi.all_ranks_equal(dg, dist) if world > 1 else True
+    agree = group.all_equal(dg.encode())
     info = h.comm_info()
-    if world > 1:
+    if info["transport"] != "none":
         h.comm_destroy()
     h.close()
-    secs = acc["scan_ms"] * 1e-3
     return {
-        "workload": "C5-shaped: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters, exact sequential "
-                    "semantics; online + offline phases per step; every rank holds the table and the points, "
-                    "scans 1/%d of the table rows per window" % (n, d, g, world),
+        "workload": "%s: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters, exact sequential "
+                    "semantics; online + offline phases per step; every rank holds the table and the points%s" % (
+                        label, n, d, g, ", scans 1/%d of the table rows per window" % world if s["sharded_windows"] else
+                        "; the table is below the split threshold (rows x d < 400 000): every rank scans all rows"),
         "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
-        "n_gpus": world, "steps": args.stream_steps, "warmup": args.stream_warmup,
+        "n_gpus": world, "rccl_ranks_seen": seen, "steps": args.stream_steps, "warmup": args.stream_warmup,
         "ms_per_step": 1e3 * elapsed / args.stream_steps,
-        "collective": "none (one rank)" if world == 1 else "%s all-gather of 64 B per window point, %d per step; "
-                      "offline: all-gather of preference vectors + reachability bitmask" % (
-                          info["transport"], int(acc["comm_launches"] / args.stream_steps)),
+        "collective": "none (one rank, no group)" if info["transport"] == "none" else (
+            "%s all-gather of 64 B per window point on the scan's stream (two communicators, one per stream), %d per "
+            "step; offline: all-gather of preference vectors + reachability bitmask" % (
+                info["transport"], int(acc["comm_launches"] / args.stream_steps))),
         "microclusters": int(s["rows"]), "clusters": n_clusters, "windows_per_step": int(s["windows"]),
         "sharded_windows_per_step": int(s["sharded_windows"]),
         "rank0_online_ms_per_step": acc["run_ms"] / args.stream_steps,
         "rank0_scan_ms_per_step": acc["scan_ms"] / args.stream_steps,
         "rank0_exchange_ms_per_step": acc["comm_ms"] / args.stream_steps,
-        "rank0_scan_fp64_valu_frac": (3.0 * acc["scan_pair_dims"] / secs / 1e12 / FP64_VALU_PEAK_TOPS) if secs else None,
+        "roofline": scan_roofline(acc, d, scan_kernel_name(s, d)),
         "all_ranks_bit_identical": bool(agree), "state_sha256": dg[:16],
     }
 
 
-def events_sharded_relaxed(args, rank, world, local_rank, dist, sync):
-    """ONE stream of the WNV shape (d = 14, 2 000 microclusters), its EVENTS sharded over the ranks: the relaxed mode
-    (cc_comm_set_relaxed).  Not the reference's semantics - the agreement with the exact path is reported beside the
-    rate (rank 0 runs the exact path on the same input after the timed region)."""
+def one_stream_exact(args, rank, world, local_rank, group, sync):
+    return exact_leg(args, rank, world, local_rank, group, sync, args.stream_points, args.stream_dim, args.stream_blobs,
+                     4242, "C5-shaped")
+
+
+def one_stream_exact_c2(args, rank, world, local_rank, group, sync):
+    """The headline's shape as ONE stream on all GPUs: default thresholds (5 000 x 20 is not split), then the split
+    forced - the number that shows why the library does not split a table this small."""
+    n, d, g = args.points, args.dim, args.blobs
+    out = exact_leg(args, rank, world, local_rank, group, sync, n, d, g, 42, "C2-shaped")
+    forced = exact_leg(args, rank, world, local_rank, group, sync, n, d, g, 42, "C2-shaped, split forced", force_split=True)
+    out["split_forced"] = {k: forced[k] for k in ("value", "ms_per_step", "collective", "sharded_windows_per_step",
+                                                   "rank0_scan_ms_per_step", "rank0_exchange_ms_per_step",
+                                                   "all_ranks_bit_identical", "state_sha256", "rccl_ranks_seen")}
+    out["split_note"] = "state_sha256 of the two runs must agree: the split changes where rows are scanned, not a result"
+    return out
+
+
+def relaxed_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label):
+    """ONE stream, its EVENTS sharded over the ranks: the relaxed mode (cc_comm_set_relaxed).  Not the reference's
+    semantics - the agreement with the exact path is reported beside the rate (rank 0 runs the exact path on the
+    same input after the timed region)."""
     from chronoclust_amd import _lib, multi
-    n, d, g = args.relaxed_points, 14, 2000
-    X = make_blobs(777, n, d, g)
+    X = make_blobs(seed, n, d, g)
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
-    if world > 1:
-        multi.join_stream_group(h, dist)
-    else:
-        h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)  # a communicator of one rank: the same code path
+    h.set_tuning(time_kernels=1)
+    seen = join_group(h, rank, world, group)
     h.comm_set_relaxed(args.relaxed_minibatch)
     set_params(h, cfg, n, d)
     h.points_upload(X)
@@ -263,16 +334,19 @@ def events_sharded_relaxed(args, rank, world, local_rank, dist, sync):
 
     for _ in range(args.stream_warmup):
         step()
-    sync()
+    sync(h)
     t0 = time.perf_counter()
+    acc = dict(scan_ms=0.0, scan_launches=0, scan_pair_dims=0.0)
     for _ in range(args.stream_steps):
         s, arrays = step()
-    sync()
+        for k in acc:
+            acc[k] += s[k]
+    sync(h)
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    elapsed = multi.max_over_ranks(elapsed, group)
     rs = h.relaxed_stats()
     dg = digest_of(h)
-    agree_ranks = multi.all_ranks_equal(dg, dist) if world > 1 else True
+    agree_ranks = group.all_equal(dg.encode())
     uid, _ = h.labels_download()
     pc = h.export(_lib.PCORE)
     pci = multi.point_cluster_index(uid, pc["id"], pc["uid"], arrays[0], arrays[1])
@@ -280,18 +354,19 @@ def events_sharded_relaxed(args, rank, world, local_rank, dist, sync):
     h.comm_destroy()
     h.close()
     out = {
-        "workload": "C4-shaped: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters; its events sharded "
-                    "over %d rank(s) in contiguous blocks; online + offline phases per step" % (n, d, g, world),
+        "workload": "%s: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters; its events sharded "
+                    "over %d rank(s) in contiguous blocks; online + offline phases per step" % (label, n, d, g, world),
         "semantics": "RELAXED (not the reference's): per super-step of %d points per rank the ranks cluster against "
                      "the shared table without seeing each other's adds, CF deltas are all-reduced, points that no "
                      "MC absorbs are clustered on every rank redundantly" % args.relaxed_minibatch,
         "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
-        "n_gpus": world, "steps": args.stream_steps, "warmup": args.stream_warmup,
+        "n_gpus": world, "rccl_ranks_seen": seen, "steps": args.stream_steps, "warmup": args.stream_warmup,
         "ms_per_step": 1e3 * elapsed / args.stream_steps,
         "collective": "RCCL all-reduce (sum, f64) of [%d, 2 x %d + 1] CF deltas + all-gather of the set-aside point "
                       "indices per super-step, %d super-steps per step" % (int(s["rows"]), d, rs["super_steps"]),
         "microclusters": int(s["rows"]), "clusters": n_clusters,
         "set_aside_points_per_step": rs["deferred_points"], "all_ranks_bit_identical": bool(agree_ranks),
+        "roofline": scan_roofline(acc, d, scan_kernel_name(s, d)),
     }
     if rank == 0:
         # the exact path on the same input, one GPU: what the relaxed result is measured against
@@ -314,6 +389,14 @@ def events_sharded_relaxed(args, rank, world, local_rank, dist, sync):
     return out
 
 
+def events_sharded_relaxed(args, rank, world, local_rank, group, sync):
+    return relaxed_leg(args, rank, world, local_rank, group, sync, args.relaxed_points, 14, 2000, 777, "C4-shaped")
+
+
+def events_sharded_relaxed_c2(args, rank, world, local_rank, group, sync):
+    return relaxed_leg(args, rank, world, local_rank, group, sync, args.points, args.dim, args.blobs, 42, "C2-shaped")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,9 +413,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads of the all-cores CPU column (at most the usable cores)")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (testing)")
     ap.add_argument("--share-gpu", action="store_true", help="testing: every rank uses GPU 0")
-    ap.add_argument("--no-one-stream", action="store_true", help="skip the one-stream-on-all-GPUs leg")
+    ap.add_argument("--no-one-stream", action="store_true", help="skip the one-stream-on-all-GPUs leg (C5-shaped)")
     ap.add_argument("--stream-points", type=int, default=2_000_000)
     ap.add_argument("--stream-dim", type=int, default=40)
     ap.add_argument("--stream-blobs", type=int, default=50_000)
@@ -340,9 +422,11 @@ def main():
     ap.add_argument("--stream-warmup", type=int, default=1)
     ap.add_argument("--stream-timeout", type=float, default=240.0,
                     help="seconds after which a one-stream leg that has not finished is abandoned")
-    ap.add_argument("--no-relaxed", action="store_true", help="skip the event-sharded relaxed leg")
+    ap.add_argument("--no-relaxed", action="store_true", help="skip the event-sharded relaxed leg (C4-shaped)")
     ap.add_argument("--relaxed-points", type=int, default=5_000_000)
     ap.add_argument("--relaxed-minibatch", type=int, default=65536, help="points per rank and super-step")
+    ap.add_argument("--no-c2-legs", action="store_true", help="skip the two C2-shaped strong-scaling legs")
+    ap.add_argument("--only-leg", default=None, help="profiling: skip the headline's CPU baseline and run only this leg")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints its path when a communicator is
@@ -350,24 +434,17 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    from chronoclust_amd import multi
+    from chronoclust_amd import multi, rendezvous
     rank, world, local_rank = multi.rank_info()
-    guard = LineGuard(json_fd) if rank == 0 else None  # (before torch, HIP or RCCL exist in this process)
+    guard = LineGuard(json_fd) if rank == 0 else None  # (before HIP or RCCL exist in this process)
 
     def emit(obj):
         guard.final(obj)
 
-    import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if args.share_gpu:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.dist_backend)
+    group = rendezvous.from_env()  # barrier, max over ranks, the RCCL id: plain TCP, no torch
+    if args.share_gpu:
+        local_rank = 0
+    os.environ.setdefault("CHRONOCLUST_HIP_COMM_TIMEOUT_S", str(int(args.stream_timeout)))
 
     from chronoclust_amd import _lib
     n, d, g = args.points, args.dim, args.blobs
@@ -386,15 +463,16 @@ def main():
         arrays, _ = h.offline_arrays()  # cc_offline + cc_clusters_export: every cluster's members and CF vectors on the host
         return s, len(arrays[2])
 
-    def sync():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
+    def sync(handle):
+        """The timing bracket: everything this rank enqueued is done (cc_sync: the handle's HIP streams), every
+        rank has got here (barrier), and once more in case the barrier let a straggler's work overlap."""
+        handle.sync()
+        group.barrier()
+        handle.sync()
 
     for _ in range(args.warmup):
         step()
-    sync()
+    sync(h)
     t0 = time.perf_counter()
     scan_ms = scan_launches = 0.0
     pair_dims = table_rows = 0.0
@@ -406,9 +484,9 @@ def main():
         pair_dims += s["scan_pair_dims"]
         table_rows += s["table_rows_scanned"]
         online_ms += s["run_ms"]
-    sync()
+    sync(h)
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, dist, device="cuda" if args.dist_backend == "nccl" else "cpu")
+    elapsed = multi.max_over_ranks(elapsed, group)
     uid, _ = h.labels_download()
 
     out = None
@@ -434,6 +512,8 @@ def main():
                        "lookahead_windows_per_step": int(s["lookahead_windows"]),
                        "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
             "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,
+            "harness": "no torch: cc_sync for the timing bracket, chronoclust_amd.rendezvous (TCP) for barrier / max "
+                       "over ranks / RCCL id",
         }
         if scan_launches:
             # The dominant kernel is bound by fp64 VALU issue, not by HBM (intensity ~1.5 M flop/B): per
@@ -448,28 +528,33 @@ def main():
             hbm = alg_bytes / secs / 1e9
             issued = 3.0 * pair_dims / secs / 1e12
             out["roofline"] = {
-                "bound": "fp64_valu", "kernel": ("k_scan_u<%d, 4> (snapshot scan)" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<DIRTY=false> (snapshot scan)", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
+                "bound": "fp64_valu", "kernel": scan_kernel_name(s, d) + " (snapshot scan)", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
                 "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
                 "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
                 "instr_per_pair_dim": 3.0, "pair_dims_per_launch": pair_dims / scan_launches,
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
                         "note": "algorithmic bytes: the window's points (8d + 4 label bytes each) + the table columns "
-                                "the distance reads (16d + 8 bytes per row); this roof does not bind"},
+                                "the distance reads (16d + 8 bytes per row); this roof does not bind: at ~1.5 M flop/B "
+                                "the path is FP64-VALU-bound for M >> 10, so north_star's '>= 60 % of the HBM roofline' "
+                                "cannot be met by an exact implementation at these table sizes (README.md)"},
                 "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead scans "
                                "(second stream, beside the validation kernels of the previous window, including the "
                                "few that go unused) and in-place scans (short windows of the start-up phase included)"}
             # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
-            # separate runs); only quoted when it was measured on this workload shape
+            # separate runs); only quoted when it was measured on this workload shape AND on these kernel sources
             try:
                 with open(PMC_TRAFFIC_FILE) as f:
                     pmc = json.load(f)
-                if (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
+                if pmc.get("csrc_sha256") != csrc_digest():
+                    out["roofline"]["traffic_note"] = "profiles/%s was measured on other kernel sources (csrc digest " \
+                                                      "differs): not quoted" % os.path.basename(PMC_TRAFFIC_FILE)
+                elif (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
                     out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
                     out["roofline"]["traffic_note"] = pmc["note"]
             except (OSError, KeyError, ValueError):
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.only_leg:
             # (the GPU box gives a one-GPU job 16 of the host's cores; os.cpu_count() reports the whole machine)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             out["cpu_baseline"] = cpu_baseline(cfg, X, args.cpu_sample, max(1, min(usable, args.cpu_cores)), uid)
@@ -484,36 +569,52 @@ def main():
         legs.append(("one_stream_exact", one_stream_exact))
     if not args.no_relaxed:
         legs.append(("events_sharded_relaxed", events_sharded_relaxed))
+    if not args.no_c2_legs:
+        legs.append(("one_stream_exact_c2", one_stream_exact_c2))
+        legs.append(("events_sharded_relaxed_c2", events_sharded_relaxed_c2))
+    if args.only_leg:
+        legs = [(nm, fn) for nm, fn in legs if nm == args.only_leg]
+    status = 0
     for name, fn in legs:
         # A collective that never completes must not take the headline measurement with it: every rank arms a
-        # timer; if the leg is still running when it fires, rank 0 prints the line without it and all ranks leave.
+        # timer; if the leg is still running when it fires, rank 0 prints the line without it and all ranks leave -
+        # with a non-zero status: a hung collective is not a clean exit.  (Inside the library every wait for a
+        # collective is bounded as well and returns CC_ERR_COMM; the timer is the backstop for everything else.)
         done = threading.Event()
 
         def abandon(name=name, done=done):
             if done.is_set():
                 return
             if rank == 0:
-                out[name] = {"error": "not finished after %.0f s, abandoned" % args.stream_timeout}
+                out[name] = {"error": "not finished after %.0f s, abandoned" % (1.5 * args.stream_timeout)}
                 emit(out)
-            os._exit(0)
+            else:
+                sys.stderr.write("[bench rank %d] leg %s not finished after %.0f s, abandoned\n" % (
+                    rank, name, 1.5 * args.stream_timeout))
+            os._exit(EXIT_LEG_FAILED)
 
-        timer = threading.Timer(args.stream_timeout, abandon)
+        timer = threading.Timer(1.5 * args.stream_timeout, abandon)
         timer.daemon = True
         timer.start()
         try:
-            leg = fn(args, rank, world, local_rank, dist, sync)
+            leg = fn(args, rank, world, local_rank, group, sync)
         except Exception as e:  # noqa: BLE001 - reported in the line
             leg = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("[bench rank %d] leg %s failed: %s\n" % (rank, name, leg["error"]))
         done.set()
         timer.cancel()
         if rank == 0:
             out[name] = leg
-        if "error" in leg and world > 1:
-            break  # the ranks may no longer be in step: no further collective legs
+        # the ranks must agree on whether to go on: one that failed may have left the others' group
+        failed = not group.all_equal(b"ok" if "error" not in leg else b"failed:" + str(rank).encode()) or "error" in leg
+        if failed:
+            status = EXIT_LEG_FAILED
+            if world > 1:
+                break  # the ranks may no longer be in step: no further collective legs
     if rank == 0:
         emit(out)
-    if dist is not None:
-        dist.destroy_process_group()
+    group.close()
+    sys.exit(status)
 
 
 if __name__ == "__main__":

@@ -81,6 +81,7 @@ SYMBOLS = {
     "cc_clusters_export": (C.c_int, [C.c_void_p, _i64p, _i32p, _dp, _dp, _dp, _dp, _dp]),
     "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
     "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
+    "cc_sync": (C.c_int, [C.c_void_p]),
     "cc_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "cc_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -163,6 +164,7 @@ class Handle(object):
                                       "device; there is no CPU fallback." % (device, _ERRORS.get(rc, rc)))
         self._h = h
         self.device = device
+        self._prefetched = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -202,13 +204,18 @@ class Handle(object):
         x = _f64(x)
         if x.ndim != 2:
             raise ValueError("points must be a 2-d array")
-        self._check(self._lib.cc_points_upload(self._h, _ptr(x), x.shape[0], x.shape[1]))
+        try:
+            self._check(self._lib.cc_points_upload(self._h, _ptr(x), x.shape[0], x.shape[1]))
+        finally:
+            self._prefetched = None  # adopted or discarded by the library: the array is no longer pinned by us
         self._n = x.shape[0]
 
     def points_prefetch(self, x, scale=None, min_=None):
         """Starts the background upload of the NEXT timepoint's points (cc_points_prefetch).  `x` must be the very
         array (C-contiguous float64) that is later passed to points_upload / points_upload_scaled / online; the
-        handle keeps a reference to it until then."""
+        handle keeps a reference to it until then.  Contract: the array must not be written to between this call and
+        that upload - the upload is recognised by pointer, shape and scaling, and the copy already on the device is
+        used as it is."""
         if not (isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags["C_CONTIGUOUS"] and x.ndim == 2):
             raise ValueError("points_prefetch needs a C-contiguous float64 [n, d] array (it is not copied)")
         if x.shape[0] == 0:
@@ -231,7 +238,11 @@ class Handle(object):
         x, scale, min_ = _f64(x), _f64(scale), _f64(min_)
         if x.ndim != 2 or scale.shape != (x.shape[1],) or min_.shape != (x.shape[1],):
             raise ValueError("points must be [n, d], scale and min_ [d]")
-        self._check(self._lib.cc_points_upload_scaled(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(scale), _ptr(min_)))
+        try:
+            self._check(self._lib.cc_points_upload_scaled(self._h, _ptr(x), x.shape[0], x.shape[1], _ptr(scale),
+                                                          _ptr(min_)))
+        finally:
+            self._prefetched = None
         self._n = x.shape[0]
 
     def points_download(self, d, scale=None, min_=None):
@@ -364,6 +375,10 @@ class Handle(object):
 
     def set_shard_thresholds(self, min_row_dims=-1, offline_min_rows=-1):
         self._check(self._lib.cc_set_shard_thresholds(self._h, int(min_row_dims), int(offline_min_rows)))
+
+    def sync(self):
+        """Waits for everything enqueued on the handle's HIP streams (cc_sync): the timing bracket of bench.py."""
+        self._check(self._lib.cc_sync(self._h))
 
     def stats(self):
         s = CcStats()

@@ -175,7 +175,6 @@ def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by
     state = hddstream.get_state()
     state[TRACKER_HISTORICAL_ASSOC] = np.frombuffer(pickle.dumps(tracker_by_association), dtype=np.uint8)
     state[TRACKER_LINEAGE] = np.frombuffer(pickle.dumps(tracker_by_lineage), dtype=np.uint8)
-    state["image_timepoint"] = np.int64(hddstream.last_data_timestamp)
     buf = io.BytesIO()
     np.savez(buf, **state)
     final = os.path.join(d, HDDSTREAM_OBJ + '.npz')
@@ -190,11 +189,25 @@ def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by
 def restore_program_state(program_state_dir, hddstream):
     """Loads what save_program_state wrote into `hddstream`; returns the two trackers (app.py:436-465)."""
     import pickle
-    with np.load(os.path.join(program_state_dir, HDDSTREAM_OBJ + '.npz')) as z:
+    path = os.path.join(program_state_dir, HDDSTREAM_OBJ + '.npz')
+    with np.load(path) as z:
         state = {k: z[k] for k in z.files}
-    if int(state["image_timepoint"]) != int(state["last_data_timestamp"]):
-        raise ValueError("program image is inconsistent: trackers of timepoint {} beside microclusters of {}".format(
-            int(state["image_timepoint"]), int(state["last_data_timestamp"])))
+    if TRACKER_HISTORICAL_ASSOC not in state or TRACKER_LINEAGE not in state:
+        # an image of the earlier layout: tables in the .npz, the trackers pickled beside it
+        legacy = {name: os.path.join(program_state_dir, name + '.pkl') for name in (TRACKER_HISTORICAL_ASSOC, TRACKER_LINEAGE)}
+        missing = [f for f in legacy.values() if not os.path.exists(f)]
+        if missing:
+            raise ValueError("program image {} holds no trackers and {} not found: it was not written by this version "
+                             "of chronoclust_amd (or is incomplete); rerun without restore_program".format(
+                                 path, " / ".join(missing)))
+        for name, f in legacy.items():
+            with open(f, 'rb') as fh:
+                state[name] = np.frombuffer(fh.read(), dtype=np.uint8)
+    needed = ("last_data_timestamp", "dataset_size", "dataset_dimensionality", "pcore_MC_last_id", "outlier_MC_last_id")
+    absent = [k for k in needed if k not in state]
+    if absent:
+        raise ValueError("program image {} lacks {}: not an image of chronoclust_amd".format(path, ", ".join(absent)))
+    state.pop("image_timepoint", None)
     tracker_by_association = pickle.loads(state.pop(TRACKER_HISTORICAL_ASSOC).tobytes())
     tracker_by_lineage = pickle.loads(state.pop(TRACKER_LINEAGE).tobytes())
     hddstream.set_state(state)
@@ -204,10 +217,19 @@ def restore_program_state(program_state_dir, hddstream):
 
 def drop_rows_after(result_filename, last_timepoint):
     """A run that stopped between writing timepoint t's rows and saving t's image resumes at t: rows of
-    timepoints the image does not cover are dropped before result.csv is appended to again."""
+    timepoints the image does not cover are dropped before result.csv is appended to again.  A last row torn by a
+    crash in the middle of a write (short, or without a readable timepoint) is dropped like them."""
     with open(result_filename, newline='') as f:
         rows = list(csv.reader(f))
-    keep = rows[:1] + [r for r in rows[1:] if r and int(r[0]) <= last_timepoint]
+    width = len(rows[0]) if rows else 0
+
+    def covered(r):
+        try:
+            return len(r) == width and int(r[0]) <= last_timepoint
+        except ValueError:
+            return False
+
+    keep = rows[:1] + [r for r in rows[1:] if covered(r)]
     if len(keep) != len(rows):
         tmp = result_filename + '.tmp'
         with open(tmp, 'w') as f:

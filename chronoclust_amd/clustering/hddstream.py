@@ -140,7 +140,8 @@ class HDDStream(object):
     def prefetch(self, input_dataset, device_scaling=None):
         """Starts uploading the NEXT timepoint in the background (cc_points_prefetch) while the caller still works on the
         current one.  Returns the array to pass to online_microcluster_maintenance (the same buffer, so that the upload
-        is recognised); results never depend on whether a timepoint was prefetched."""
+        is recognised); results never depend on whether a timepoint was prefetched.  The returned array must not be
+        modified before it is passed on: the device copy made here is the one that gets clustered."""
         X = np.ascontiguousarray(np.asarray(input_dataset, dtype=np.float64))
         if X.ndim == 2 and X.shape[0] > 0:
             if device_scaling is None:

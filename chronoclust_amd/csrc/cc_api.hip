@@ -225,22 +225,41 @@ int fail(cc_handle* h, int code, const std::string& msg)
     return code;
 }
 
+// Every non-OK way out of a call made while the handle belongs to a group leaves the peers waiting for a rank that
+// will not come: the group is given up (in-process peers are released, RCCL communicators aborted) and the peers
+// get CC_ERR_COMM instead of hanging.
+void group_lost(cc_handle* h)
+{
+    if (h && h->comm.active()) h->comm.fail_group();
+}
+
 template <typename F>
 int guarded(cc_handle* h, F&& f)
 {
     try {
         if (h) HIPCHK(hipSetDevice(h->device));
-        return f();
+        const int rc = f();
+        if (rc < 0) group_lost(h);
+        return rc;
     } catch (const HipErr& e) {
         char buf[512];
         snprintf(buf, sizeof buf, "HIP error %d (%s) in %s", (int)e.e, hipGetErrorString(e.e), e.what);
-        if (h && h->comm.local) h->comm.local->abandon();  // peers of an in-process group must not wait for this rank
+        group_lost(h);
         return fail(h, e.e == hipErrorOutOfMemory ? CC_ERR_OOM : CC_ERR_NO_DEVICE, buf);
     } catch (const cc::CommErr& e) {
+        group_lost(h);
         return fail(h, CC_ERR_COMM, "exchange between ranks failed: " + e.what);
     } catch (const std::bad_alloc&) {
+        group_lost(h);
         return fail(h, CC_ERR_OOM, "host allocation failed");
     }
+}
+
+// hipStreamSynchronize of a stream that may hold a collective of the handle's group: bounded (cc::Comm::wait_stream)
+void sync_stream(cc_handle* h, hipStream_t st)
+{
+    if (h->comm.rccl() || h->comm.broken) h->comm.wait_stream(st);
+    else HIPCHK(hipStreamSynchronize(st));
 }
 
 bool is_pow2(double k)
@@ -272,7 +291,7 @@ void push_ctl(cc_handle* h) { HIPCHK(hipMemcpyAsync(h->ctl.p, &h->hc, sizeof(Ctl
 void pull_ctl(cc_handle* h)
 {
     HIPCHK(hipMemcpyAsync(&h->hc, h->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    sync_stream(h, h->stream);
 }
 
 // grow the table to at least `rows` rows, keeping the first m_rows rows
@@ -303,7 +322,7 @@ void ensure_table(cc_handle* h, size_t rows)
     if (m > 0) HIPCHK(hipMemcpyAsync(nt.carry_of.p, h->tab.carry_of.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(nt.cnt.p, 0, want * 8, h->stream));
     HIPCHK(hipMemsetAsync(nt.clen.p, 0, want * 4, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    sync_stream(h, h->stream);
     h->tab.swap(nt);
 }
 
@@ -532,7 +551,7 @@ RowList list_order(cc_handle* h, std::vector<int>* kind_out = nullptr, std::vect
     if (m) {
         HIPCHK(hipMemcpyAsync(kind.data(), h->tab.kind.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(key.data(), h->tab.key.p, (size_t)m * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
     }
     RowList rl;
     for (int r = 0; r < m; ++r) {
@@ -600,7 +619,7 @@ int cc_create(int device, cc_handle** out)
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return CC_OK;
     });
     if (rc != CC_OK) {
@@ -619,8 +638,17 @@ void cc_destroy(cc_handle* h)
     if (h->pf.stream) (void)hipStreamDestroy(h->pf.stream);
     for (int q = 0; q < 2; ++q)
         if (h->pf.pin[q]) (void)hipHostFree(h->pf.pin[q]);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    // (a pending collective whose peer is gone must not hang the destructor: bounded wait, then abort)
+    auto drain = [&](hipStream_t st) {
+        if (!st) return;
+        try {
+            if (h->comm.rccl() && !h->comm.broken) h->comm.wait_stream(st);
+            else (void)hipStreamSynchronize(st);
+        } catch (const cc::CommErr&) {
+        }
+    };
+    drain(h->stream);
+    drain(h->stream2);
     h->comm.destroy();
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
@@ -670,7 +698,7 @@ int cc_reset(cc_handle* h)
         h->n_core = 0;
         refresh_ctl_params(h);
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -702,7 +730,7 @@ int cc_set_counters(cc_handle* h, int64_t pcore_last_id, int64_t outlier_last_id
         h->hc.pcore_last_id = pcore_last_id;
         h->hc.outlier_last_id = outlier_last_id;
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -730,7 +758,7 @@ int cc_col_minmax(cc_handle* h, const double* x, int64_t n, int32_t d, double* o
                            chunks);
         std::vector<double> part((size_t)2 * chunks * d);
         HIPCHK(hipMemcpyAsync(part.data(), h->scr2.p, part.size() * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         for (int c = 0; c < d; ++c) {
             double mn = std::numeric_limits<double>::infinity(), mx = -mn;
             for (int b = 0; b < chunks; ++b) {
@@ -803,7 +831,7 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
                        h->Xt.p, (long long)n, (int)d);
     int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    sync_stream(h, h->stream);
     if (bad) {
         h->n_points = 0;
         return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
@@ -899,7 +927,7 @@ int cc_points_download(cc_handle* h, double* out, const double* scale, const dou
                                tot, d, h->scr2.p, h->scr2.p + d);
             HIPCHK(hipMemcpyAsync(out, h->scr.p, (size_t)tot * 8, hipMemcpyDeviceToHost, h->stream));
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -914,8 +942,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
 void comm_all_reduce_sum(cc_handle* h, double* buf, size_t count, hipStream_t st)
 {
     cc::Comm& cm = h->comm;
-    if (cm.nccl) {
-        cm.check(cc::RcclApi::get().AllReduce(buf, buf, count, ncclDouble, ncclSum, cm.nccl, st), "ncclAllReduce");
+    if (cm.rccl()) {
+        if (cm.broken) throw cc::CommErr{"the group has failed earlier"};
+        cm.check(cc::RcclApi::get().AllReduce(buf, buf, count, ncclDouble, ncclSum, cm.lane(0), st), "ncclAllReduce");
         return;
     }
     if (!cm.local || cm.world == 1) return;
@@ -976,7 +1005,7 @@ int online_relaxed(cc_handle* h)
         }
         // ---- A: this rank's mini-batch, no MC creation ----
         const auto tA0 = std::chrono::steady_clock::now();
-        if (h->trace) HIPCHK(hipStreamSynchronize(st));
+        if (h->trace) sync_stream(h, st);
         const auto tA1 = std::chrono::steady_clock::now();
         int rc = online_range(h, a, e, true, sidx > 0);
         const auto tA2 = std::chrono::steady_clock::now();
@@ -1009,7 +1038,7 @@ int online_relaxed(cc_handle* h)
         if (total > 0) {  // (the same decision on every rank: the counts are the gathered ones)
             h->comm.all_gather(h->r_didx.p, h->r_didx_all.p, (size_t)(b + 1) * 4, st);
             HIPCHK(hipMemcpyAsync(didx_host.data(), h->r_didx_all.p, didx_host.size() * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            sync_stream(h, st);
             for (int r = 0; r < W; ++r) {
                 const int* blk = didx_host.data() + (size_t)r * (b + 1);
                 list.insert(list.end(), blk + 1, blk + 1 + blk[0]);
@@ -1064,7 +1093,7 @@ int online_relaxed(cc_handle* h)
     // every rank's shard of the labels to every rank (in place, shards padded to the same length)
     h->comm.all_gather(h->lab_uid.p + (size_t)rank * L, h->lab_uid.p, (size_t)L * 8, st);
     h->comm.all_gather(h->lab_path.p + (size_t)rank * L, h->lab_path.p, (size_t)L, st);
-    HIPCHK(hipStreamSynchronize(st));
+    sync_stream(h, st);
     HIPCHK(hipGetLastError());
     h->stats.points = N;
     return (int)CC_OK;
@@ -1327,7 +1356,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
                                            h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode);
                         h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
-                                           (size_t)gw * 4 * sizeof(Cand), st);
+                                           (size_t)gw * 4 * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
                         if (timing) {
                             HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
                             timed_comm.push_back(ev_used);
@@ -1400,7 +1429,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             }
             HIPCHK(hipGetLastError());
             pull_ctl(h);
-            if (la_on) HIPCHK(hipStreamSynchronize(sB));
+            if (la_on) sync_stream(h, sB);
             seq_host = h->hc.window_seq;
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
@@ -1594,7 +1623,7 @@ int cc_labels_download(cc_handle* h, int64_t* out_uid, int8_t* out_path)
         static_assert(sizeof(long long) == sizeof(int64_t), "int64");
         if (out_uid) HIPCHK(hipMemcpyAsync(out_uid, h->lab_uid.p, n * 8, hipMemcpyDeviceToHost, h->stream));
         if (out_path) HIPCHK(hipMemcpyAsync(out_path, h->lab_path.p, n, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -1633,7 +1662,7 @@ int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w, doub
             if (!out) return;
             std::vector<double> tmp(m * d);
             HIPCHK(hipMemcpyAsync(tmp.data(), dev, m * d * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            sync_stream(h, h->stream);
             for (size_t i = 0; i < n; ++i) memcpy(out + i * d, tmp.data() + (size_t)rows[i] * d, d * 8);
         };
         fetch_vec(h->tab.cf1.p, cf1);
@@ -1643,14 +1672,14 @@ int cc_export(cc_handle* h, int kind, int64_t* id, int64_t* uid, double* w, doub
         if (w) {
             std::vector<double> tmp(m);
             HIPCHK(hipMemcpyAsync(tmp.data(), h->tab.w.p, m * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            sync_stream(h, h->stream);
             for (size_t i = 0; i < n; ++i) w[i] = tmp[rows[i]];
         }
         auto fetch_i64 = [&](const long long* dev, int64_t* out) {
             if (!out) return;
             std::vector<long long> tmp(m);
             HIPCHK(hipMemcpyAsync(tmp.data(), dev, m * 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            sync_stream(h, h->stream);
             for (size_t i = 0; i < n; ++i) out[i] = tmp[rows[i]];
         };
         fetch_i64(h->tab.id.p, id);
@@ -1682,13 +1711,13 @@ int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const dou
         HIPCHK(hipMemcpyAsync(h->tab.key.p + r, &key, 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->tab.id.p + r, &lid, 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->tab.uid.p + r, &luid, 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         h->hc.m_rows += 1;
         if (kind == CC_PCORE && id >= h->hc.pcore_last_id) h->hc.pcore_last_id = id + 1;
         if (uid >= h->hc.outlier_last_id) h->hc.outlier_last_id = uid + 1;
         refresh_ctl_params(h);
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -1720,7 +1749,7 @@ int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* c
         HIPCHK(hipMemcpyAsync(h->tab.key.p + r, keys.data(), nn * 4, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->tab.id.p + r, id, nn * 8, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->tab.uid.p + r, uid, nn * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         nkeys += n;
         h->hc.m_rows += n;
         for (size_t i = 0; i < nn; ++i) {
@@ -1729,7 +1758,7 @@ int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* c
         }
         refresh_ctl_params(h);
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -1797,13 +1826,13 @@ int cc_decay_downgrade(cc_handle* h, double factor)
             hipLaunchKernelGGL(k_gather_rows, dim3((n * d + 255) / 256), dim3(256), 0, h->stream, tab, h->tab2.view(),
                                dperm.p, dkind.p, dkey.p, dnid.p, n, d);
         }
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         h->tab.swap(h->tab2);
         h->hc.m_rows = n;
         h->hc.n_pkeys = np;
         h->hc.n_okeys = no;
         push_ctl(h);
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -1882,7 +1911,7 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(nw_cnt.data(), h->nw_cnt.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(h->pcore_ids_host.data(), h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         HIPCHK(hipGetLastError());
         std::vector<long long> nw_off((size_t)mp + 1, 0);
         for (int i = 0; i < mp; ++i) nw_off[(size_t)i + 1] = nw_off[i] + nw_cnt[i];
@@ -1894,7 +1923,7 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
             HIPCHK(hipMemcpyAsync(h->nw_off.p, nw_off.data(), ((size_t)mp + 1) * 8, hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(k_adj_fill, dim3(mp), dim3(64), 0, h->stream, h->adjw.p, words, mp, h->nw_off.p, h->nw_nbr.p);
             HIPCHK(hipMemcpyAsync(nbr.data(), h->nw_nbr.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
+            sync_stream(h, h->stream);
             HIPCHK(hipGetLastError());
         }
 
@@ -1944,7 +1973,7 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
             hipLaunchKernelGGL(k_cluster_merge, dim3((unsigned)((cd + 255) / 256)), dim3(256), 0, h->stream, pv,
                                h->mem_dev.p, h->off_dev.p, nc, d, p.delta_sq, p.k, h->c_cf1.p, h->c_cf2.p, h->c_cen.p,
                                h->c_pref.p, h->c_w.p);
-            HIPCHK(hipStreamSynchronize(h->stream));
+            sync_stream(h, h->stream);
         }
         if (out_core) memcpy(out_core, core.data(), mp);
         if (out_pdim) memcpy(out_pdim, pdim.data(), (size_t)mp * 4);
@@ -1977,7 +2006,7 @@ int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, doub
         if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
         if (cen) HIPCHK(hipMemcpyAsync(cen, h->c_cen.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
         if (pref) HIPCHK(hipMemcpyAsync(pref, h->c_pref.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -2011,7 +2040,7 @@ int cc_clusters_export(cc_handle* h, int64_t* members, int32_t* offsets, double*
         if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
         if (cen) HIPCHK(hipMemcpyAsync(cen, h->c_cen.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
         if (pref) HIPCHK(hipMemcpyAsync(pref, h->c_pref.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         return (int)CC_OK;
     });
 }
@@ -2068,7 +2097,11 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
             hipLaunchKernelGGL(k_assoc_merge, dim3((c_hi - c_lo + 255) / 256), dim3(256), 0, h->stream, h->a_pdist.p,
                                h->a_pidx.p, S, mc, c_lo, c_hi, h->a_idx.p, h->a_dist.p);
         } else if (c_hi > c_lo) {
-            HIPCHK(hipMemsetAsync(h->a_idx.p + c_lo, 0xFF, (size_t)(c_hi - c_lo) * 4, h->stream));  // no previous pcores: -1
+            // no previous pcores: index -1, distance +inf (what the argmin kernel starts from)
+            HIPCHK(hipMemsetAsync(h->a_idx.p + c_lo, 0xFF, (size_t)(c_hi - c_lo) * 4, h->stream));
+            const std::vector<double> inf((size_t)(c_hi - c_lo), std::numeric_limits<double>::infinity());
+            HIPCHK(hipMemcpyAsync(h->a_dist.p + c_lo, inf.data(), inf.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));  // (`inf` is a local)
         }
         if (shard) {
             h->comm.all_gather(h->a_idx.p + (size_t)rank * share, h->a_idx.p, (size_t)share * 4, h->stream);
@@ -2076,7 +2109,7 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
         }
         HIPCHK(hipMemcpyAsync(out_idx, h->a_idx.p, (size_t)mc * 4, hipMemcpyDeviceToHost, h->stream));
         if (out_dist) HIPCHK(hipMemcpyAsync(out_dist, h->a_dist.p, (size_t)mc * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        sync_stream(h, h->stream);
         HIPCHK(hipGetLastError());
         return (int)CC_OK;
     });
@@ -2106,11 +2139,35 @@ int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world)
         ncclUniqueId id;
         memcpy(&id, id_bytes, sizeof(id));
         ncclComm_t comm = nullptr;
-        const ncclResult_t r = api.CommInitRank(&comm, world, id, rank);  // (the handle's device is current)
+        ncclResult_t r = api.CommInitRank(&comm, world, id, rank);  // (the handle's device is current)
         if (r != ncclSuccess) return fail(h, CC_ERR_COMM, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
-        h->comm.nccl = comm;
+        h->comm.nccl[0] = comm;
         h->comm.rank = rank;
         h->comm.world = world;
+        h->comm.broken = false;
+        const char* to = getenv("CHRONOCLUST_HIP_COMM_TIMEOUT_S");
+        if (to && atof(to) > 0.0) h->comm.timeout_s = atof(to);
+        // the second communicator (lookahead stream): its id is made by rank 0 and travels through the first one
+        const char* one = getenv("CHRONOCLUST_HIP_ONE_COMM");
+        if (!(one && one[0] == '1')) {
+            DevBuf<char> ids;
+            ids.ensure((size_t)world * sizeof(ncclUniqueId) + sizeof(ncclUniqueId));
+            ncclUniqueId id2;
+            memset(&id2, 0, sizeof id2);
+            if (rank == 0) {
+                r = api.GetUniqueId(&id2);
+                if (r != ncclSuccess) return fail(h, CC_ERR_COMM, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+            }
+            char* send = ids.p + (size_t)world * sizeof(ncclUniqueId);
+            HIPCHK(hipMemcpyAsync(send, &id2, sizeof id2, hipMemcpyHostToDevice, h->stream));
+            h->comm.all_gather(send, ids.p, sizeof id2, h->stream, 0);
+            HIPCHK(hipMemcpyAsync(&id2, ids.p, sizeof id2, hipMemcpyDeviceToHost, h->stream));  // rank 0's block
+            sync_stream(h, h->stream);
+            ncclComm_t comm2 = nullptr;
+            r = api.CommInitRank(&comm2, world, id2, rank);
+            if (r != ncclSuccess) return fail(h, CC_ERR_COMM, std::string("ncclCommInitRank (second communicator): ") + api.GetErrorString(r));
+            h->comm.nccl[1] = comm2;
+        }
         return (int)CC_OK;
     });
 }
@@ -2146,8 +2203,11 @@ int cc_comm_destroy(cc_handle* h)
 {
     if (!h) return CC_ERR_BAD_ARG;
     return guarded(h, [&]() {
-        (void)hipStreamSynchronize(h->stream);
-        (void)hipStreamSynchronize(h->stream2);
+        try {
+            sync_stream(h, h->stream);
+            sync_stream(h, h->stream2);
+        } catch (const cc::CommErr&) {  // (the group is already lost: nothing left to drain)
+        }
         h->comm.destroy();
         return (int)CC_OK;
     });
@@ -2158,7 +2218,7 @@ int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport
     if (!h) return CC_ERR_BAD_ARG;
     if (rank) *rank = h->comm.rank;
     if (world) *world = h->comm.world;
-    if (transport) *transport = h->comm.nccl ? 1 : (h->comm.local ? 2 : 0);
+    if (transport) *transport = h->comm.rccl() ? 1 : (h->comm.local ? 2 : 0);
     return CC_OK;
 }
 
@@ -2193,6 +2253,17 @@ int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_
     if (min_row_dims >= 0) h->shard_min_row_dims = min_row_dims;
     if (offline_min_rows >= 0) h->offline_shard_min_rows = offline_min_rows;
     return CC_OK;
+}
+
+int cc_sync(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        sync_stream(h, h->stream);
+        sync_stream(h, h->stream2);
+        HIPCHK(hipGetLastError());
+        return (int)CC_OK;
+    });
 }
 
 int cc_get_stats(cc_handle* h, cc_stats* out)

@@ -5,7 +5,14 @@
 // Two transports behind one call:
 //   RCCL   one process per GPU; ncclAllGather over xGMI on the stream of the scan that produced the records.
 //          librccl is opened with dlopen when a communicator is first asked for, so single-GPU users of the
-//          library never load it (and the library has no link-time dependency on it).
+//          library never load it (and the library has no link-time dependency on it).  TWO communicators per
+//          group, one per HIP stream of the handle (lane 0: main stream, lane 1: lookahead stream): operations on
+//          one ncclComm_t are serialised by RCCL whatever stream they are enqueued on, which would tie the
+//          lookahead scans' all-gathers to the in-place ones of the validation stream.  The second communicator is
+//          created from an id that travels through the first (all-gather of 128 bytes).  Nothing in the library
+//          waits for a collective without a bound: host waits on a stream that may hold one poll
+//          ncclCommGetAsyncError and a deadline (wait_stream); on an error or when the deadline passes both
+//          communicators are aborted (ncclCommAbort) and the call returns CC_ERR_COMM.
 //   LOCAL  several handles of ONE process (one host thread each) that form a group: the same all-gather done
 //          with stream-ordered device copies between the handles' buffers.  This is how the sharded path is
 //          verified on a machine with a single GPU (two handles on GPU 0, each scanning half of the rows).
@@ -15,10 +22,14 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
+#include <cstdio>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace cc {
@@ -34,6 +45,8 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommGetAsyncError) CommGetAsyncError = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -53,13 +66,19 @@ struct RcclApi {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.dl, "ncclGetUniqueId");
             api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.dl, "ncclCommInitRank");
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.dl, "ncclCommDestroy");
+            api.CommAbort = (decltype(api.CommAbort))dlsym(api.dl, "ncclCommAbort");
+            api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.dl, "ncclCommGetAsyncError");
             api.AllGather = (decltype(api.AllGather))dlsym(api.dl, "ncclAllGather");
             api.AllReduce = (decltype(api.AllReduce))dlsym(api.dl, "ncclAllReduce");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.dl, "ncclGetErrorString");
         });
         return api;
     }
-    bool ok() const { return dl && GetUniqueId && CommInitRank && CommDestroy && AllGather && AllReduce && GetErrorString; }
+    bool ok() const
+    {
+        return dl && GetUniqueId && CommInitRank && CommDestroy && CommAbort && CommGetAsyncError && AllGather && AllReduce &&
+               GetErrorString;
+    }
 };
 
 // ---- in-process group ------------------------------------------------------------------------------------
@@ -103,22 +122,88 @@ struct LocalGroup {
 
 struct Comm {
     int rank = 0, world = 1;
-    ncclComm_t nccl = nullptr;
+    // RCCL: one communicator per stream lane (0: the handle's main stream, 1: its lookahead stream); nccl[1] may be
+    // null (a group set up with one communicator serves both lanes from nccl[0])
+    ncclComm_t nccl[2] = {nullptr, nullptr};
+    bool broken = false;  // the group failed (error, deadline, a peer left): every further exchange fails at once
+    double timeout_s = 120.0;  // bound of every host wait that may hold a collective (CHRONOCLUST_HIP_COMM_TIMEOUT_S)
     std::shared_ptr<LocalGroup> local;
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;  // LOCAL: this rank's two events
 
-    bool active() const { return world > 1 || nccl != nullptr; }
+    bool active() const { return world > 1 || nccl[0] != nullptr; }
+    bool rccl() const { return nccl[0] != nullptr; }
+    ncclComm_t lane(int l) const { return (l == 1 && nccl[1]) ? nccl[1] : nccl[0]; }
 
     void check(ncclResult_t r, const char* what)
     {
-        if (r != ncclSuccess) throw CommErr{std::string(what) + ": " + RcclApi::get().GetErrorString(r)};
+        if (r != ncclSuccess) {
+            fail_group();
+            throw CommErr{std::string(what) + ": " + RcclApi::get().GetErrorString(r)};
+        }
     }
 
-    // recv[p * bytes .. (p + 1) * bytes) = rank p's send[0 .. bytes), for every p, ordered on `st`
-    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t st)
+    // The group is lost for this rank: in-process peers are released (their barriers throw), RCCL communicators are
+    // aborted so that kernels of pending collectives end and the streams drain.  Idempotent.
+    void fail_group()
     {
-        if (nccl) {
-            check(RcclApi::get().AllGather(send, recv, bytes, ncclInt8, nccl, st), "ncclAllGather");
+        if (broken) return;
+        broken = true;
+        if (local) local->abandon();
+        for (int l = 0; l < 2; ++l)
+            if (nccl[l]) {
+                (void)RcclApi::get().CommAbort(nccl[l]);
+                nccl[l] = nullptr;
+            }
+    }
+
+    // hipStreamSynchronize with a bound.  Without an RCCL communicator a plain synchronise (in-process groups block
+    // in host barriers that abandon() releases, not in the stream).  With one: poll the stream, both communicators'
+    // asynchronous error state and the deadline.
+    void wait_stream(hipStream_t st)
+    {
+        if (broken) throw CommErr{"the group has failed earlier"};
+        if (!rccl()) {
+            const hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) throw CommErr{std::string("hipStreamSynchronize: ") + hipGetErrorString(e)};
+            return;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        for (;;) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) {
+                fail_group();
+                throw CommErr{std::string("hipStreamQuery: ") + hipGetErrorString(e)};
+            }
+            if ((++spins & 63u) == 0u) {
+                for (int l = 0; l < 2; ++l) {
+                    ncclResult_t ar = ncclSuccess;
+                    if (nccl[l] && (RcclApi::get().CommGetAsyncError(nccl[l], &ar) != ncclSuccess || (ar != ncclSuccess && ar != ncclInProgress))) {
+                        const std::string msg = std::string("asynchronous RCCL error: ") + RcclApi::get().GetErrorString(ar);
+                        fail_group();
+                        throw CommErr{msg};
+                    }
+                }
+                const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (dt > timeout_s) {
+                    fail_group();
+                    char buf[160];
+                    snprintf(buf, sizeof buf, "a collective did not complete within %.0f s (a peer is gone or stuck); communicators aborted", timeout_s);
+                    throw CommErr{buf};
+                }
+                if (dt > 0.002) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            }
+        }
+    }
+
+    // recv[p * bytes .. (p + 1) * bytes) = rank p's send[0 .. bytes), for every p, ordered on `st`.
+    // lane: which of the handle's two streams `st` is (selects the RCCL communicator)
+    void all_gather(const void* send, void* recv, size_t bytes, hipStream_t st, int lane_idx = 0)
+    {
+        if (broken) throw CommErr{"the group has failed earlier"};
+        if (rccl()) {
+            check(RcclApi::get().AllGather(send, recv, bytes, ncclInt8, lane(lane_idx), st), "ncclAllGather");
             return;
         }
         if (!local) {
@@ -153,10 +238,12 @@ struct Comm {
 
     void destroy()
     {
-        if (nccl) {
-            (void)RcclApi::get().CommDestroy(nccl);
-            nccl = nullptr;
-        }
+        for (int l = 0; l < 2; ++l)
+            if (nccl[l]) {
+                // a communicator that is still healthy is destroyed (collective, drains); a failed group was aborted
+                (void)RcclApi::get().CommDestroy(nccl[l]);
+                nccl[l] = nullptr;
+            }
         if (local) {
             local->abandon();
             local.reset();
@@ -165,6 +252,7 @@ struct Comm {
         if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
         rank = 0;
         world = 1;
+        broken = false;
     }
 };
 

@@ -8,9 +8,11 @@
    candidate record per window point over RCCL (cc_comm_init_rccl), the offline and association pair matrices
    are split by rows.  All ranks end with bit-identical results.  `join_stream_group` sets this up.
 
-`torch.distributed` is plumbing here: the barrier / max-over-ranks time of bench.py and the channel that carries
-the 128-byte RCCL id from rank 0 to the other ranks.  The collectives of the data path are RCCL calls made by
-the C-ABI library on its own HIP streams."""
+The host-side group (`dist` below) is plumbing: the barrier / max-over-ranks time of bench.py and the channel that
+carries the 128-byte RCCL id from rank 0 to the other ranks.  It is a `chronoclust_amd.rendezvous.HostGroup` (plain
+TCP on 127.0.0.1, no torch; what bench.py uses) or, for callers that already run under it, `torch.distributed` -
+the helpers below only use what both offer.  The collectives of the data path are RCCL calls made by the C-ABI
+library on its own HIP streams."""
 import os
 
 
@@ -25,9 +27,11 @@ def stream_seed(base_seed, rank):
 
 
 def max_over_ranks(value, dist=None, device=None):
-    """The job's step time is the slowest rank's.  `dist` is torch.distributed (or None for one process)."""
+    """The job's step time is the slowest rank's.  `dist`: a HostGroup, torch.distributed, or None for one process."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
+    if hasattr(dist, "max_float"):
+        return dist.max_float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -45,7 +49,7 @@ def one_stream_rate(points, steps, seconds):
 
 
 def broadcast_bytes(payload, dist, src=0):
-    """`payload` (bytes on rank `src`, ignored elsewhere) to every rank, through torch.distributed."""
+    """`payload` (bytes on rank `src`, ignored elsewhere) to every rank, through the host-side group."""
     box = [payload if dist.get_rank() == src else None]
     dist.broadcast_object_list(box, src=src)
     return box[0]

@@ -219,7 +219,13 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
  * Small tables are not split (cc_set_shard_thresholds): below ~1 ms of scan per window the exchange costs more
  * than it saves.
  *   cc_comm_unique_id  : rank 0 obtains the 128-byte RCCL id and hands it to the other ranks (any channel)
- *   cc_comm_init_rccl  : joins the communicator (collective; librccl is loaded here, not before)
+ *   cc_comm_init_rccl  : joins the group (collective; librccl is loaded here, not before).  Two communicators are
+ *                        created, one per HIP stream of the handle, so that the all-gathers of lookahead scans
+ *                        (second stream) are not serialised with those of the validation stream; the second
+ *                        one's id travels through the first.  No wait for a collective is unbounded: host waits
+ *                        poll ncclCommGetAsyncError and a deadline (CHRONOCLUST_HIP_COMM_TIMEOUT_S, default
+ *                        120 s); on an error, a missed deadline or any failing call of a member the
+ *                        communicators are aborted (ncclCommAbort) and calls return CC_ERR_COMM
  *   cc_comm_init_local : the in-process group of handles[0..world)
  *   cc_comm_info       : transport 0 none, 1 RCCL, 2 local */
 #define CC_COMM_ID_BYTES 128
@@ -255,6 +261,11 @@ int cc_shard_rows(int32_t n, int32_t world, int32_t rank, int32_t unit, int32_t*
 /* split the scan when rows * d >= min_row_dims, the offline / association pair matrices when rows >=
  * offline_min_rows; a negative value keeps the current setting (defaults 400 000 and 8 192) */
 int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows);
+
+/* Waits until everything the handle has enqueued on its HIP streams is done (the timing bracket of a harness: what
+ * torch.cuda.synchronize() would be for work a framework had launched).  Inside a group the wait is bounded like
+ * every wait of the library that may hold a collective: CC_ERR_COMM when a peer is gone. */
+int cc_sync(cc_handle* h);
 
 int cc_get_stats(cc_handle* h, cc_stats* out);
 

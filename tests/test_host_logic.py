@@ -95,6 +95,41 @@ def test_drop_rows_after_keeps_header_and_earlier_timepoints(tmp_path):
     assert open(fn, newline="").read() == before[:before.index("2,3.0")]
 
 
+def test_drop_rows_after_drops_a_torn_last_row(tmp_path):
+    """A crash in the middle of append_to_file leaves a short last row (or one whose timepoint is cut): it is dropped
+    like the rows of uncovered timepoints instead of blocking the resume with a ValueError."""
+    import csv
+    from chronoclust_amd.app import append_to_file, drop_rows_after, write_file_header
+    fn = str(tmp_path / "result.csv")
+    write_file_header(fn, ["timepoint", "cumulative_size", "tracking_by_lineage"])
+    append_to_file(fn, [[0, "10.0", "A"], [1, "12.5", "B"]])
+    for torn in ("1,3", "", "x1,2.0,C", "1"):
+        whole = open(fn, newline="").read()
+        with open(fn, "a") as f:
+            f.write(torn)
+        drop_rows_after(fn, 1)
+        with open(fn, newline="") as f:
+            assert list(csv.reader(f)) == [["timepoint", "cumulative_size", "tracking_by_lineage"], ["0", "10.0", "A"],
+                                           ["1", "12.5", "B"]]
+        assert open(fn, newline="").read() == whole
+
+
+def test_restore_of_a_foreign_or_incomplete_image_says_so(tmp_path):
+    """restore_program_state on an .npz that save_program_state did not write (keys missing): a clear ValueError
+    before anything touches the GPU, not a bare KeyError."""
+    import pytest
+    from chronoclust_amd import app
+    d = str(tmp_path)
+    np.savez(os.path.join(d, app.HDDSTREAM_OBJ + ".npz"), last_data_timestamp=np.int64(2))
+    with pytest.raises(ValueError, match="holds no trackers"):
+        app.restore_program_state(d, hddstream=None)
+    for name in (app.TRACKER_HISTORICAL_ASSOC, app.TRACKER_LINEAGE):
+        with open(os.path.join(d, name + ".pkl"), "wb") as f:
+            f.write(b"x")
+    with pytest.raises(ValueError, match="lacks dataset_size"):
+        app.restore_program_state(d, hddstream=None)
+
+
 def test_rounded_weights_equal_the_reference_expression():
     """chronoclust_amd.clustering.hddstream.rounded_weights against app.py:184 evaluated per value, on integers,
     decayed weights, exact and near half-way cases (x.y5 decimal strings whose doubles lie on either side)."""

@@ -1,5 +1,7 @@
-"""world_size-2 gloo tests (CPU) of the N > 1 path of bench.py: replicas only, one stream per rank, whole-job
-rate = units of all ranks / max-over-ranks time (chronoclust_amd/multi.py)."""
+"""Multi-process CPU tests of the N > 1 path of bench.py: the helpers of chronoclust_amd/multi.py over world_size-2 gloo
+(torch.distributed) and over the torch-free host group bench.py itself uses (chronoclust_amd/rendezvous.py, worlds of
+2 and 4): rank info, barrier, max-over-ranks time, the channel of the 128-byte RCCL id, the all-ranks-equal check of
+the state digests, the partition arithmetic of the exact multi-GPU path."""
 import os
 import socket
 
@@ -118,6 +120,73 @@ def test_two_rank_id_broadcast_and_digest_check_gloo():
         assert out[0] == out[1] == 4000.0
 
 
+def _host_group_worker(rank, world, rdzv_file, out):
+    """What bench.py does between its legs, on the group it uses: no torch in this process."""
+    import sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), CHRONOCLUST_RDZV_FILE=rdzv_file)
+    from chronoclust_amd import _lib, rendezvous
+    g = rendezvous.from_env(timeout=60.0)
+    try:
+        assert (g.get_rank(), g.get_world_size()) == (rank, world) and multi.rank_info() == (rank, world, rank)
+        g.barrier()
+        assert multi.max_over_ranks(1.0 + rank, g) == float(world)
+        payload = bytes(range(128)) if rank == 0 else None
+        assert multi.broadcast_bytes(payload, g) == bytes(range(128))
+        assert multi.all_ranks_equal("same-digest", g) and not multi.all_ranks_equal("digest-of-rank-%d" % rank, g)
+        assert g.all_equal(b"ok") and (world == 1 or not g.all_equal(b"failed:%d" % rank))
+        parts = g.all_gather_bytes(b"rank%d" % rank * (rank + 1))  # ragged payloads
+        assert parts == [b"rank%d" % r * (r + 1) for r in range(world)]
+        # the partition of the exact multi-GPU path, exchanged through the group
+        mine = [_lib.shard_rows(n, world, rank, unit) for unit in (1, 64) for n in (0, 1, 63, 65, 5000, 123_457)]
+        box = [None] * world
+        g.all_gather_object(box, mine)
+        for i in range(len(mine)):
+            blocks = [b[i] for b in box]
+            assert blocks[0][0] == 0 and all(blocks[r][1] == blocks[r + 1][0] for r in range(world - 1))
+        out[rank] = ("torch" in sys.modules, multi.whole_job_rate(1000, 3, world, multi.max_over_ranks(1.0 + rank, g)))
+    finally:
+        g.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_host_group_without_torch(world, tmp_path):
+    import multiprocessing
+    ctx = multiprocessing.get_context("spawn")
+    rdzv = str(tmp_path / "rdzv")
+    with open(rdzv, "w") as f:
+        f.write("1 stale-token-of-an-earlier-job\n")  # a stale file must not confuse the joiners
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_host_group_worker, args=(r, world, rdzv, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+        assert all(p.exitcode == 0 for p in procs)
+        assert all(out[r][1] == pytest.approx(world * 1000 * 3 / float(world)) for r in range(world))
+    assert not os.path.exists(rdzv)  # rank 0 removes the rendezvous file
+
+
+def test_host_group_peer_gone_raises_instead_of_hanging(tmp_path):
+    """A rank that never shows up: the others get a TimeoutError after the deadline."""
+    from chronoclust_amd import rendezvous
+    with pytest.raises(TimeoutError):
+        rendezvous.HostGroup(0, 2, rdzv_file=str(tmp_path / "r"), timeout=0.5)
+    with pytest.raises(TimeoutError):
+        rendezvous.HostGroup(1, 2, rdzv_file=str(tmp_path / "nobody"), timeout=0.5)
+
+
+def test_bench_imports_no_torch():
+    """north_star: no PyTorch on the path - bench.py and the package import neither torch nor the oracle at import time."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import sys; sys.path.insert(0, %r); import bench, chronoclust_amd, chronoclust_amd.multi, " \
+           "chronoclust_amd.rendezvous, chronoclust_amd.app; " \
+           "assert 'torch' not in sys.modules and 'oracle' not in sys.modules and 'oracle.oracle' not in sys.modules" % root
+    subprocess.run([sys.executable, "-c", code], check=True, timeout=120)
+
+
 def test_bench_command_line_parses_without_a_gpu():
     """`python bench.py --help` (argument surface of the driver contract: --gpus / --steps / --warmup) needs neither a
     GPU nor torch."""
@@ -126,7 +195,8 @@ def test_bench_command_line_parses_without_a_gpu():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=60)
     assert out.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup", "--no-one-stream", "--no-relaxed", "--relaxed-minibatch"):
+    for flag in ("--gpus", "--steps", "--warmup", "--no-one-stream", "--no-relaxed", "--relaxed-minibatch",
+                 "--no-c2-legs", "--only-leg"):
         assert flag in out.stdout
 
 
