@@ -96,3 +96,38 @@ def make_blobs(seed, n, d, g, sigma=0.01):
     centres = rng.uniform(0.1, 0.9, (g, d))
     lab = rng.integers(0, g, n)
     return np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, sigma, (n, d)), 0.0, 1.0))
+
+
+def blob_chunk(seed, c, rows, d, centres, sigma=0.01):
+    """Rows [c * CHUNK, c * CHUNK + rows) of make_blobs_chunked(seed, ...): a chunk depends on (seed, c) only."""
+    rng = np.random.default_rng([int(seed), int(c)])
+    lab = rng.integers(0, centres.shape[0], rows)
+    out = rng.normal(0.0, sigma, (rows, d))
+    out += centres[lab]
+    np.clip(out, 0.0, 1.0, out=out)
+    return out
+
+
+BLOB_CHUNK = 1 << 20
+
+
+def blob_centres(seed, d, g):
+    return np.random.default_rng(int(seed)).uniform(0.1, 0.9, (g, d))
+
+
+def make_blobs_chunked(seed, n, d, g, sigma=0.01, threads=8):
+    """The BASELINE generator for timepoints too large for one Generator call (C5: 50 M x 40 = 16 GB): the same
+    distribution as make_blobs, generated in chunks of 2^20 rows - each from its own seeded stream, so any chunk can
+    be regenerated alone - by a few threads (numpy's generators release the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    centres = blob_centres(seed, d, g)
+    X = np.empty((n, d), dtype=np.float64)
+
+    def fill(c):
+        a = c * BLOB_CHUNK
+        rows = min(BLOB_CHUNK, n - a)
+        X[a:a + rows] = blob_chunk(seed, c, rows, d, centres, sigma)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(fill, range((n + BLOB_CHUNK - 1) // BLOB_CHUNK)))
+    return X
