@@ -123,6 +123,16 @@ struct cc_handle {
     // lookahead scan a small workgroup finds room on a single SIMD (measured: 4 % per window in steady state)
     int chain_threads = 64, decide_threads = 256, commit_threads = 256;
     bool allow_scan_u = true;  // k_scan_u where it applies (CHRONOCLUST_HIP_SCANU=0: always k_scan)
+    // the pruned snapshot scan (k_seed / k_seed_merge / k_scan_p) where k_scan_u applies and d > 8:
+    // CHRONOCLUST_HIP_PRUNE = 0 never, 1 (default) while it pays (the device counts the rows it still evaluates in
+    // full), 2 always; CHRONOCLUST_HIP_PRUNE_F = threshold factor (default 16)
+    int prune_mode = 1;
+    double prune_F = 16.0;
+    bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
+    int prune_rounds4 = 8;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS)
+    DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range (two window parities)
+    DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
+    size_t spart_stride = 0, thr_stride = 0;
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
@@ -349,6 +359,10 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_tgt.ensure(w);
     h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2); h->v_unsafe.ensure(w);
     h->part_stride = w * seg * 4;
+    h->spart_stride = w * seg * 4 * 2;  // (entries per wave: seg workgroups x 4 waves)
+    h->thr_stride = w * 2;
+    h->spart.ensure(2 * h->spart_stride);
+    h->thr.ensure(2 * h->thr_stride);
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
@@ -421,6 +435,24 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
         static_assert(ScanShape<DP, false>::PT == 1, "k_scan_u holds one window point per lane");
         if (scan_u_applies(h, DP)) {
             ++h->stats.scan_u_launches;
+            if constexpr (DP > 8) {
+                if (h->prune_now && shard_world == 1) {
+                    // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them
+                    ++h->stats.scan_p_launches;
+                    if (h->hc.m_rows > 8192)  // (a large table is dense in six dimensions: seeds from eight)
+                        hipLaunchKernelGGL((k_seed<DP, 8, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
+                                           h->spart.p, round, mode, h->spart_stride);
+                    else
+                        hipLaunchKernelGGL((k_seed<DP, 6, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
+                                           h->spart.p, round, mode, h->spart_stride);
+                    hipLaunchKernelGGL(k_seed_merge, dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
+                                       rows.scl, h->spart.p, h->spart_stride, S * NW, h->thr.p, h->thr_stride, h->prune_F,
+                                       round, mode);
+                    hipLaunchKernelGGL((k_scan_p<DP, 8, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                       rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride);
+                    return;
+                }
+            }
             hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
             return;
@@ -616,6 +648,12 @@ int cc_create(int device, cc_handle** out)
         if (se) h->light_sync_events = atoi(se) != 0;
         const char* su = getenv("CHRONOCLUST_HIP_SCANU");
         if (su) h->allow_scan_u = atoi(su) != 0;
+        const char* pr = getenv("CHRONOCLUST_HIP_PRUNE");
+        if (pr && atoi(pr) >= 0 && atoi(pr) <= 2) h->prune_mode = atoi(pr);
+        const char* pw = getenv("CHRONOCLUST_HIP_PRUNE_WGS");
+        if (pw && atoi(pw) >= 1 && atoi(pw) <= 64) h->prune_rounds4 = atoi(pw);
+        const char* pf = getenv("CHRONOCLUST_HIP_PRUNE_F");
+        if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
         push_ctl(h);
@@ -1171,6 +1209,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_table_rows = 0;
         c.stat_seq_points = 0;
         c.stat_seq_clk = c.stat_seq_wall = 0;
+        c.stat_prune_rows = c.stat_prune_full = 0;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         const bool la_forced = h->tun.lookahead == 3;                    // from the first window on, whatever happens (tests)
         const bool la_enabled = h->tun.lookahead != 2;                   // 0 (default) and 1: while windows commit in full
@@ -1247,6 +1286,14 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         bool first_batch = true;
         int batch_windows = (c.win_cfg < 1024) ? 2 : std::max(2, h->tun.windows_per_sync / 4);
         const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
+        // the pruned snapshot scan (k_scan_p): on while the rows it still evaluates in full stay a minority; after a batch
+        // in which they were not, the plain scan runs for a few batches before the next try
+        const bool prune_applicable = h->prune_mode != 0 && h->d > 8 && h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 != 0 &&
+                                      (h->d == 14 || h->d == 16 || h->d == 20 || h->d == 32 || h->d == 40 || h->d == 64);
+        int prune_hold = 0;  // batches left before pruning is tried again
+        int stalled_batches = 0;
+        h->prune_now = prune_applicable && !shard_on;
+        unsigned long long prune_rows_prev = 0, prune_full_prev = 0;
         long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
         long long trunc_prev = 0, tiles_prev = 0, dtiles_prev = 0;
         int rounds_batch = R;  // validation rounds that were enqueued per window in the batch just finished
@@ -1297,6 +1344,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 continue;
             }
             const double batch_t0 = now_ms();
+            // pruned snapshot scans for this batch?  (a function of device counters only: every rank decides alike)
+            // (h->prune_now was set for this batch at the end of the previous one, together with the lookahead restart a
+            // change of it needs: a pruned scan leaves fewer partials per point than a plain one)
             const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
                              nullptr, nullptr, nullptr, nullptr, 0};
             const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
@@ -1308,7 +1358,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             const int gw = std::max(64, std::min(win, h->hc.win_cfg));
             // partials per point of this batch's clean scans (a pending lookahead scan was launched with the same value:
             // it only depends on the window size, and a change of that restarts the lookahead chain)
-            const int S = scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h));
+            // A pruned scan spends a few VALU instructions per row, so a wave must own many rows for its fixed costs
+            // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
+            // the machine once (about a fifth of the plain scan's partials at the full window).
+            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (h->n_cus * h->prune_rounds4) / std::max(1, (gw + 63) / 64)))
+                                       : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h));
             const int decide_threads = h->decide_threads;
             const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
             const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
@@ -1431,8 +1485,29 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             pull_ctl(h);
             if (la_on) sync_stream(h, sB);
             seq_host = h->hc.window_seq;
+            const long long done_before = done;
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
+            {
+                const unsigned long long pr = h->hc.stat_prune_rows - prune_rows_prev, pfu = h->hc.stat_prune_full - prune_full_prev;
+                prune_rows_prev = h->hc.stat_prune_rows;
+                prune_full_prev = h->hc.stat_prune_full;
+                if (h->prune_now) {
+                    // more than half of the (wave, row) pairs evaluated in full: the prefix scan and the tests cost more
+                    // than they save (start-up: the points' own microclusters do not exist yet; overlapping data)
+                    if (pr > 0 && pfu * 2 > pr) prune_hold = 4;
+                    // a window that commits nothing although its first point is always decidable: cannot happen with
+                    // exact first candidates - should it, the plain scan takes over for good
+                    if (done == done_before && !nodirty) prune_hold = 1 << 30;
+                } else if (prune_hold > 0) --prune_hold;
+                // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused
+                // for want of the dirty scans idle the rest of their batch), not three times in a row
+                stalled_batches = (done == done_before) ? stalled_batches + 1 : 0;
+                if (stalled_batches >= 3)
+                    return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
+                if (h->trace && pr > 0)
+                    fprintf(stderr, "[cc] pruned scans of the batch: %llu (wave, row) pairs, %.1f %% evaluated in full\n", pr, 100.0 * (double)pfu / (double)pr);
+            }
             pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_on ? (double)world : 1.0);
             pair_rows_prev = h->hc.stat_pair_rows;
             {
@@ -1518,7 +1593,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 if (shard_on) sharded_windows += wins;
                 const bool shard_flip = shard_next != shard_on;
                 shard_on = shard_next;
-                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0 || shard_flip) && done < N) {
+                // pruned snapshot scans in the next batch?  (a function of device counters only: every rank decides alike)
+                const bool prune_next = prune_applicable && !shard_on && ((h->prune_mode == 2 && prune_hold < (1 << 29)) || prune_hold == 0);
+                const bool prune_flip = prune_next != h->prune_now;
+                h->prune_now = prune_next;
+                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0 || shard_flip || prune_flip) && done < N) {
                     h->hc.win_cfg = want;
                     h->hc.win_b = (int)std::min<long long>(want, N - done);
                     set_lookahead(want_la);
@@ -1577,6 +1656,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->seq_sticky = seq_on;
         h->stats.table_rows_scanned += h->hc.stat_table_rows;
         h->stats.lookahead_windows += h->hc.stat_lookahead;
+        h->stats.pruned_scan_rows += (int64_t)h->hc.stat_prune_rows;
+        h->stats.pruned_scan_full_rows += (int64_t)h->hc.stat_prune_full;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {

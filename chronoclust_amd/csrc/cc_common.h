@@ -14,6 +14,11 @@
 
 // One candidate of a per-point argmin: (distance, list-order key) ordered lexicographically
 // (strict `<` + "first in list order wins", hddstream.py:326/373), plus the row it refers to.
+// slot -1: no candidate.  slot CC_SLOT_BOUND: not a row but a BOUND left by the pruned snapshot scan (k_scan_p): every
+// row of the kind that is not listed before it has a distance >= dist.  Its key is -1, so that on an exact tie of
+// distances the bound comes first: a bound in second place says "the second-best row is unknown, but not closer than
+// this", and the decision procedure treats it like a second-best candidate that is dirty (k_decide, state 2).
+#define CC_SLOT_BOUND (-2)
 struct __attribute__((aligned(16))) Cand {
     double dist;
     int key;
@@ -175,6 +180,9 @@ struct Ctl {
     long long stat_tiles, stat_dirty_tiles;  // 64-point tiles validated / of those, tiles whose dirty scan had to run
     long long stat_seq_points;               // points taken by the sequential kernel (k_seq)
     long long stat_seq_clk, stat_seq_wall;   // ... its shader-clock cycles / constant 100 MHz ticks (trace)
+    // pruned snapshot scans (k_scan_p): (wave, row) pairs visited / of those, pairs whose distance was evaluated in full
+    // (a sample: the waves of every window's first point tile)
+    unsigned long long stat_prune_rows, stat_prune_full;
 };
 
 // Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole

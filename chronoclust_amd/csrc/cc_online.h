@@ -131,12 +131,14 @@ __device__ inline double cc_tentative_radius(const double* bcf1, const double* b
     return r2;
 }
 
-// insert x into the ordered pair (a, b); field-wise selects keep the structs in registers
+// insert x into the ordered pair (a, b); field-wise selects keep the structs in registers.  Bounds (CC_SLOT_BOUND,
+// key -1) take part like candidates: the pair then reads "best, then either the exact second-best or a lower bound for
+// everything else", whatever the order in which partial pairs are merged.
 __device__ __forceinline__ void cc_top2_push(Cand& a, Cand& b, const Cand& x)
 {
-    const bool ok = x.slot >= 0;
-    const bool beats_a = ok && (a.slot < 0 || cand_less(x.dist, x.key, a.dist, a.key));
-    const bool beats_b = ok && !beats_a && (b.slot < 0 || cand_less(x.dist, x.key, b.dist, b.key));
+    const bool ok = x.slot != -1;
+    const bool beats_a = ok && (a.slot == -1 || cand_less(x.dist, x.key, a.dist, a.key));
+    const bool beats_b = ok && !beats_a && (b.slot == -1 || cand_less(x.dist, x.key, b.dist, b.key));
     b.dist = beats_a ? a.dist : (beats_b ? x.dist : b.dist);
     b.key = beats_a ? a.key : (beats_b ? x.key : b.key);
     b.slot = beats_a ? a.slot : (beats_b ? x.slot : b.slot);
@@ -1019,6 +1021,467 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
 }
 
 // ---------------------------------------------------------------------------------
+// The PRUNED snapshot scan: k_seed -> k_seed_merge -> k_scan_p.  Same contract as k_scan_u (per point and kind the
+// best candidates by (projected distance, list order)), for a fraction of its arithmetic.
+//
+// A distance is a sum of non-negative terms taken left to right (mc_functions.py:37-41), so its partial sums never
+// decrease: a row whose partial sum already exceeds a threshold T cannot have a distance <= T.  With T well above the
+// distance of the point's nearest microcluster, almost every row drops out after four or eight dimensions - for all 64
+// points of a wave at once, because the other microclusters are far from every one of them (the test is wave-uniform:
+// a row is abandoned when ALL lanes are over their thresholds; otherwise its distance is completed for all lanes).
+//   k_seed        per point and kind the row with the smallest UNSCALED squared distance over the first PRE
+//                 dimensions (a heuristic: nothing downstream relies on it being the nearest), per wave sub-range.
+//                 It has to be the point's nearest microcluster almost always, though: one lane with a far seed keeps
+//                 its whole wave evaluating every row in full - hence six or eight dimensions, not four (in four, 1 %
+//                 of the C2 points have another of the 5 000 microclusters closer than their own)
+//   k_seed_merge  per point and kind: the three best of those, their exact distances, T = F x the smallest
+//   k_scan_p      k_scan_u's row loop with the abandon test after dimensions 4, 8, 16, 24, ...; per kind it keeps the
+//                 two best EVALUATED rows and the smallest partial sum at which a row was abandoned (> T).  What leaves
+//                 the kernel per kind is a pair (best, second) in which `second` may be a BOUND (CC_SLOT_BOUND): the
+//                 best is exact whenever it is <= T (the seed row always is evaluated), the second is exact when it is
+//                 smaller than every abandoned partial sum, else all that is known of the other rows is that none is
+//                 closer than the bound.  Pairs merge like candidate pairs (cc_top2_push), in any order.
+// k_decide treats a bound in second place like a second-best candidate that is dirty: the decision is exact iff a live
+// version beats the bound, otherwise the point is undecidable in this window (CC_T_UNKNOWN) - with F = 16 that takes a
+// microcluster whose live version is four times as far (in distance units) as the seed was.
+// ---------------------------------------------------------------------------------
+
+struct __attribute__((aligned(16))) SeedCand {
+    double part;  // unscaled squared distance over the first PRE dimensions
+    int row;      // -1: none
+    int pad;
+};
+
+// the window a snapshot scan works on: mode 0 = the current window (in place), 1 = the lookahead window of parity round & 1
+struct ScanWin {
+    int B, rows, q;
+    long long cursor;
+};
+__device__ __forceinline__ ScanWin cc_scan_window(const Ctl* __restrict__ ctl, int round, int mode)
+{
+    ScanWin w;
+    if (mode == 1) {
+        w.q = round & 1;
+        w.B = ctl->la_b[w.q];
+        w.rows = ctl->la_rows[w.q];
+        w.cursor = ctl->la_cursor[w.q];
+    } else {
+        w.B = (ctl->mode != 0) ? 0 : ctl->win_b;  // (mode != 0: this window's snapshot scan ran ahead)
+        w.rows = ctl->m_rows;
+        w.cursor = ctl->cursor;
+        w.q = (int)(ctl->window_seq & 1ull);
+    }
+    return w;
+}
+
+template <int DP, int PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                  const double* __restrict__ g_cen, const int* __restrict__ g_kind,
+                                                  SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride)
+{
+    static_assert(PRE <= DP && PRE % 2 == 0, "prefix dimensions");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 64;
+    if (j0 >= B) return;
+    spart += (size_t)win.q * spart_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    const int per = (win.rows + nsub - 1) / nsub;
+    const int r0 = sub * per;
+    const int r1 = min(win.rows, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const int jj = j0 + lane;
+    const bool valid = jj < B;
+    double p[PRE];
+    {
+        const double* xp = Xt + win.cursor + (valid ? jj : 0);
+#pragma unroll
+        for (int i = 0; i < PRE; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    // per wave: the prefixes of a tile of 16 rows in LDS (the wave is the only reader and writer of its tile), read
+    // back as wave-uniform broadcasts; the next tile's values are requested before the row loop of the current one
+    constexpr int NLP = (CC_SCAN_TM * PRE + 63) / 64;
+    __shared__ __attribute__((aligned(16))) double s_pre[NW * NLP * 64];
+    double* const tile = s_pre + (size_t)wv * NLP * 64;
+    typedef double cc_d2 __attribute__((ext_vector_type(2)));
+    auto load_tile = [&](int rt, double (&tc)[NLP], int& kd) {
+        const int tm = min(CC_SCAN_TM, r1 - rt);
+#pragma unroll
+        for (int q = 0; q < NLP; ++q) {
+            const int e = lane + q * 64, m = e / PRE, i = e - m * PRE;
+            tc[q] = (m < tm) ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;  // (m < 16 follows: tm <= 16)
+        }
+        kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+    };
+    double best[2] = {CC_INF, CC_INF};
+    int idx[2] = {-1, -1};
+    double tc[NLP];
+    int kdl = CC_KIND_DEAD;
+    if (r0 < r1) load_tile(r0, tc, kdl);
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < NLP; ++q) tile[lane + q * 64] = tc[q];
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) load_tile(rt + CC_SCAN_TM, tc, kdl);
+        const cc_d2* t2 = reinterpret_cast<const cc_d2*>(__builtin_assume_aligned(tile, 16));
+        for (int m = 0; m < tm; ++m) {
+            const int rowg = rt + m;
+            double acc = 0.0;
+#pragma unroll
+            for (int h2 = 0; h2 < PRE / 2; ++h2) {
+                const cc_d2 c = t2[m * (PRE / 2) + h2];
+                const double x = p[2 * h2] - c.x, y = p[2 * h2 + 1] - c.y;
+                acc = (h2 == 0) ? x * x : __builtin_fma(x, x, acc);  // (a heuristic score: contraction is welcome)
+                acc = __builtin_fma(y, y, acc);
+            }
+            auto update = [&](auto KC) {
+                constexpr int K = decltype(KC)::value;
+                const bool lt = acc < best[K];  // strict: the first row in scan order keeps a tie (deterministic)
+                best[K] = lt ? acc : best[K];
+                idx[K] = lt ? rowg : idx[K];
+            };
+            if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+            else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+        }
+    }
+    // every wave leaves its own winners: S x NW entries per point and kind for k_seed_merge to choose from
+    if (!valid) return;
+    SeedCand* o = spart + ((size_t)jj * nsub + sub) * 2;
+    o[0] = SeedCand{best[0], idx[0], 0};
+    o[1] = SeedCand{best[1], idx[1], 0};
+}
+
+// per point and kind (one thread each): the three best prefix scores of the S sub-ranges -> their exact distances (the
+// scans' own operations, in their order; the three sums advance together) -> T = F x the smallest; +inf when the kind
+// has no row.
+__global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, const double* __restrict__ X,
+                                                   const double* __restrict__ g_cen, const double* __restrict__ g_scl,
+                                                   const SeedCand* __restrict__ spart, size_t spart_stride, int S,
+                                                   double* __restrict__ thr, size_t thr_stride, double F, int round,
+                                                   int mode)
+{
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t >> 1, K = t & 1;
+    if (j >= win.B) return;
+    const int d = ctl->d;
+    spart += (size_t)win.q * spart_stride;
+    thr += (size_t)win.q * thr_stride;
+    const double* p = X + (size_t)(win.cursor + j) * d;
+    double b0 = CC_INF, b1 = CC_INF, b2 = CC_INF;
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int s = 0; s < S; ++s) {
+        const SeedCand c = spart[((size_t)j * S + s) * 2 + K];
+        if (c.row < 0) continue;
+        if (i0 < 0 || c.part < b0) { b2 = b1; i2 = i1; b1 = b0; i1 = i0; b0 = c.part; i0 = c.row; }
+        else if (i1 < 0 || c.part < b1) { b2 = b1; i2 = i1; b1 = c.part; i1 = c.row; }
+        else if (i2 < 0 || c.part < b2) { b2 = c.part; i2 = c.row; }
+    }
+    double out = CC_INF;
+    if (i0 >= 0) {
+        const bool h1 = i1 >= 0, h2 = i2 >= 0;
+        const size_t o0 = (size_t)i0 * d, o1 = (size_t)(h1 ? i1 : i0) * d, o2 = (size_t)(h2 ? i2 : i0) * d;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int i = 0; i < d; ++i) {
+            const double pi = p[i];
+            double x0 = pi - g_cen[o0 + i], x1 = pi - g_cen[o1 + i], x2 = pi - g_cen[o2 + i];
+            x0 = x0 * x0; x1 = x1 * x1; x2 = x2 * x2;
+            x0 = x0 * g_scl[o0 + i]; x1 = x1 * g_scl[o1 + i]; x2 = x2 * g_scl[o2 + i];
+            a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2;
+        }
+        double dmin = a0;
+        dmin = a1 < dmin ? a1 : dmin;
+        dmin = a2 < dmin ? a2 : dmin;
+        out = F * dmin;
+    }
+    thr[(size_t)j * 2 + K] = out;
+}
+
+// Per wave and tile of 16 rows two phases:
+//   A  every row, straight-line: the partial sum over the first PA dimensions (mc_functions.py:37-41, the scans' own
+//      operations in their order), the wave-uniform test "some lane within its threshold", one bit per row; a row that
+//      no lane keeps only leaves its partial sum in the kind's bound.  Only the first PA dimensions of the tile's rows
+//      are fetched (centroid and distance operand: 2 x 16 x PA doubles, coalesced, staged in the wave's LDS tile and read
+//      back as wave-uniform broadcasts; the next tile's loads are in flight during the row loop of the current one) -
+//      the whole rows, as k_scan stages them, would be five times the bytes at d = 20 for 3 % of the rows, and the same
+//      lines are wanted by every point tile's workgroup at the same moment.  When every row of the tile is preferred
+//      in all of these dimensions (the usual case) the operand is the constant 1/k and the phase needs no scalar selects.
+//   B  the rows phase A kept (few): the whole distance from its first dimension with the reference's four operations
+//      per term (sub, square, scale, add - no fusion, so no CC_TINY condition to check), centroid and operand as scalar
+//      loads of eight dimensions at a time, the same test every eight dimensions beyond PA, then the best-two update of
+//      k_scan_u.
+template <int DP, int PA, int NW>
+__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void k_scan_p(
+    Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
+    const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr, size_t thr_stride,
+    Cand* __restrict__ part, int round, int mode, size_t part_stride)
+{
+    static_assert(DP % 2 == 0 && DP > 8 && DP <= 64 && PA == 8 && PA < DP, "k_scan_p shapes");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 64;
+    if (j0 >= B) return;
+    part += (size_t)win.q * part_stride;
+    thr += (size_t)win.q * thr_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    const int per = (win.rows + nsub - 1) / nsub;
+    const int r0 = sub * per;
+    const int r1 = min(win.rows, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const double k = ctl->k;
+    const double inv_k = ctl->inv_k;
+    const int jj = j0 + lane;
+    const bool valid = jj < B;
+
+    constexpr int TILE_BYTES = NW * CC_SCAN_TM * PA * 8;
+    constexpr int MERGE_BYTES = (NW - 1) * 4 * 64 * (int)sizeof(Cand);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
+    double* const tile = reinterpret_cast<double*>(smem) + (size_t)wv * CC_SCAN_TM * PA;
+    typedef double cc_d2 __attribute__((ext_vector_type(2)));
+
+    double p[DP];
+    {
+        const double* xp = Xt + win.cursor + (valid ? jj : 0);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    bool fuse_wave = k >= 0x1p-64 && k <= 0x1p64;
+    {
+        bool tn = false;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) tn = tn || cc_is_tiny(p[i]);  // (phase A is the only fused arithmetic here)
+        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+    }
+    // thresholds and the smallest abandoned partial sum, per kind; lanes without a point keep no row alive
+    double th[2], lb[2] = {CC_INF, CC_INF};
+    th[0] = valid ? thr[(size_t)jj * 2 + 0] : -CC_INF;
+    th[1] = valid ? thr[(size_t)jj * 2 + 1] : -CC_INF;
+    double bd[2][2];
+    int bs[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bd[kd][r] = valid ? CC_INF : -CC_INF;
+            bs[kd][r] = -1;
+        }
+    int n_rows = 0, n_full = 0;  // statistics (wave-uniform)
+
+    constexpr int NLP = CC_SCAN_TM * PA / 64;  // 2: lane + 64 q = 8 m + i
+    double tc[NLP], ts[NLP];
+    int kdl = CC_KIND_DEAD;
+    auto load_tile = [&](int rt) {
+        const int tm = min(CC_SCAN_TM, r1 - rt);
+#pragma unroll
+        for (int q = 0; q < NLP; ++q) {
+            const int e = lane + q * 64, m = e / PA, i = e - m * PA;
+            const bool in = m < tm;
+            tc[q] = in ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;
+            ts[q] = in ? g_scl[(size_t)(rt + m) * DP + i] : 1.0;
+        }
+        kdl = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+    };
+    if (r0 < r1) load_tile(r0);
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+        unsigned long long wmask[NLP];  // bit 8 m' + i of word q: row 8 q + m' is scaled by 1/k in dimension i
+        bool tn = false, any_one = false;
+#pragma unroll
+        for (int q = 0; q < NLP; ++q) {
+            const int e = lane + q * 64;
+            tile[e] = tc[q];
+            tn = tn || cc_is_tiny(tc[q]);
+            wmask[q] = __builtin_amdgcn_ballot_w64(ts[q] != 1.0);
+            any_one = any_one || (e / PA < tm && ts[q] == 1.0);
+        }
+        const bool fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+        const bool uni = __builtin_amdgcn_ballot_w64(any_one) == 0ull;  // all rows preferred in all of the first PA dimensions
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) load_tile(rt + CC_SCAN_TM);  // in flight during the row loops below
+        n_rows += tm;
+        const cc_d2* t2 = reinterpret_cast<const cc_d2*>(__builtin_assume_aligned(tile, 16));
+        const unsigned full = (1u << tm) - 1u;
+        const double one = 1.0;
+
+        // ---- phase A ----
+        unsigned surv = 0u;
+        auto phase_a = [&](auto UNIC, auto FUSEC, auto KSELC) {
+            constexpr bool UNI = decltype(UNIC)::value;
+            constexpr bool FUSE = decltype(FUSEC)::value;
+            constexpr int KSEL = decltype(KSELC)::value;
+            for (int m = 0; m < tm; ++m) {
+                const cc_d2* r2 = t2 + m * (PA / 2);
+                unsigned mlo = 0u;
+                if constexpr (!UNI) mlo = (unsigned)((m < 8 ? wmask[0] : wmask[NLP - 1]) >> ((m & 7) * 8)) & 0xFFu;
+                double acc = 0.0;
+#ifdef CC_DBG_NO_PHASE_A_MATH
+                acc = 1e30 + (double)m;
+                if (false)
+#endif
+                cc_static_for<PA / 2>([&](auto QC) {
+                    constexpr int i = 2 * decltype(QC)::value;
+                    const cc_d2 c = r2[i / 2];
+                    double s0 = inv_k, s1 = inv_k;
+                    if constexpr (!UNI) cc_sel_scale2<i>(mlo, inv_k, one, s0, s1);
+                    double x = p[i] - c.x;
+                    double y = p[i + 1] - c.y;
+                    x = x * x;
+                    y = y * y;
+                    if (FUSE) {
+                        acc = (i == 0) ? x * s0 : __builtin_fma(x, s0, acc);  // :39 + :41 in one rounding, see CC_TINY
+                        acc = __builtin_fma(y, s1, acc);
+                    } else {
+                        x = x * s0;
+                        y = y * s1;
+                        acc = (i == 0) ? x : acc + x;
+                        acc = acc + y;
+                    }
+                });
+                const bool is_p = KSEL == 0 || (KSEL < 0 && ((pmask >> m) & 1u) != 0u);
+                if (is_p) {
+                    if (__builtin_amdgcn_ballot_w64(acc <= th[0]) != 0ull) surv |= 1u << m;
+                    else lb[0] = cc_vmin(lb[0], acc);
+                } else {
+                    if (__builtin_amdgcn_ballot_w64(acc <= th[1]) != 0ull) surv |= 1u << m;
+                    else lb[1] = cc_vmin(lb[1], acc);
+                }
+            }
+        };
+        auto phase_a_k = [&](auto UNIC, auto FUSEC) {
+            if (pmask == full) phase_a(UNIC, FUSEC, std::integral_constant<int, 0>{});
+            else if (omask == full) phase_a(UNIC, FUSEC, std::integral_constant<int, 1>{});
+            else phase_a(UNIC, FUSEC, std::integral_constant<int, -1>{});
+        };
+        if (fuse_tile) {
+            if (uni) phase_a_k(std::true_type{}, std::true_type{});
+            else phase_a_k(std::false_type{}, std::true_type{});
+        } else phase_a(std::false_type{}, std::false_type{}, std::integral_constant<int, -1>{});
+
+        // ---- phase B: the rows that stayed ----
+#ifdef CC_DBG_NO_PHASE_B
+        surv = 0u;
+#endif
+        while (surv != 0u) {
+            const int m = __builtin_ctz(surv);
+            surv &= surv - 1u;
+            const int rowg = rt + m;
+            const bool is_p = ((pmask >> m) & 1u) != 0u;
+            const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
+            const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
+            double acc = 0.0;
+            bool gone = false;
+            cc_static_for<(DP + 7) / 8>([&](auto CC) {
+                constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
+                if (gone) return;
+                double c[hi - lo], sc[hi - lo];
+#pragma unroll
+                for (int i = 0; i < hi - lo; ++i) {
+                    c[i] = rc[lo + i];
+                    sc[i] = rs[lo + i];
+                }
+#pragma unroll
+                for (int i = 0; i < hi - lo; ++i) {
+                    double x = p[lo + i] - c[i];          // mc_functions.py:37
+                    x = x * x;                             // :38
+                    x = x * sc[i];                         // :39 (the divisor is a power of two)
+                    acc = (lo + i == 0) ? x : acc + x;     // :41
+                }
+                if constexpr (hi < DP && hi > PA) {
+                    if (is_p) {
+                        if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
+                    } else {
+                        if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
+                    }
+                }
+            });
+            if (gone) continue;
+            ++n_full;
+            auto update = [&](auto KC) {
+                constexpr int K = decltype(KC)::value;
+                const double a = acc;
+                double& d0 = bd[K][0];
+                double& d1 = bd[K][1];
+                int& s0 = bs[K][0];
+                int& s1 = bs[K][1];
+                bool ins = a < d1;
+                bool first = a < d0;
+                // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+                const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                if ((e1 | e0) != 0ull) {
+                    if (a == d1 || a == d0) {
+                        const int key = g_key[rowg];
+                        if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                        if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                    }
+                }
+                d1 = cc_vmin(d1, cc_vmax(d0, a));
+                d0 = cc_vmin(d0, a);
+                s1 = first ? s0 : (ins ? rowg : s1);
+                s0 = first ? rowg : s0;
+            };
+            if (is_p) update(std::integral_constant<int, 0>{});
+            else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+        }
+    }
+    // statistics for the host's policy: a sample - the waves of the window's first point tile (atomics of every wave on
+    // one address serialise: 30 000 of them cost more than the scan)
+    if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
+        atomicAdd(&ctl->stat_prune_rows, (unsigned long long)n_rows);
+        atomicAdd(&ctl->stat_prune_full, (unsigned long long)n_full);
+    }
+
+    // the survivors' list-order keys; every kind's pair then takes in the bound of what the wave abandoned; the waves'
+    // pairs are merged through LDS as in k_scan_u
+    int bk[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bk[kd][r] = bs[kd][r] >= 0 ? g_key[bs[kd][r]] : CC_IDX_INF;
+    Cand c0{bd[0][0], bk[0][0], bs[0][0]}, c1{bd[0][1], bk[0][1], bs[0][1]};
+    Cand c2{bd[1][0], bk[1][0], bs[1][0]}, c3{bd[1][1], bk[1][1], bs[1][1]};
+    cc_top2_push(c0, c1, Cand{lb[0], -1, lb[0] < CC_INF ? CC_SLOT_BOUND : -1});
+    cc_top2_push(c2, c3, Cand{lb[1], -1, lb[1] < CC_INF ? CC_SLOT_BOUND : -1});
+    Cand* s_m = reinterpret_cast<Cand*>(smem);
+    auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 4 + c) * 64 + lane]; };
+    __syncthreads();  // every wave is done with its tile: the same bytes now carry the candidate exchange
+    if (wv > 0) {
+        s_m_at(wv - 1, 0) = c0;
+        s_m_at(wv - 1, 1) = c1;
+        s_m_at(wv - 1, 2) = c2;
+        s_m_at(wv - 1, 3) = c3;
+    }
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        cc_top2_push(c0, c1, s_m_at(w, 0));
+        cc_top2_push(c0, c1, s_m_at(w, 1));
+        cc_top2_push(c2, c3, s_m_at(w, 2));
+        cc_top2_push(c2, c3, s_m_at(w, 3));
+    }
+    Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
 // k_merge_partials (exact multi-GPU path): the S partials a rank's snapshot scan left per window point -> ONE record
 // of four candidates per point, the unit the ranks all-gather (64 B per point instead of S x 64 B).  Candidates are
 // totally ordered by (distance, list-order key), so the best two of a union do not depend on the merge order and
@@ -1248,8 +1711,11 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     bool look[4];
 #pragma unroll
     for (int kd = 0; kd < 2; ++kd) {
-        if (cq[kd * 2 + 1].slot >= 0) d2v[kd] = cq[kd * 2 + 1].dist;
+        // (a bound in second place - pruned snapshot scan - serves as d2 like an exact second-best distance: what is
+        // needed of d2 below is that no MC outside the list was closer than it at window start)
+        if (cq[kd * 2 + 1].slot != -1) d2v[kd] = cq[kd * 2 + 1].dist;
         have1[kd] = cq[kd * 2].slot >= 0;  // no snapshot candidate of this kind: cap stays +inf
+        if (cq[kd * 2].slot == CC_SLOT_BOUND) provable = false;  // (never left in first place; k_decide refuses the point)
         look[kd * 2] = have1[kd];
         look[kd * 2 + 1] = have1[kd] && cq[kd * 2 + 1].slot >= 0;
     }
@@ -1592,9 +2058,11 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     auto run_stage = [&](const Cand& c1, const Cand& c2, const Cand& dd, int stage) {
         int state;  // 0: no clean candidate, 1: cb is the exact clean best, 2: cb only bounds the clean best from below
         Cand cb = none;
-        if (c1.slot < 0) state = 0;
+        if (c1.slot == -1) state = 0;
+        else if (c1.slot == CC_SLOT_BOUND) { T = CC_T_UNKNOWN; return; }  // (a pruned scan never leaves this)
         else if (!dirty(c1.slot)) { state = 1; cb = c1; }
-        else if (c2.slot < 0) state = 0;
+        else if (c2.slot == -1) state = 0;
+        else if (c2.slot == CC_SLOT_BOUND) { state = 2; cb = c2; }  // the clean rows are only known to be >= c2.dist
         else if (!dirty(c2.slot)) { state = 1; cb = c2; }
         else { state = 2; cb = c2; }
 

@@ -106,6 +106,11 @@ typedef struct cc_stats {
     int64_t seq_points;      /* points taken by the sequential kernel             */
     int64_t scan_u_launches; /* snapshot scans launched as k_scan_u (rows as scalar
                               * operands) rather than the LDS-staged k_scan          */
+    int64_t scan_p_launches; /* of those, pruned scans (k_seed + k_seed_merge + k_scan_p: rows
+                              * abandoned as soon as their partial sums pass a threshold) */
+    int64_t pruned_scan_rows;      /* (wave, row) pairs the pruned scans visited (sampled: the
+                                    * first point tile of every window) ...              */
+    int64_t pruned_scan_full_rows; /* ... and of those, pairs evaluated over all dimensions */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

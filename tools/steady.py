@@ -30,3 +30,6 @@ if __name__ == "__main__":
                   rep, s["run_ms"], n / s["run_ms"] / 1e3, s["windows"], s["rounds"], s["truncated"],
                   s["scan_launches"], 1e3 * s["scan_ms"] / max(1, s["scan_launches"]),
                   s["scan_pair_dims"] / max(1e-9, s["scan_ms"]) / 1e9), flush=True)
+        if s.get("scan_p_launches"):
+            print("   pruned scans: %d launches, %d (wave, row) pairs, %.2f %% evaluated in full" % (
+                s["scan_p_launches"], s["pruned_scan_rows"], 100.0 * s["pruned_scan_full_rows"] / max(1, s["pruned_scan_rows"])), flush=True)
