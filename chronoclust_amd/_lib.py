@@ -83,6 +83,9 @@ SYMBOLS = {
     "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
     "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
     "cc_sync": (C.c_int, [C.c_void_p]),
+    "cc_point_clusters": (C.c_int, [C.c_void_p, _i32p]),
+    "cc_format_points_csv": (C.c_int64, [_dp, C.c_int64, C.c_int32, C.c_int64, _i32p, C.c_char_p, _i32p, C.c_int32,
+                                         C.c_void_p, C.c_int64]),
     "cc_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "cc_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
@@ -142,6 +145,39 @@ def comm_init_local(handles):
     rc = load().cc_comm_init_local(arr, len(handles))
     if rc != 0:
         raise ChronoclustHipError("cc_comm_init_local failed: %s" % _ERRORS.get(rc, rc))
+
+
+def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=65536):
+    """The body of cluster_points_D{t}.csv (app.py:357-360, DataFrame.to_csv(index=False)) as bytes: one line per row of
+    `values` [n, d] - "<id>,<label>,<repr(float)>,..." -, ids counting from first_id, labels[label_idx[r]] as the label
+    (already CSV-quoted where needed; index -1 = the last label).  Formatted by cc_format_points_csv in chunks on a few
+    threads (ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    lib = load()
+    values = _f64(values)
+    n, d = values.shape
+    label_idx = np.ascontiguousarray(label_idx, dtype=np.int32)
+    enc = [s.encode() for s in labels]
+    offs = np.zeros(len(enc) + 1, np.int32)
+    offs[1:] = np.cumsum([len(e) for e in enc])
+    blob = b"".join(enc)
+    per_row = 25 + max(len(e) for e in enc) + 33 * d + 2
+
+    def work(a):
+        b = min(n, a + chunk)
+        buf = C.create_string_buffer(per_row * (b - a))
+        got = lib.cc_format_points_csv(values[a:b].ctypes.data_as(_dp), b - a, d, first_id + a,
+                                       label_idx[a:b].ctypes.data_as(_i32p), blob, offs.ctypes.data_as(_i32p), len(enc),
+                                       buf, len(buf))
+        if got < 0:
+            raise ChronoclustHipError("cc_format_points_csv failed: %s" % _ERRORS.get(got, got))
+        return buf.raw[:got]
+
+    starts = range(0, n, chunk)
+    if n == 0:
+        return b""
+    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
+        return b"".join(ex.map(work, starts))
 
 
 def shard_rows(n, world, rank, unit=1):
@@ -336,6 +372,13 @@ class Handle(object):
         clusters = [dict(members=mem[off[c]:off[c + 1]], w=float(w[c]), cf1=cf1[c], cf2=cf2[c], cen=cen[c],
                          pref=pref[c]) for c in range(len(w))]
         return clusters, info
+
+    def point_clusters(self):
+        """Cluster index (order of offline_arrays) of every resident point, -1 outside every cluster (cc_point_clusters)."""
+        out = np.empty(self._n, dtype=np.int32)
+        if self._n:
+            self._check(self._lib.cc_point_clusters(self._h, _ptr(out, _i32p)))
+        return out
 
     def num_core(self):
         return self._check(self._lib.cc_num_core(self._h))

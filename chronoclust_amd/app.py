@@ -18,6 +18,9 @@ from .clustering.hddstream import HDDStream
 from .scaling.scaler import Scaler, read_timepoint
 from .tracking.cluster_tracker import TrackByHistoricalAssociation, TrackByLineage
 
+# wall-clock seconds per phase and timepoint of the last run() of this process (tools/c3_app.py reports them)
+LAST_RUN_TIMINGS = []
+
 HDDSTREAM_OBJ = 'hddstream'
 TRACKER_HISTORICAL_ASSOC = 'tracking_by_historical_association'
 TRACKER_LINEAGE = 'tracking_by_lineage'
@@ -75,37 +78,57 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
         logger.info("Setting up scaler")
         scaler = Scaler(data, handle=hddstream._h)  # column min / max reduced on the device, files parsed once
 
+    import time
+    del LAST_RUN_TIMINGS[:]
     for timepoint, data_file in enumerate(data):
         if restoring and hddstream.last_data_timestamp >= timepoint:
             continue  # already processed before the checkpoint (app.py:165-166)
         logger.info("Processing dataset {}".format(timepoint))
+        tm = {"timepoint": timepoint}
+        t0 = time.perf_counter()
         raw = scaler.parsed.pop(data_file, None) if scaler is not None else None
         if raw is None:
             raw = read_timepoint(data_file)
+        tm["read"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         if normalise_data:
             # MinMaxScaler.transform runs on the device as part of the upload (cc_points_upload_scaled)
             logger.info("Scaling dataset {}".format(timepoint))
             hddstream.online_microcluster_maintenance(raw, timepoint, device_scaling=(scaler.scale_, scaler.min_))
         else:
             hddstream.online_microcluster_maintenance(raw, timepoint)
+        tm["clustering"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         # app.py:179-190: one Cluster record per final cluster (weight to one decimal place, half up, through the
         # float's shortest repr; member pcores attached), built from the exported arrays
         for cluster in hddstream.cluster_records():
             tracker_by_lineage.add_new_child_cluster(cluster)
+        tm["cluster_records"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
 
         tracker_by_lineage.calculate_ids()
+        tm["lineage"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         tracker_by_association.set_current_clusters(tracker_by_lineage.child_clusters)
         tracker_by_association.track_cluster_history()
+        tm["association"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
 
         write_result_file(gating, result_filename, timepoint, tracker_by_association, scaler=scaler)
+        tm["result_rows"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
         write_datapoints_details(dataset_attributes, tracker_by_lineage.child_clusters, hddstream,
                                  raw, f'{output_directory}/cluster_points_D{timepoint}.csv', scaler)
+        tm["point_details"] = time.perf_counter() - t0
+        t0 = time.perf_counter()
 
         tracker_by_lineage.transfer_child_to_parent()
         tracker_by_association.transfer_current_to_previous()
 
         logger.info("Saving Chronoclust state for timepoint {}".format(timepoint))
         save_program_state(hddstream, output_directory, tracker_by_association, tracker_by_lineage)
+        tm["program_image"] = time.perf_counter() - t0
+        LAST_RUN_TIMINGS.append(tm)
 
     with open(f'{output_directory}/parameters.csv', 'w') as f:
         w = csv.DictWriter(f, config.keys())
@@ -138,29 +161,34 @@ def write_result_file(gating, result_filename, timepoint, tracker_by_association
 def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, cluster_points_filename, scaler):
     """id, cluster_id, <features> for every point of the timepoint, in input order (app.py:263-360).
 
-    The reference walks per-microcluster `points` dicts; here the per-point microcluster labels are one int64
-    array (creation number of the MC holding each row), joined to the lineage ids by lookup."""
+    The reference walks per-microcluster `points` dicts and lets pandas format 10^6 x d floats one by one; here the
+    cluster of every point is a gather on the device (cc_point_clusters: per-point microcluster label -> creation
+    number -> cluster), the lineage ids are looked up by cluster index, and the text is produced by
+    cc_format_points_csv (repr(float) bytes, a few host threads).  Same bytes as DataFrame.to_csv(index=False)."""
+    import io
     write_file_header(cluster_points_filename, ['id', 'cluster_id'] + dataset_attributes)
     n = raw.shape[0]
-    pcore = hddstream.table(0)
-    uid_of_pcore = {int(i): int(u) for i, u in zip(pcore["id"], pcore["uid"])}
-    label_of_uid = {}
+    if n == 0:
+        return
+    from . import _lib
+    # CSV text of every cluster's lineage id (ids like "(A|1,C)" need quotes), by position among the final clusters;
+    # last entry: the literal None of points outside every cluster (app.py:396)
+    n_final = len(hddstream.final_clusters)
+    labels = ["None"] * (n_final + 1)
     for cluster in clusters:
-        for pcore_id in cluster.pcore_ids:
-            label_of_uid[uid_of_pcore[pcore_id]] = cluster.id
-    uids, inverse = np.unique(hddstream.labels_uid, return_inverse=True)
-    names = np.array([label_of_uid.get(int(u), "None") for u in uids], dtype=object)
-    cluster_ids = names[inverse] if n else np.empty(0, dtype=object)
-
+        buf = io.StringIO()
+        csv.writer(buf, lineterminator="").writerow([cluster.id])
+        labels[cluster.offline_index] = buf.getvalue()
+    idx = hddstream.point_cluster_index()  # -1 -> labels[-1]
     if scaler:
         # the reference writes inverse_transform(transform(raw)), not raw: (X - min_) / scale_ on the device
         values = hddstream.resident_points(scaler.scale_, scaler.min_)
     else:
         values = raw
-    columns = {'id': np.arange(n, dtype=np.int64), 'cluster_id': cluster_ids}
-    for c, name in enumerate(dataset_attributes):
-        columns[name] = values[:, c] if n else []
-    pd.DataFrame(columns).to_csv(cluster_points_filename, index=False)
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    body = _lib.format_points_csv(values, 0, idx, labels, threads=max(1, min(16, usable)))
+    with open(cluster_points_filename, 'ab') as f:
+        f.write(body)
 
 
 def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by_lineage):

@@ -204,10 +204,11 @@ class HDDStream(object):
         app.py:303-332 derives from the per-MC `points` dicts; written as the literal None there)."""
         if self.labels_uid is None or getattr(self, "_cl_arrays", None) is None:
             return np.empty(0, np.int64)
-        from ..multi import point_cluster_index
-        mem, off, *_ = self._cl_arrays
-        pc = self.table(_lib.PCORE)
-        return point_cluster_index(self.labels_uid, pc["id"], pc["uid"], mem, off)
+        if not getattr(self, "_n_points", 0):
+            return np.empty(0, np.int64)
+        # a gather on the device: per-point labels -> creation number -> cluster (cc_point_clusters);
+        # chronoclust_amd.multi.point_cluster_index is the same join in numpy (tests compare the two)
+        return self._h.point_clusters().astype(np.int64)
 
     def cluster_records(self):
         """The tracking-side records of this timepoint's clusters: what app.py:181-190 builds one by one -
@@ -249,7 +250,8 @@ class HDDStream(object):
             cl.__dict__ = {"pcore_ids": ids, "id": set(), "parents": set(), "centroid": cen_rows[c],
                            "cumulative_weight": weights[c], "preferred_dimensions": pref_rows[c], "_pcore_objects": None,
                            "_pc_cen": None, "_pc_pref": None, "_pc_uid": None, "_pc_base": base, "_pc_rows": rows,
-                           "historical_associates": set(), "historical_associates_pcores": set()}
+                           "historical_associates": set(), "historical_associates_pcores": set(),
+                           "offline_index": c}  # position among final_clusters (what point_cluster_index returns)
             out.append(cl)
         return out
 

@@ -20,6 +20,7 @@
 #include "cc_online.h"
 #include "cc_offline.h"
 #include "cc_comm.h"
+#include "cc_csv.h"
 
 namespace {
 
@@ -175,7 +176,8 @@ struct cc_handle {
     DevBuf<unsigned long long> adj, adjw;
     DevBuf<double> c_cf1, c_cf2, c_cen, c_pref, c_w;
     std::vector<HostCluster> clusters;
-    std::vector<long long> pcore_ids_host;
+    std::vector<long long> pcore_ids_host, pcore_uid_host;  // ids / creation numbers of the pcores, list order
+    DevBuf<int32_t> pc_map, pc_out;                         // cc_point_clusters: creation number -> cluster, result
     int n_core = 0;
 
     // association scratch
@@ -1927,6 +1929,7 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         refresh_ctl_params(h);
         h->clusters.clear();
         h->pcore_ids_host.clear();
+        h->pcore_uid_host.clear();
         h->n_core = 0;
         if (n_clusters) *n_clusters = 0;
         RowList rl = list_order(h);
@@ -1987,6 +1990,14 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         std::vector<int8_t> core(mp);
         std::vector<int> pdim(mp), nn(mp), nw_cnt(mp);
         h->pcore_ids_host.resize(mp);
+        {
+            // creation numbers of the pcores (cc_point_clusters joins the per-point labels to the clusters through them)
+            std::vector<long long> uid_all((size_t)h->hc.m_rows);
+            HIPCHK(hipMemcpyAsync(uid_all.data(), h->tab.uid.p, uid_all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+            sync_stream(h, h->stream);
+            h->pcore_uid_host.resize(mp);
+            for (int i = 0; i < mp; ++i) h->pcore_uid_host[(size_t)i] = uid_all[(size_t)rl.pcore[(size_t)i]];
+        }
         HIPCHK(hipMemcpyAsync(core.data(), h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(pdim.data(), h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
@@ -2334,6 +2345,64 @@ int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_
     if (min_row_dims >= 0) h->shard_min_row_dims = min_row_dims;
     if (offline_min_rows >= 0) h->offline_shard_min_rows = offline_min_rows;
     return CC_OK;
+}
+
+// ---- per-point output: cluster index of every point (device), text of the per-point file (host) ----------
+
+int cc_point_clusters(cc_handle* h, int32_t* out_idx)
+{
+    if (!h || !out_idx) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        const long long n = h->n_points;
+        if (n == 0) return (int)CC_OK;
+        // creation number -> cluster index, for the pcores the last cc_offline put into clusters (everything else,
+        // outlier microclusters included: -1), built from the merge lists and uploaded as one dense table
+        const long long n_uid = h->hc.outlier_last_id;
+        std::vector<int32_t> map((size_t)std::max<long long>(n_uid, 1), -1);
+        for (size_t c = 0; c < h->clusters.size(); ++c)
+            for (int m : h->clusters[c].members) {
+                const long long u = h->pcore_uid_host[(size_t)m];
+                if (u >= 0 && u < n_uid) map[(size_t)u] = (int32_t)c;
+            }
+        h->pc_map.ensure(map.size());
+        h->pc_out.ensure((size_t)n);
+        HIPCHK(hipMemcpyAsync(h->pc_map.p, map.data(), map.size() * 4, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_point_clusters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->lab_uid.p, n,
+                           h->pc_map.p, n_uid, h->pc_out.p);
+        HIPCHK(hipMemcpyAsync(out_idx, h->pc_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+        sync_stream(h, h->stream);  // (`map` is a local)
+        HIPCHK(hipGetLastError());
+        return (int)CC_OK;
+    });
+}
+
+int64_t cc_format_points_csv(const double* values, int64_t n, int32_t d, int64_t first_id, const int32_t* label_idx,
+                             const char* label_bytes, const int32_t* label_offsets, int32_t n_labels, char* out,
+                             int64_t cap)
+{
+    if (!values || n < 0 || d < 0 || !label_idx || !label_bytes || !label_offsets || n_labels < 1 || !out) return CC_ERR_BAD_ARG;
+    char* o = out;
+    char* const end = out + cap;
+    int max_label = 0;
+    for (int i = 0; i < n_labels; ++i) max_label = std::max(max_label, label_offsets[i + 1] - label_offsets[i]);
+    const int64_t row_max = 24 + 1 + max_label + (int64_t)d * 33 + 2;
+    for (int64_t r = 0; r < n; ++r) {
+        if (end - o < row_max) return CC_ERR_OOM;  // the caller's buffer is too small
+        o += cc::format_i64(first_id + r, o);
+        *o++ = ',';
+        int li = label_idx[r];
+        if (li < 0 || li >= n_labels) li = n_labels - 1;  // (-1: the last entry, "None")
+        const int ll = label_offsets[li + 1] - label_offsets[li];
+        memcpy(o, label_bytes + label_offsets[li], (size_t)ll);
+        o += ll;
+        const double* v = values + r * d;
+        for (int i = 0; i < d; ++i) {
+            *o++ = ',';
+            o += cc::format_repr(v[i], o);
+        }
+        *o++ = '\n';
+    }
+    return (int64_t)(o - out);
 }
 
 int cc_sync(cc_handle* h)

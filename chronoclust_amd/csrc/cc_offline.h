@@ -398,3 +398,14 @@ __global__ void k_assoc_merge(const double* __restrict__ part_dist, const int* _
     out_idx[c] = bidx;
     if (out_dist) out_dist[c] = best;
 }
+
+// cc_point_clusters: out[i] = cluster index of the microcluster whose creation number labels point i, or -1
+// (app.py:303-332 walks the per-microcluster `points` dicts of every cluster's pcores for this join)
+__global__ void k_point_clusters(const long long* __restrict__ lab_uid, long long n, const int* __restrict__ map,
+                                 long long n_uid, int* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long u = lab_uid[i];
+    out[i] = (u >= 0 && u < n_uid) ? map[u] : -1;
+}

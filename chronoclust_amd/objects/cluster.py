@@ -51,6 +51,7 @@ class Cluster(object):
         self._pc_rows = None         # timepoint + this cluster's rows of them (a range, or a list in pcore_ids order)
         self.historical_associates = set()
         self.historical_associates_pcores = set()
+        self.offline_index = None    # position among HDDStream.final_clusters (set by HDDStream.cluster_records)
 
     # -- lineage side (cluster.py:35-47) ------------------------------------------------------
     def add_id(self, id):

@@ -267,6 +267,22 @@ int cc_shard_rows(int32_t n, int32_t world, int32_t rank, int32_t unit, int32_t*
  * offline_min_rows; a negative value keeps the current setting (defaults 400 000 and 8 192) */
 int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows);
 
+/* The join of app.py:303-332 (write_datapoints_details walks the `points` dicts of every cluster's pcores): for every
+ * resident point the index of the cluster (order of cc_clusters_export, after cc_offline) its microcluster belongs
+ * to, -1 for points in outlier microclusters and in pcores outside every cluster (the literal `None` of app.py:396).
+ * A gather on the device from the per-point labels through a creation-number -> cluster table. */
+int cc_point_clusters(cc_handle* h, int32_t* out_idx);
+
+/* Text of n rows of cluster_points_D{t}.csv as DataFrame.to_csv(index=False) writes them (app.py:357-360):
+ * "<first_id + r>,<label>,<v[r,0]>,...,<v[r,d-1]>\n", floats as repr(float) (shortest round-trip digits, CPython's
+ * layout rules).  label_idx[r] selects one of n_labels CSV-ready label texts (label_bytes[label_offsets[i] ..
+ * label_offsets[i + 1])); an index outside [0, n_labels) selects the last one.  Pure host work, no handle: callers
+ * format chunks of rows on several threads.  Returns the number of bytes written to out, or CC_ERR_OOM when `cap`
+ * cannot hold them (25 + longest label + 33 d + 2 bytes per row always suffice). */
+int64_t cc_format_points_csv(const double* values, int64_t n, int32_t d, int64_t first_id, const int32_t* label_idx,
+                             const char* label_bytes, const int32_t* label_offsets, int32_t n_labels, char* out,
+                             int64_t cap);
+
 /* Waits until everything the handle has enqueued on its HIP streams is done (the timing bracket of a harness: what
  * torch.cuda.synchronize() would be for work a framework had launched).  Inside a group the wait is bounded like
  * every wait of the library that may hold a collective: CC_ERR_COMM when a peer is gone. */

@@ -348,3 +348,28 @@ def test_prefetched_upload_changes_nothing():
     ref = _hdd(cfg)
     ref.online_microcluster_maintenance(Xs[0] * 3.0, 0, device_scaling=(np.full(20, 1 / 3.0), np.zeros(20)))
     assert np.array_equal(ahead.labels_uid, ref.labels_uid)
+
+
+def test_point_clusters_device_gather_equals_numpy_join_and_reference_labels():
+    """cc_point_clusters (per-point label -> creation number -> cluster, on the device) against the same join in numpy
+    (chronoclust_amd.multi.point_cluster_index) on every timepoint of a churn scenario and of the bundled data, where
+    outlier microclusters, pcores outside every cluster and merged clusters all occur."""
+    from chronoclust_amd import multi
+    for name, cfg, Xs in (("d20", scenarios.params_to_config(scenarios.BLOB_SCENARIOS["d20"]["params"]),
+                           scenarios.make_blob_timepoints(scenarios.BLOB_SCENARIOS["d20"])),
+                          ("c1", scenarios.params_to_config(scenarios.C1_PARAMS), None)):
+        if Xs is None:
+            dump = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
+            Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
+        h = _hdd(cfg)
+        seen_none = seen_cluster = False
+        for t, X in enumerate(Xs):
+            h.online_microcluster_maintenance(X, t)
+            got = h.point_cluster_index()
+            mem, off, *_ = h._cl_arrays
+            pc = h.table(0)
+            exp = multi.point_cluster_index(h.labels_uid, pc["id"], pc["uid"], mem, off)
+            assert got.dtype == np.int64 and np.array_equal(got, exp), (name, t)
+            seen_none |= bool((got < 0).any())
+            seen_cluster |= bool((got >= 0).any())
+        assert seen_none and seen_cluster

@@ -130,6 +130,41 @@ def test_restore_of_a_foreign_or_incomplete_image_says_so(tmp_path):
         app.restore_program_state(d, hddstream=None)
 
 
+def test_points_csv_formatter_writes_repr_bytes():
+    """cc_format_points_csv (host side of the library, no GPU) against Python: every float as repr(float) - shortest
+    round-trip digits, exponent notation below 1e-4 and from 1e16, '.0' on integral values -, ids, quoted labels, and the
+    whole text equal to what the csv module / DataFrame.to_csv(index=False) write."""
+    import csv
+    import io
+    import pandas as pd
+    from chronoclust_amd import _lib
+    rng = np.random.default_rng(1)
+    specials = [0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1.5e-5, 123456789.0, 1e15, 1e16, 9999999999999998.0,
+                1.2345678901234567e16, 1e22, 1e23, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, 1 / 3, 100.0,
+                12345.678, 0.000123, 4.35e-07, 29.90423, 123456789012345678.0, 2.5e-310, 1e100, 1e-100, 16.0]
+    vals = np.array(specials + list(rng.uniform(-1, 1, 5000)) + list(rng.normal(0, 1, 5000) * 10.0 ** rng.integers(-30, 30, 5000))
+                    + list(np.round(rng.uniform(0, 50, 5000), 5)) + list(rng.integers(-10 ** 6, 10 ** 6, 2000).astype(float)))
+    text = _lib.format_points_csv(vals.reshape(-1, 1), 7, np.zeros(len(vals), np.int32), ["L"], threads=2, chunk=999).decode()
+    assert text.split("\n")[:-1] == ["%d,L,%s" % (7 + i, repr(float(v))) for i, v in enumerate(vals)]
+    n, d = 3000, 7
+    Y = (rng.uniform(0, 1, (n, d)) - 0.1) / 0.013
+    idx = rng.integers(-1, 3, n).astype(np.int32)
+    names = ["A|1", "(B,C)", "C", "None"]
+    quoted = []
+    for s in names:
+        b = io.StringIO()
+        csv.writer(b, lineterminator="").writerow([s])
+        quoted.append(b.getvalue())
+    assert quoted[1] == '"(B,C)"'
+    got = _lib.format_points_csv(Y, 0, idx, quoted, threads=3, chunk=512)
+    cols = {"id": np.arange(n), "cluster_id": np.array(names, dtype=object)[idx]}
+    cols.update({"m%d" % c: Y[:, c] for c in range(d)})
+    f = io.StringIO()
+    pd.DataFrame(cols).to_csv(f, index=False, header=False)
+    assert got == f.getvalue().encode()
+    assert _lib.format_points_csv(np.empty((0, 3)), 0, np.empty(0, np.int32), ["None"]) == b""
+
+
 def test_rounded_weights_equal_the_reference_expression():
     """chronoclust_amd.clustering.hddstream.rounded_weights against app.py:184 evaluated per value, on integers,
     decayed weights, exact and near half-way cases (x.y5 decimal strings whose doubles lie on either side)."""
