@@ -39,6 +39,33 @@ class CcStats(C.Structure):
                 ("scan_p_launches", C.c_int64), ("pruned_scan_rows", C.c_int64), ("pruned_scan_full_rows", C.c_int64)]
 
 
+POLICY_MAX_ROUNDS = 8
+
+
+class CcPolicyConfig(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
+                                         "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
+                                         "pad")] + [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
+
+
+class CcPolicyCarry(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("adapt_win", "clean_batches", "since_shrink", "pad")]
+
+
+class CcPolicyObs(C.Structure):
+    _fields_ = [("cursor", C.c_int64), ("m_rows", C.c_int32), ("stall_b", C.c_int32)] + \
+               [(k, C.c_int64) for k in ("stat_windows", "stat_truncated", "stat_trunc_unknown", "stat_tiles",
+                                         "stat_dirty_tiles")] + \
+               [("round_hist", C.c_int64 * (POLICY_MAX_ROUNDS + 2)), ("prune_rows", C.c_uint64), ("prune_full", C.c_uint64),
+                ("after_sequential", C.c_int32), ("pad", C.c_int32)]
+
+
+class CcPolicyDecision(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune",
+                                         "shard", "restart", "bad", "stalled", "pad")] + \
+               [(k, C.c_int64) for k in ("wins", "pts", "trunc", "unk", "tiles", "dtiles", "grew", "prune_rows", "prune_full")]
+
+
 class CcRelaxedStats(C.Structure):
     _fields_ = [("super_steps", C.c_int64), ("minibatch_points", C.c_int64), ("deferred_points", C.c_int64),
                 ("reserved", C.c_int64 * 5)]
@@ -83,6 +110,8 @@ SYMBOLS = {
     "cc_assoc_argmin": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, _i32p, _dp]),
     "cc_get_stats": (C.c_int, [C.c_void_p, C.POINTER(CcStats)]),
     "cc_sync": (C.c_int, [C.c_void_p]),
+    "cc_policy_replay": (C.c_int, [C.POINTER(CcPolicyConfig), C.POINTER(CcPolicyCarry), C.c_int64, C.c_int32,
+                                   C.POINTER(CcPolicyObs), C.c_int32, C.POINTER(CcPolicyDecision)]),
     "cc_point_clusters": (C.c_int, [C.c_void_p, _i32p]),
     "cc_format_points_csv": (C.c_int64, [_dp, C.c_int64, C.c_int32, C.c_int64, _i32p, C.c_char_p, _i32p, C.c_int32,
                                          C.c_void_p, C.c_int64]),
@@ -178,6 +207,29 @@ def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=6553
         return b""
     with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
         return b"".join(ex.map(work, starts))
+
+
+def policy_replay(config, carry, start, observations):
+    """cc_policy_replay: the window policy over recorded observations, no GPU.  config: dict of cc_policy_config fields;
+    carry: (adapt_win, clean_batches, since_shrink); start: (cursor, rows); observations: dicts of cc_policy_obs fields.
+    Returns (decisions as dicts - one more than observations -, carry after the call)."""
+    cfg = CcPolicyConfig(**{k: int(v) for k, v in config.items()})
+    car = CcPolicyCarry(int(carry[0]), int(carry[1]), int(carry[2]), 0)
+    n = len(observations)
+    obs = (CcPolicyObs * max(n, 1))()
+    for i, o in enumerate(observations):
+        for k, v in o.items():
+            if k == "round_hist":
+                for r, x in enumerate(v):
+                    obs[i].round_hist[r] = int(x)
+            else:
+                setattr(obs[i], k, int(v))
+    out = (CcPolicyDecision * (n + 1))()
+    rc = load().cc_policy_replay(C.byref(cfg), C.byref(car), int(start[0]), int(start[1]), obs, n, out)
+    if rc != 0:
+        raise ValueError("cc_policy_replay: %s" % _ERRORS.get(rc, rc))
+    keys = [k for k, _ in CcPolicyDecision._fields_ if k != "pad"]
+    return [{k: getattr(d, k) for k in keys} for d in out], (car.adapt_win, car.clean_batches, car.since_shrink)
 
 
 def shard_rows(n, world, rank, unit=1):

@@ -138,18 +138,20 @@ def run(data, output_directory, gating_centroid_file=None, normalise_data=True, 
 
 
 def write_result_file(gating, result_filename, timepoint, tracker_by_association, scaler):
-    """One row per cluster of this timepoint (app.py:229-260)."""
+    """One row per cluster of this timepoint (app.py:229-260); the centroids of all clusters are de-normalised and
+    rounded in one array operation (elementwise arithmetic: the same doubles as cluster by cluster)."""
     rows = []
     gating_now = gating.get(timepoint)
-    for cluster in tracker_by_association.current_clusters:
+    clusters = tracker_by_association.current_clusters
+    if clusters:
+        cen = np.asarray([cluster.centroid for cluster in clusters], dtype=np.float64)
+        if scaler:
+            cen = np.asarray(scaler.reverse_scaling(cen), dtype=np.float64)
+        centroids = np.round(cen, 5).tolist()
+    for i, cluster in enumerate(clusters):
         row = [timepoint, cluster.cumulative_weight, cluster.get_pcore_ids_as_str(),
                cluster.get_preferred_dimensions_as_str()]
-        if scaler:
-            centroid = scaler.reverse_scaling([cluster.centroid]).tolist()[0]
-            centroid = np.round(centroid, 5).tolist()
-        else:
-            centroid = np.round(cluster.centroid, 5).tolist()
-        row.extend(centroid)
+        row.extend(centroids[i])
         row.append(cluster.id)
         row.append(cluster.get_historical_associates_as_str())
         if bool(gating_now):
@@ -166,7 +168,11 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, clust
     number -> cluster), the lineage ids are looked up by cluster index, and the text is produced by
     cc_format_points_csv (repr(float) bytes, a few host threads).  Same bytes as DataFrame.to_csv(index=False)."""
     import io
-    write_file_header(cluster_points_filename, ['id', 'cluster_id'] + dataset_attributes)
+    # (the reference's final DataFrame.to_csv rewrites the whole file, header included, with "\n" line ends)
+    head = io.StringIO()
+    csv.writer(head, lineterminator="\n").writerow(['id', 'cluster_id'] + dataset_attributes)
+    with open(cluster_points_filename, 'w') as f:
+        f.write(head.getvalue())
     n = raw.shape[0]
     if n == 0:
         return

@@ -21,6 +21,7 @@
 #include "cc_offline.h"
 #include "cc_comm.h"
 #include "cc_csv.h"
+#include "cc_policy.h"
 
 namespace {
 
@@ -230,6 +231,68 @@ struct cc_handle {
 };
 
 namespace {
+
+// CHRONOCLUST_HIP_POLICY_TRACE=<file>: the observations and decisions of the window policy, one JSON object per line
+struct PolicyTrace {
+    FILE* f = nullptr;
+    static void obs_json(FILE* f, const cc_policy_obs& o)
+    {
+        fprintf(f, "{\"cursor\": %lld, \"m_rows\": %d, \"stall_b\": %d, \"stat_windows\": %lld, \"stat_truncated\": %lld, "
+                   "\"stat_trunc_unknown\": %lld, \"stat_tiles\": %lld, \"stat_dirty_tiles\": %lld, \"round_hist\": [",
+                (long long)o.cursor, o.m_rows, o.stall_b, (long long)o.stat_windows, (long long)o.stat_truncated,
+                (long long)o.stat_trunc_unknown, (long long)o.stat_tiles, (long long)o.stat_dirty_tiles);
+        for (int r = 0; r < CC_POLICY_MAX_ROUNDS + 2; ++r) fprintf(f, "%s%lld", r ? ", " : "", (long long)o.round_hist[r]);
+        fprintf(f, "], \"prune_rows\": %llu, \"prune_full\": %llu, \"after_sequential\": %d}", (unsigned long long)o.prune_rows,
+                (unsigned long long)o.prune_full, o.after_sequential);
+    }
+    static void dec_json(FILE* f, const cc_policy_decision& d)
+    {
+        fprintf(f, "{\"win_cfg\": %d, \"want\": %d, \"rounds\": %d, \"batch_windows\": %d, \"lookahead\": %d, \"nodirty\": %d, "
+                   "\"prune\": %d, \"shard\": %d, \"restart\": %d, \"bad\": %d, \"stalled\": %d}",
+                d.win_cfg, d.want, d.rounds, d.batch_windows, d.lookahead, d.nodirty, d.prune, d.shard, d.restart, d.bad, d.stalled);
+    }
+    // rank >= 0: the handle is rank `rank` of a group and writes <file>.rank<rank>
+    PolicyTrace(const cc_policy_config& c, const cc_policy_carry& k, long long cursor, int rows, const cc_policy_decision& d0,
+                int rank)
+    {
+        const char* path = getenv("CHRONOCLUST_HIP_POLICY_TRACE");
+        if (!path || !path[0]) return;
+        const std::string name = rank >= 0 ? std::string(path) + ".rank" + std::to_string(rank) : std::string(path);
+        f = fopen(name.c_str(), "a");
+        if (!f) return;
+        fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
+                   "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
+                   "\"resume\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
+                c.prune_applicable, c.can_shard, c.d, c.resume, (long long)c.shard_min_row_dims, (long long)c.n_end,
+                k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
+        dec_json(f, d0);
+        fprintf(f, "}}\n");
+    }
+    void batch(const cc_policy_obs& o, const cc_policy_decision& d)
+    {
+        if (!f) return;
+        fprintf(f, "{\"obs\": ");
+        obs_json(f, o);
+        fprintf(f, ", \"dec\": ");
+        dec_json(f, d);
+        fprintf(f, "}\n");
+    }
+    void sequential(long long cursor, int rows, const cc_policy_decision& d)
+    {
+        cc_policy_obs o{};
+        o.cursor = cursor;
+        o.m_rows = rows;
+        o.after_sequential = 1;
+        batch(o, d);
+    }
+    ~PolicyTrace()
+    {
+        if (f) fclose(f);
+    }
+    PolicyTrace(const PolicyTrace&) = delete;
+    PolicyTrace& operator=(const PolicyTrace&) = delete;
+};
 
 int fail(cc_handle* h, int code, const std::string& msg)
 {
@@ -1172,9 +1235,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         const int world = h->comm.world, myrank = h->comm.rank;
         // (a communicator of one rank takes the same path: that is how the RCCL calls are exercised on one GPU)
         const bool grouped = h->comm.active();
-        auto want_shard = [&](int m_rows) {
-            return grouped && !h->shard_suspended && (long long)m_rows * h->d >= h->shard_min_row_dims;
-        };
         if (grouped) {
             h->gsend_stride = (size_t)h->win_alloc * 4;
             h->gpart_stride = (size_t)world * h->win_alloc * 4;
@@ -1190,14 +1250,29 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.n_points = N;
         c.xt_stride = h->n_points;
         c.no_create = no_create ? 1 : 0;
-        const int early0 = h->tun.early_window > 0 ? h->tun.early_window : 4096;
-        // start where the previous call settled; a (nearly) empty table starts small and grows by doubling
-        const int start_small = 256;
-        const int fast_below = 4096;  // below this size a clean batch quadruples the window (and batches are two windows)
-        // (a new timepoint begins with whatever changed since the last one - decayed weights, new populations -, which
-        // takes a few validation rounds per window: not with the largest window the previous one ended on)
-        if (h->adapt_win > 0) c.win_cfg = std::min(win, resume ? h->adapt_win : std::min(h->adapt_win, early0));
-        else c.win_cfg = std::min(win, (c.m_rows < 1024) ? start_small : early0);
+        // How the batches of windows run - window size, validation rounds, windows per batch, lookahead, dirty scans,
+        // pruned or plain scans, split over the ranks - is decided by cc::WindowPolicy (cc_policy.h) from the device
+        // counters alone; this function carries the decisions out.
+        cc_policy_config pcfg{};
+        pcfg.window = win;
+        pcfg.rounds_max = R;
+        pcfg.windows_per_sync = h->tun.windows_per_sync;
+        pcfg.early_window = h->tun.early_window;
+        pcfg.lookahead = h->tun.lookahead;
+        pcfg.allow_nodirty = h->allow_nodirty ? 1 : 0;
+        pcfg.prune_mode = h->prune_mode;
+        pcfg.prune_applicable = (h->d > 8 && h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 != 0 &&
+                                 (h->d == 14 || h->d == 16 || h->d == 20 || h->d == 32 || h->d == 40 || h->d == 64)) ? 1 : 0;
+        pcfg.can_shard = (grouped && !h->shard_suspended) ? 1 : 0;
+        pcfg.d = h->d;
+        pcfg.resume = resume ? 1 : 0;
+        pcfg.shard_min_row_dims = h->shard_min_row_dims;
+        pcfg.n_end = N;
+        cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
+        cc::WindowPolicy policy(pcfg, pcarry);
+        cc_policy_decision dec = policy.start(range_a, c.m_rows);
+        PolicyTrace ptrace(pcfg, pcarry, range_a, c.m_rows, dec, grouped ? myrank : -1);
+        c.win_cfg = dec.win_cfg;
         c.win_b = (int)std::min<long long>(c.win_cfg, N - range_a);
         c.max_rounds = R;
         c.last_round = 0;
@@ -1213,8 +1288,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
-        const bool la_forced = h->tun.lookahead == 3;                    // from the first window on, whatever happens (tests)
-        const bool la_enabled = h->tun.lookahead != 2;                   // 0 (default) and 1: while windows commit in full
         bool la_on = false;
         auto set_lookahead = [&](bool on) {
             // (re)start: the current window is a fresh one, the lookahead scan enqueued next covers the one after it
@@ -1233,7 +1306,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             c.la_b[q ^ 1] = 0;
             c.la_rows[q ^ 1] = 0;
         };
-        set_lookahead(la_forced);
+        set_lookahead(dec.lookahead != 0);
         c.stat_pair_rows = 0.0;
         for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
         push_ctl(h);
@@ -1249,7 +1322,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         std::vector<std::pair<size_t, double>> timed;  // (event index, pair-dims covered)
         std::vector<size_t> timed_comm;                // event index of every timed merge + all-gather
         const bool timing = h->tun.time_kernels != 0;
-        bool shard_on = want_shard(c.m_rows);
+        bool shard_on = dec.shard != 0;
         double pair_rows_eff = 0.0, pair_rows_prev = 0.0;  // (window points x table rows) this rank's scans covered
         long long sharded_windows = 0;
 
@@ -1280,26 +1353,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         bool seq_probe = false;           // the batch of windows in flight is a probe after a sequential stint
         double win_rate = 0.0, seq_rate_last = 0.0;  // points per millisecond (wall clock) of the last batch / chunk
         auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        // Validation rounds enqueued per window adapt to what the last batch needed: a skipped round is still a
-        // launch, and a window that would need one more round than enqueued simply commits a shorter prefix.
-        const int Rmax = R;
-        int Rcur = R;
-        long long rows_prev = c.m_rows, cursor_prev = range_a, windows_prev = 0, trunc_batch = 0;
-        bool first_batch = true;
-        int batch_windows = (c.win_cfg < 1024) ? 2 : std::max(2, h->tun.windows_per_sync / 4);
-        const int early_win = h->tun.early_window > 0 ? h->tun.early_window : 4096;
-        // the pruned snapshot scan (k_scan_p): on while the rows it still evaluates in full stay a minority; after a batch
-        // in which they were not, the plain scan runs for a few batches before the next try
-        const bool prune_applicable = h->prune_mode != 0 && h->d > 8 && h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 != 0 &&
-                                      (h->d == 14 || h->d == 16 || h->d == 20 || h->d == 32 || h->d == 40 || h->d == 64);
-        int prune_hold = 0;  // batches left before pruning is tried again
-        int stalled_batches = 0;
-        h->prune_now = prune_applicable && !shard_on;
-        unsigned long long prune_rows_prev = 0, prune_full_prev = 0;
-        long long hist_prev[CC_MAX_ROUNDS + 2] = {0};
-        long long trunc_prev = 0, tiles_prev = 0, dtiles_prev = 0;
-        int rounds_batch = R;  // validation rounds that were enqueued per window in the batch just finished
-        long long unk_prev = 0, unk_batch = 0;  // truncated windows that stopped at an undecidable point
+        int Rcur = dec.rounds;             // validation rounds enqueued per window of the batch
+        int batch_windows = dec.batch_windows;
+        h->prune_now = dec.prune != 0;
+        nodirty = dec.nodirty != 0;
+        long long cursor_prev = range_a;
         unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
@@ -1323,7 +1381,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 done = h->hc.cursor;
                 m_known = h->hc.m_rows;
                 seq_host = h->hc.window_seq;
-                rows_prev = h->hc.m_rows; cursor_prev = h->hc.cursor;
+                cursor_prev = h->hc.cursor;
                 const double seq_rate = got > 0 ? (double)got / std::max(dt, 1e-3) : 0.0;
                 if (h->trace)
                     fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms (so far %lld shader cycles, %.3f ms of kernel time)\n",
@@ -1339,8 +1397,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     bad_batches = 0;
                     HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
                     h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
-                    nodirty = false;
-                    set_lookahead(la_forced);
+                    dec = policy.after_sequential(h->hc.cursor, h->hc.m_rows);
+                    ptrace.sequential(h->hc.cursor, h->hc.m_rows, dec);
+                    nodirty = dec.nodirty != 0;
+                    set_lookahead(dec.lookahead != 0);
                     push_ctl(h);
                 }
                 continue;
@@ -1487,138 +1547,61 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             pull_ctl(h);
             if (la_on) sync_stream(h, sB);
             seq_host = h->hc.window_seq;
-            const long long done_before = done;
             done = h->hc.cursor;
             m_known = h->hc.m_rows;
-            {
-                const unsigned long long pr = h->hc.stat_prune_rows - prune_rows_prev, pfu = h->hc.stat_prune_full - prune_full_prev;
-                prune_rows_prev = h->hc.stat_prune_rows;
-                prune_full_prev = h->hc.stat_prune_full;
-                if (h->prune_now) {
-                    // more than half of the (wave, row) pairs evaluated in full: the prefix scan and the tests cost more
-                    // than they save (start-up: the points' own microclusters do not exist yet; overlapping data)
-                    if (pr > 0 && pfu * 2 > pr) prune_hold = 4;
-                    // a window that commits nothing although its first point is always decidable: cannot happen with
-                    // exact first candidates - should it, the plain scan takes over for good
-                    if (done == done_before && !nodirty) prune_hold = 1 << 30;
-                } else if (prune_hold > 0) --prune_hold;
-                // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused
-                // for want of the dirty scans idle the rest of their batch), not three times in a row
-                stalled_batches = (done == done_before) ? stalled_batches + 1 : 0;
-                if (stalled_batches >= 3)
-                    return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
-                if (h->trace && pr > 0)
-                    fprintf(stderr, "[cc] pruned scans of the batch: %llu (wave, row) pairs, %.1f %% evaluated in full\n", pr, 100.0 * (double)pfu / (double)pr);
-            }
-            pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_on ? (double)world : 1.0);
-            pair_rows_prev = h->hc.stat_pair_rows;
+            const bool shard_was = shard_on;
             {
                 const double dt = now_ms() - batch_t0;
                 const long long pts_b = h->hc.cursor - cursor_prev;
                 if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
-            }
-            {
-                int used = 1;
-                for (int r = 1; r <= CC_MAX_ROUNDS; ++r) {
-                    if (h->hc.round_hist[r] - hist_prev[r] > 0) used = r;
-                    hist_prev[r] = h->hc.round_hist[r];
-                }
-                const long long trunc = h->hc.stat_truncated - trunc_prev;
-                trunc_prev = h->hc.stat_truncated;
-                trunc_batch = trunc;
-                rounds_batch = Rcur;
-                unk_batch = h->hc.stat_trunc_unknown - unk_prev;
-                unk_prev = h->hc.stat_trunc_unknown;
-                if (trunc > 0 && nodirty) {
-                    // points refused for want of the dirty scans: the next batch launches them again, nothing else changes
-                } else if (trunc > 0) Rcur = std::min(Rmax, std::max(used, Rcur) + 1);
-                else Rcur = std::max(1, std::min(Rcur, used));
-            }
-            {
-                // Window size for the next batch.
-                //  - While many MCs are being created the validation of a window is quadratic in its size (their
-                //    versions cannot be pruned): at most `early_win` there, the configured size once the table is stable.
-                //  - When windows commit short of their size (few MCs, overlapping data: the validation frontier stops
-                //    early) the speculated remainder is wasted: aim at the average committed length; grow back
-                //    by doubling while nothing is truncated.
-                const long long grew = (long long)h->hc.m_rows - rows_prev, pts = h->hc.cursor - cursor_prev;
-                // while MCs are being created every window needs its chains replayed two or three times: all the rounds
-                if (pts > 0 && grew * 50 > pts) Rcur = Rmax;
-                const long long wins = h->hc.stat_windows - windows_prev;
-                rows_prev = h->hc.m_rows;
                 cursor_prev = h->hc.cursor;
-                windows_prev = h->hc.stat_windows;
-                //  - The same holds while MCs are being promoted: a promoted MC competes in a list it was not scanned
-                //    for, so the dirty scans run unpruned; the device counts the point tiles whose dirty scan ran.
-                const long long tiles = h->hc.stat_tiles - tiles_prev, dtiles = h->hc.stat_dirty_tiles - dtiles_prev;
-                tiles_prev = h->hc.stat_tiles;
-                dtiles_prev = h->hc.stat_dirty_tiles;
-                const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
-                const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
-                int want = h->hc.win_cfg;
-                if (nodirty && trunc_batch > 0) {
-                    // (see above: windows stopped at points that needed the dirty scans)
-                } else if (trunc_batch * 4 >= wins && trunc_batch > 0 && rounds_batch < Rmax && unk_batch * 2 < trunc_batch) {
-                    // windows stopped short because their decisions were still moving, with fewer validation rounds
-                    // enqueued than allowed: more rounds (above) are the remedy, not a shorter window
-                    h->clean_batches = 0;
-                } else if (trunc_batch * 4 >= wins && trunc_batch > 0) {
-                    // a quarter or more of the windows stopped short: the window is too long for this data
-                    const long long avg = pts / wins;
-                    want = (int)std::min<long long>(target, std::max<long long>(128, ((avg + 63) / 64) * 64));
-                    h->clean_batches = 0;
-                    h->since_shrink = 0;
-                } else {
-                    // an occasional short window (one more validation round needed than enqueued) is no reason to
-                    // shrink; grow by doubling after one clean batch, after two if a shrink is recent
-                    ++h->since_shrink;
-                    if (trunc_batch == 0) ++h->clean_batches;
-                    const int need = (h->since_shrink > 8 || want < fast_below) ? 1 : 2;
-                    if (trunc_batch == 0 && h->clean_batches >= need) {
-                        // a batch in which no window was cut short and no point tile needed its dirty scan (the table has
-                        // settled: nothing created or promoted any more) goes straight to the full size
-                        const bool settled = tiles > 0 && dtiles == 0 && grew == 0;
-                        want = settled ? target : std::min(target, std::max(want, 64) * (want < fast_below ? 4 : 2));  // small windows: fast start
-                    }
-                }
-                want = std::min(want, target);
-                h->adapt_win = want;
-                // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few
-                // overlapping MCs) the scan of a window that then starts elsewhere is wasted
-                // (the dirty scans keep their full split: when only a few tiles need them those tiles are long - every
-                // version row before them -, and when none does they are not launched at all)
+            }
+            {
+                // what the device counted, and the policy's decision for the next batch
+                cc_policy_obs o{};
+                o.cursor = h->hc.cursor;
+                o.m_rows = h->hc.m_rows;
+                o.stall_b = h->hc.stall_b;
+                o.stat_windows = h->hc.stat_windows;
+                o.stat_truncated = h->hc.stat_truncated;
+                o.stat_trunc_unknown = h->hc.stat_trunc_unknown;
+                o.stat_tiles = h->hc.stat_tiles;
+                o.stat_dirty_tiles = h->hc.stat_dirty_tiles;
+                for (int r = 0; r < CC_MAX_ROUNDS + 2; ++r) o.round_hist[r] = h->hc.round_hist[r];
+                o.prune_rows = h->hc.stat_prune_rows;
+                o.prune_full = h->hc.stat_prune_full;
+                dec = policy.after_batch(o);
+                ptrace.batch(o, dec);
+                const cc_policy_carry& k = policy.carry();
+                h->adapt_win = k.adapt_win; h->clean_batches = k.clean_batches; h->since_shrink = k.since_shrink;
+                if (dec.stalled)
+                    return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
+                if (h->trace && dec.prune_rows > 0)
+                    fprintf(stderr, "[cc] pruned scans of the batch (sample): %lld (wave, row) pairs, %.1f %% evaluated in full\n",
+                            (long long)dec.prune_rows, 100.0 * (double)dec.prune_full / (double)dec.prune_rows);
+                pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
+                pair_rows_prev = h->hc.stat_pair_rows;
+                if (shard_was) sharded_windows += dec.wins;
+                Rcur = dec.rounds;
                 Sd = Sd_full;
-                nodirty = h->allow_nodirty && tiles > 0 && dtiles == 0 && trunc_batch == 0;
-                const bool want_la = la_forced || (la_enabled && trunc_batch == 0 && !unpruned);
-                // (a pending lookahead scan was made for the old split of the table rows: restart when the split changes)
-                const bool shard_next = want_shard(h->hc.m_rows);
-                if (shard_on) sharded_windows += wins;
-                const bool shard_flip = shard_next != shard_on;
-                shard_on = shard_next;
-                // pruned snapshot scans in the next batch?  (a function of device counters only: every rank decides alike)
-                const bool prune_next = prune_applicable && !shard_on && ((h->prune_mode == 2 && prune_hold < (1 << 29)) || prune_hold == 0);
-                const bool prune_flip = prune_next != h->prune_now;
-                h->prune_now = prune_next;
-                if ((want != h->hc.win_cfg || want_la != la_on || h->hc.stall_b > 0 || shard_flip || prune_flip) && done < N) {
-                    h->hc.win_cfg = want;
-                    h->hc.win_b = (int)std::min<long long>(want, N - done);
-                    set_lookahead(want_la);
+                nodirty = dec.nodirty != 0;
+                shard_on = dec.shard != 0;
+                h->prune_now = dec.prune != 0;
+                if (dec.restart) {
+                    h->hc.win_cfg = dec.win_cfg;
+                    h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);
+                    set_lookahead(dec.lookahead != 0);
                     push_ctl(h);
                 }
                 if (h->trace)
                     fprintf(stderr, "[cc] %.2f ms done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
-                            now_ms() - batch_t0, done, h->hc.m_rows, wins, pts, trunc_batch, unk_batch, (long long)h->hc.stat_lookahead, dtiles, tiles,
-                            (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, want, Rcur);
-                // settle quickly at the start of a call and whenever windows are being truncated
-                // ... and while the window is held at the start-up size: the end of that phase is only seen at a batch boundary
-                batch_windows = (trunc_batch > 0 || first_batch || want < target || target < win) ? std::max(2, h->tun.windows_per_sync / 4)
-                                                                                                  : h->tun.windows_per_sync;
-                if (want < fast_below && trunc_batch == 0) batch_windows = 2;
-                first_batch = false;
+                            now_ms() - batch_t0, done, h->hc.m_rows, (long long)dec.wins, (long long)dec.pts, (long long)dec.trunc, (long long)dec.unk, (long long)h->hc.stat_lookahead, (long long)dec.dtiles, (long long)dec.tiles,
+                            (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, dec.want, Rcur);
+                batch_windows = dec.batch_windows;
                 // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back
                 // if it measures slower than this batch did)
                 {
-                    const bool bad = trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024;
+                    const bool bad = dec.bad != 0;
                     bad_batches = bad ? bad_batches + 1 : 0;
                     if (seq_mode == 0 && seq_possible() && done < N) {
                         if (seq_probe) {
@@ -2414,6 +2397,18 @@ int cc_sync(cc_handle* h)
         HIPCHK(hipGetLastError());
         return (int)CC_OK;
     });
+}
+
+int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,
+                     const cc_policy_obs* obs, int32_t n, cc_policy_decision* out)
+{
+    if (!cfg || !carry || n < 0 || (n > 0 && !obs) || !out) return CC_ERR_BAD_ARG;
+    cc::WindowPolicy policy(*cfg, *carry);
+    out[0] = policy.start(start_cursor, start_rows);
+    for (int i = 0; i < n; ++i)
+        out[i + 1] = obs[i].after_sequential ? policy.after_sequential(obs[i].cursor, obs[i].m_rows) : policy.after_batch(obs[i]);
+    *carry = policy.carry();
+    return CC_OK;
 }
 
 int cc_get_stats(cc_handle* h, cc_stats* out)

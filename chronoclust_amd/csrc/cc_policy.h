@@ -1,0 +1,205 @@
+// cc_policy.h — the window policy of the exact online phase as a pure host object.
+//
+// Between two batches of windows the host reads the device's control block once and decides how the next batch runs:
+// window size, validation rounds enqueued per window, windows per batch, lookahead scans on / off, dirty scans launched
+// or not, pruned or plain snapshot scans, scans split over the ranks of a group or not.  None of this can change a
+// result (every combination is exact), but inside a multi-GPU group every rank has to take the SAME decisions - they
+// determine the sequence of collectives -, so the policy must be a function of the device counters alone, which are
+// identical on all ranks.  That is what this file isolates: WindowPolicy sees nothing but PolicyConfig (the call's
+// constants), PolicyCarry (three integers a handle keeps from call to call) and one BatchObs per batch (cumulative
+// counters as read back); no clock, no pointer, no HIP.  cc_policy_replay (C-ABI) runs it over recorded observations on
+// a machine without a GPU (tests/test_window_policy.py).
+// The one wall-clock rule of the library - handing a stream of short, truncated windows to the sequential kernel when
+// that measures faster - stays in cc_api.hip, is switched off inside a group, and only consumes Decision::bad from here.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/chronoclust_hip.h"
+
+namespace cc {
+
+inline bool policy_want_shard(const cc_policy_config& c, int m_rows)
+{
+    return c.can_shard != 0 && (long long)m_rows * c.d >= c.shard_min_row_dims;
+}
+
+class WindowPolicy {
+public:
+    static constexpr int kStartSmall = 256;   // window on a (nearly) empty table
+    static constexpr int kFastBelow = 4096;   // below this size a clean batch quadruples the window, batches are two windows
+
+    WindowPolicy(const cc_policy_config& cfg, const cc_policy_carry& carry) : c_(cfg), k_(carry) {}
+
+    // the first batch of a call that starts at `cursor` with `m_rows` table rows
+    cc_policy_decision start(long long cursor, int m_rows)
+    {
+        const int early0 = c_.early_window > 0 ? c_.early_window : 4096;
+        // start where the previous call settled; a (nearly) empty table starts small and grows by doubling (a new
+        // timepoint begins with whatever changed since the last one - decayed weights, new populations -, which takes a
+        // few validation rounds per window: not with the largest window the previous one ended on)
+        if (k_.adapt_win > 0) win_cfg_ = std::min(c_.window, c_.resume ? k_.adapt_win : std::min(k_.adapt_win, early0));
+        else win_cfg_ = std::min(c_.window, (m_rows < 1024) ? kStartSmall : early0);
+        rcur_ = c_.rounds_max;
+        batch_windows_ = (win_cfg_ < 1024) ? 2 : std::max(2, c_.windows_per_sync / 4);
+        la_on_ = c_.lookahead == 3;
+        nodirty_ = false;
+        shard_on_ = policy_want_shard(c_, m_rows);
+        prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_;
+        prune_hold_ = 0;
+        stalled_ = 0;
+        first_batch_ = true;
+        prev_ = cc_policy_obs{};
+        prev_.cursor = cursor;
+        prev_.m_rows = m_rows;
+        return decision(0, 0);
+    }
+
+    // the stream comes back from the sequential kernel: a fresh window at the cursor, dirty scans launched again, no
+    // lookahead scan pending; the counters of the windows were not touched meanwhile
+    cc_policy_decision after_sequential(long long cursor, int m_rows)
+    {
+        prev_.cursor = cursor;
+        prev_.m_rows = m_rows;
+        nodirty_ = false;
+        la_on_ = c_.lookahead == 3;
+        return decision(1, 0);
+    }
+
+    // a batch of windows has run; `o` = the cumulative counters now
+    cc_policy_decision after_batch(const cc_policy_obs& o)
+    {
+        const int Rmax = c_.rounds_max, win = c_.window;
+        const int early_win = c_.early_window > 0 ? c_.early_window : 4096;
+        const long long done_before = prev_.cursor, done = o.cursor;
+        // ---- pruned scans: on while the rows they still evaluate in full stay a minority ----
+        const unsigned long long pr = o.prune_rows - prev_.prune_rows, pfu = o.prune_full - prev_.prune_full;
+        if (prune_on_) {
+            // more than half of the (wave, row) pairs evaluated in full: the prefix scan and the tests cost more than
+            // they save (start-up: the points' own microclusters do not exist yet; overlapping data)
+            if (pr > 0 && pfu * 2 > pr) prune_hold_ = 4;
+            // a window that commits nothing although its first point is always decidable: cannot happen with exact
+            // first candidates - should it, the plain scan takes over for good
+            if (done == done_before && !nodirty_) prune_hold_ = 1 << 30;
+        } else if (prune_hold_ > 0) --prune_hold_;
+        // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused for want
+        // of the dirty scans idle the rest of their batch), not three times in a row
+        stalled_ = (done == done_before) ? stalled_ + 1 : 0;
+        // ---- validation rounds enqueued per window: what the last batch needed ----
+        int used = 1;
+        for (int r = 1; r <= CC_POLICY_MAX_ROUNDS; ++r)
+            if (o.round_hist[r] - prev_.round_hist[r] > 0) used = r;
+        const long long trunc_batch = o.stat_truncated - prev_.stat_truncated;
+        const int rounds_batch = rcur_;
+        const long long unk_batch = o.stat_trunc_unknown - prev_.stat_trunc_unknown;
+        if (trunc_batch > 0 && nodirty_) {
+            // points refused for want of the dirty scans: the next batch launches them again, nothing else changes
+        } else if (trunc_batch > 0) rcur_ = std::min(Rmax, std::max(used, rcur_) + 1);
+        else rcur_ = std::max(1, std::min(rcur_, used));
+        // ---- window size ----
+        //  - While many MCs are being created the validation of a window is quadratic in its size (their versions cannot
+        //    be pruned): at most `early_win` there, the configured size once the table is stable.
+        //  - When windows commit short of their size (few MCs, overlapping data: the validation frontier stops early) the
+        //    speculated remainder is wasted: aim at the average committed length; grow back by doubling while nothing
+        //    is truncated.
+        const long long grew = (long long)o.m_rows - prev_.m_rows, pts = o.cursor - prev_.cursor;
+        // while MCs are being created every window needs its chains replayed two or three times: all the rounds
+        if (pts > 0 && grew * 50 > pts) rcur_ = Rmax;
+        const long long wins = o.stat_windows - prev_.stat_windows;
+        //  - The same holds while MCs are being promoted: a promoted MC competes in a list it was not scanned for, so
+        //    the dirty scans run unpruned; the device counts the point tiles whose dirty scan ran.
+        const long long tiles = o.stat_tiles - prev_.stat_tiles, dtiles = o.stat_dirty_tiles - prev_.stat_dirty_tiles;
+        const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
+        const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
+        int want = win_cfg_;
+        if (nodirty_ && trunc_batch > 0) {
+            // (see above: windows stopped at points that needed the dirty scans)
+        } else if (trunc_batch * 4 >= wins && trunc_batch > 0 && rounds_batch < Rmax && unk_batch * 2 < trunc_batch) {
+            // windows stopped short because their decisions were still moving, with fewer validation rounds enqueued
+            // than allowed: more rounds (above) are the remedy, not a shorter window
+            k_.clean_batches = 0;
+        } else if (trunc_batch * 4 >= wins && trunc_batch > 0) {
+            // a quarter or more of the windows stopped short: the window is too long for this data
+            const long long avg = pts / wins;
+            want = (int)std::min<long long>(target, std::max<long long>(128, ((avg + 63) / 64) * 64));
+            k_.clean_batches = 0;
+            k_.since_shrink = 0;
+        } else {
+            // an occasional short window (one more validation round needed than enqueued) is no reason to shrink; grow
+            // by doubling after one clean batch, after two if a shrink is recent
+            ++k_.since_shrink;
+            if (trunc_batch == 0) ++k_.clean_batches;
+            const int need = (k_.since_shrink > 8 || want < kFastBelow) ? 1 : 2;
+            if (trunc_batch == 0 && k_.clean_batches >= need) {
+                // a batch in which no window was cut short and no point tile needed its dirty scan (the table has
+                // settled: nothing created or promoted any more) goes straight to the full size
+                const bool settled = tiles > 0 && dtiles == 0 && grew == 0;
+                want = settled ? target : std::min(target, std::max(want, 64) * (want < kFastBelow ? 4 : 2));
+            }
+        }
+        want = std::min(want, target);
+        k_.adapt_win = want;
+        // ---- dirty scans, lookahead, split, scan kind ----
+        // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few overlapping
+        // MCs) the scan of a window that then starts elsewhere is wasted
+        nodirty_ = c_.allow_nodirty != 0 && tiles > 0 && dtiles == 0 && trunc_batch == 0;
+        const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned);
+        // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)
+        const bool shard_next = policy_want_shard(c_, o.m_rows);
+        const bool shard_flip = shard_next != shard_on_;
+        shard_on_ = shard_next;
+        const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_ &&
+                                ((c_.prune_mode == 2 && prune_hold_ < (1 << 29)) || prune_hold_ == 0);
+        const bool prune_flip = prune_next != prune_on_;
+        prune_on_ = prune_next;
+        const bool more = done < c_.n_end;
+        const int restart = ((want != win_cfg_ || want_la != la_on_ || o.stall_b > 0 || shard_flip || prune_flip) && more) ? 1 : 0;
+        if (restart) {
+            win_cfg_ = want;
+            la_on_ = want_la;
+        }
+        // settle quickly at the start of a call and whenever windows are being truncated ... and while the window is
+        // held at the start-up size: the end of that phase is only seen at a batch boundary
+        batch_windows_ = (trunc_batch > 0 || first_batch_ || want < target || target < win) ? std::max(2, c_.windows_per_sync / 4)
+                                                                                            : c_.windows_per_sync;
+        if (want < kFastBelow && trunc_batch == 0) batch_windows_ = 2;
+        first_batch_ = false;
+        // windows that keep stopping short on a small table (input of the sequential-kernel rule)
+        const int bad = (trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024) ? 1 : 0;
+        prev_ = o;
+        cc_policy_decision d = decision(restart, bad);
+        d.want = want;
+        d.wins = wins; d.pts = pts; d.trunc = trunc_batch; d.unk = unk_batch; d.tiles = tiles; d.dtiles = dtiles; d.grew = grew;
+        d.prune_rows = (long long)pr; d.prune_full = (long long)pfu;
+        return d;
+    }
+
+    const cc_policy_carry& carry() const { return k_; }
+    bool shard_on() const { return shard_on_; }
+
+private:
+    cc_policy_decision decision(int restart, int bad) const
+    {
+        cc_policy_decision d{};
+        d.win_cfg = win_cfg_;
+        d.want = win_cfg_;
+        d.rounds = rcur_;
+        d.batch_windows = batch_windows_;
+        d.lookahead = la_on_ ? 1 : 0;
+        d.nodirty = nodirty_ ? 1 : 0;
+        d.prune = prune_on_ ? 1 : 0;
+        d.shard = shard_on_ ? 1 : 0;
+        d.restart = restart;
+        d.bad = bad;
+        d.stalled = stalled_ >= 3 ? 1 : 0;
+        return d;
+    }
+
+    cc_policy_config c_;
+    cc_policy_carry k_;
+    cc_policy_obs prev_{};
+    int win_cfg_ = 0, rcur_ = 0, batch_windows_ = 2, prune_hold_ = 0, stalled_ = 0;
+    bool la_on_ = false, nodirty_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
+};
+
+}  // namespace cc

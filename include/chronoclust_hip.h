@@ -290,6 +290,53 @@ int cc_sync(cc_handle* h);
 
 int cc_get_stats(cc_handle* h, cc_stats* out);
 
+/* The window policy of the exact online phase as a pure function (csrc/cc_policy.h; no reference counterpart): between
+ * two batches of windows the library reads the device's counters and decides window size, validation rounds, windows per
+ * batch, lookahead / dirty / pruned scans and the split over the ranks of a group.  No decision can change a result, but
+ * the ranks of a group must all take the same ones, so they depend on the counters alone.  cc_policy_replay runs the
+ * policy over recorded observations - no handle, no GPU: out[0] is the decision for the first batch of a call that
+ * starts at (start_cursor, start_rows), out[i + 1] the one taken after obs[i] (obs[i].after_sequential != 0: the stream
+ * came back from the sequential kernel at obs[i].cursor / m_rows instead of finishing a batch).  *carry is updated to
+ * what the handle would keep for its next call.  CHRONOCLUST_HIP_POLICY_TRACE=<file> makes the library append the
+ * observations and decisions of every call as JSON lines (how the traces under tests/golden/policy/ were recorded). */
+#define CC_POLICY_MAX_ROUNDS 8
+typedef struct cc_policy_config {
+    int32_t window, rounds_max, windows_per_sync, early_window;  /* cc_tuning values in force                        */
+    int32_t lookahead;         /* cc_tuning.lookahead                                                              */
+    int32_t allow_nodirty;     /* dirty scans may be left out while ruled out (CHRONOCLUST_HIP_NODIRTY != 0)       */
+    int32_t prune_mode;        /* CHRONOCLUST_HIP_PRUNE: 0 never, 1 while it pays, 2 always                        */
+    int32_t prune_applicable;  /* k = 2^e, pi >= d and d one of the widths the pruned scan is compiled for         */
+    int32_t can_shard;         /* the handle belongs to a group and is not inside a relaxed super-step             */
+    int32_t d;
+    int32_t resume;            /* the call continues a stream this handle was clustering a moment ago              */
+    int32_t pad;
+    int64_t shard_min_row_dims;
+    int64_t n_end;             /* end of the range of points the call clusters                                     */
+} cc_policy_config;
+typedef struct cc_policy_carry {
+    int32_t adapt_win, clean_batches, since_shrink, pad;
+} cc_policy_carry;
+typedef struct cc_policy_obs {   /* cumulative device counters of the call as read back after a batch              */
+    int64_t cursor;
+    int32_t m_rows, stall_b;
+    int64_t stat_windows, stat_truncated, stat_trunc_unknown, stat_tiles, stat_dirty_tiles;
+    int64_t round_hist[CC_POLICY_MAX_ROUNDS + 2];
+    uint64_t prune_rows, prune_full;
+    int32_t after_sequential, pad;
+} cc_policy_obs;
+typedef struct cc_policy_decision {
+    int32_t win_cfg;        /* window size of the next batch (changes only with `restart`)                         */
+    int32_t want;           /* the size the policy is heading for                                                  */
+    int32_t rounds, batch_windows, lookahead, nodirty, prune, shard;
+    int32_t restart;        /* the chain of windows restarts: pending lookahead scan dropped, control block pushed */
+    int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
+    int32_t stalled;        /* three batches without progress: the call fails with CC_ERR_INTERNAL                 */
+    int32_t pad;
+    int64_t wins, pts, trunc, unk, tiles, dtiles, grew, prune_rows, prune_full;  /* what the batch did (deltas)     */
+} cc_policy_decision;
+int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,
+                     const cc_policy_obs* obs, int32_t n, cc_policy_decision* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,9 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     (plain gcc: the header is C) prints sizeof and the offset of every member; the ctypes mirrors must say the same."""
     import subprocess
     pairs = [("cc_params", _lib.CcParams), ("cc_tuning", _lib.CcTuning), ("cc_stats", _lib.CcStats),
-             ("cc_relaxed_stats", _lib.CcRelaxedStats)]
+             ("cc_relaxed_stats", _lib.CcRelaxedStats), ("cc_policy_config", _lib.CcPolicyConfig),
+             ("cc_policy_carry", _lib.CcPolicyCarry), ("cc_policy_obs", _lib.CcPolicyObs),
+             ("cc_policy_decision", _lib.CcPolicyDecision)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "chronoclust_hip.h"', 'int main(void) {']
     for cname, ctype in pairs:
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

