@@ -134,6 +134,8 @@ struct cc_handle {
     int prune_rounds4 = 8;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS)
     DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range (two window parities)
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
+    DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
+    DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
     size_t spart_stride = 0, thr_stride = 0;
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
@@ -428,6 +430,8 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->thr_stride = w * 2;
     h->spart.ensure(2 * h->spart_stride);
     h->thr.ensure(2 * h->thr_stride);
+    h->thr32.ensure(2 * h->thr_stride);
+    h->cmax.ensure(2);
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
@@ -504,17 +508,14 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 if (h->prune_now && shard_world == 1) {
                     // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them
                     ++h->stats.scan_p_launches;
-                    if (h->hc.m_rows > 8192)  // (a large table is dense in six dimensions: seeds from eight)
-                        hipLaunchKernelGGL((k_seed<DP, 8, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
-                                           h->spart.p, round, mode, h->spart_stride);
-                    else
-                        hipLaunchKernelGGL((k_seed<DP, 6, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
-                                           h->spart.p, round, mode, h->spart_stride);
+                    hipLaunchKernelGGL((k_seed<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
+                                       h->spart.p, round, mode, h->spart_stride, h->cmax.p);
                     hipLaunchKernelGGL(k_seed_merge, dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
-                                       rows.scl, h->spart.p, h->spart_stride, S * NW, h->thr.p, h->thr_stride, h->prune_F,
-                                       round, mode);
-                    hipLaunchKernelGGL((k_scan_p<DP, 8, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
-                                       rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride);
+                                       rows.scl, h->spart.p, h->spart_stride, S * NW, h->thr.p, h->thr32.p, h->thr_stride,
+                                       h->prune_F, round, mode, h->cmax.p);
+                    hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                       rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
+                                       h->part_stride);
                     return;
                 }
             }
@@ -1313,6 +1314,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
 
         // no carry set yet: the commit record of an earlier call describes rows that may have moved since
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
+        HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);

@@ -1029,14 +1029,16 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
 // distance of the point's nearest microcluster, almost every row drops out after four or eight dimensions - for all 64
 // points of a wave at once, because the other microclusters are far from every one of them (the test is wave-uniform:
 // a row is abandoned when ALL lanes are over their thresholds; otherwise its distance is completed for all lanes).
-//   k_seed        per point and kind the row with the smallest UNSCALED squared distance over the first PRE
-//                 dimensions (a heuristic: nothing downstream relies on it being the nearest), per wave sub-range.
-//                 It has to be the point's nearest microcluster almost always, though: one lane with a far seed keeps
-//                 its whole wave evaluating every row in full - hence six or eight dimensions, not four (in four, 1 %
-//                 of the C2 points have another of the 5 000 microclusters closer than their own)
-//   k_seed_merge  per point and kind: the three best of those, their exact distances, T = F x the smallest
-//   k_scan_p      k_scan_u's row loop with the abandon test after dimensions 4, 8, 16, 24, ...; per kind it keeps the
-//                 two best EVALUATED rows and the smallest partial sum at which a row was abandoned (> T).  What leaves
+//   k_seed        per point and kind the row with the smallest UNSCALED squared distance over the first eight
+//                 dimensions, in single precision (a heuristic: nothing downstream relies on it being the nearest), per
+//                 wave sub-range.  It has to be the point's nearest microcluster almost always, though: one lane with a
+//                 far seed keeps its whole wave evaluating every row in full - hence eight dimensions, not four (in
+//                 four, 1 % of the C2 points have another of the 5 000 microclusters closer than their own)
+//   k_seed_merge  per point and kind: the three best of those, their exact distances, T = F x the smallest, and the
+//                 single-precision threshold T32 that goes with it (see there)
+//   k_scan_p      per tile of 16 rows: phase A abandons rows on an eight-dimension single-precision prefix sum, phase B
+//                 completes the others in double precision with the abandon test every eight dimensions; per kind it keeps
+//                 the two best EVALUATED rows and a lower bound (> = T) for every abandoned row's distance.  What leaves
 //                 the kernel per kind is a pair (best, second) in which `second` may be a BOUND (CC_SLOT_BOUND): the
 //                 best is exact whenever it is <= T (the seed row always is evaluated), the second is exact when it is
 //                 smaller than every abandoned partial sum, else all that is known of the other rows is that none is
@@ -1074,12 +1076,49 @@ __device__ __forceinline__ ScanWin cc_scan_window(const Ctl* __restrict__ ctl, i
     return w;
 }
 
-template <int DP, int PRE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
-                                                  const double* __restrict__ g_cen, const int* __restrict__ g_kind,
-                                                  SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride)
+// single-precision pairs: the prefix arithmetic of k_seed and of k_scan_p's phase A runs on packed FP32 instructions
+typedef float cc_f2 __attribute__((ext_vector_type(2)));
+typedef float cc_f4 __attribute__((ext_vector_type(4)));
+#define CC_PRE 8  // dimensions of the prefix (k_seed's score, phase A's bound): 8 floats = two 16-byte LDS reads per row
+
+// the wave's tile of 16 row prefixes, converted to single precision and staged in LDS: tile[m * 8 + i]
+// (lane + 64 q = 8 m + i); returns the largest |coordinate| this lane saw
+template <int DP>
+__device__ __forceinline__ void cc_load_prefix(const double* __restrict__ g_cen, const int* __restrict__ g_kind, int rt,
+                                               int tm, int lane, double (&tc)[2], int& kd)
 {
-    static_assert(PRE <= DP && PRE % 2 == 0, "prefix dimensions");
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + q * 64, m = e >> 3, i = e & 7;
+        tc[q] = (m < tm) ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;
+    }
+    kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+}
+
+// sum over the prefix of (p - c)^2 in single precision, two dimensions per instruction
+__device__ __forceinline__ float cc_prefix_score(const cc_f2 (&p2)[CC_PRE / 2], const cc_f4* __restrict__ row)
+{
+    const cc_f4 c01 = row[0], c23 = row[1];
+    cc_f2 x0 = p2[0] - cc_f2{c01.x, c01.y};
+    cc_f2 x1 = p2[1] - cc_f2{c01.z, c01.w};
+    cc_f2 x2 = p2[2] - cc_f2{c23.x, c23.y};
+    cc_f2 x3 = p2[3] - cc_f2{c23.z, c23.w};
+    cc_f2 acc = x0 * x0;
+    acc = __builtin_elementwise_fma(x1, x1, acc);
+    acc = __builtin_elementwise_fma(x2, x2, acc);
+    acc = __builtin_elementwise_fma(x3, x3, acc);
+    return acc.x + acc.y;
+}
+
+// cmax[q] (bits of a double): the largest |centroid coordinate| among the prefixes of the scanned rows, left by the
+// workgroups of the window's first point tile (every row is in exactly one of their waves' sub-ranges)
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 8) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                  const double* __restrict__ g_cen, const int* __restrict__ g_kind,
+                                                  SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride,
+                                                  unsigned long long* __restrict__ cmax)
+{
+    static_assert(CC_PRE <= DP, "prefix dimensions");
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
@@ -1097,77 +1136,90 @@ __global__ __launch_bounds__(64 * NW) void k_seed(const Ctl* __restrict__ ctl, c
     const size_t n_pts = (size_t)ctl->xt_stride;
     const int jj = j0 + lane;
     const bool valid = jj < B;
-    double p[PRE];
+    cc_f2 p2[CC_PRE / 2];
     {
         const double* xp = Xt + win.cursor + (valid ? jj : 0);
 #pragma unroll
-        for (int i = 0; i < PRE; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+        for (int i = 0; i < CC_PRE / 2; ++i)
+            p2[i] = cc_f2{valid ? (float)xp[(size_t)(2 * i) * n_pts] : 0.f, valid ? (float)xp[(size_t)(2 * i + 1) * n_pts] : 0.f};
     }
     // per wave: the prefixes of a tile of 16 rows in LDS (the wave is the only reader and writer of its tile), read
     // back as wave-uniform broadcasts; the next tile's values are requested before the row loop of the current one
-    constexpr int NLP = (CC_SCAN_TM * PRE + 63) / 64;
-    __shared__ __attribute__((aligned(16))) double s_pre[NW * NLP * 64];
-    double* const tile = s_pre + (size_t)wv * NLP * 64;
-    typedef double cc_d2 __attribute__((ext_vector_type(2)));
-    auto load_tile = [&](int rt, double (&tc)[NLP], int& kd) {
-        const int tm = min(CC_SCAN_TM, r1 - rt);
-#pragma unroll
-        for (int q = 0; q < NLP; ++q) {
-            const int e = lane + q * 64, m = e / PRE, i = e - m * PRE;
-            tc[q] = (m < tm) ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;  // (m < 16 follows: tm <= 16)
-        }
-        kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
-    };
-    double best[2] = {CC_INF, CC_INF};
+    __shared__ __attribute__((aligned(16))) float s_pre[NW * CC_SCAN_TM * CC_PRE];
+    float* const tile = s_pre + (size_t)wv * CC_SCAN_TM * CC_PRE;
+    float best[2] = {__builtin_inff(), __builtin_inff()};
     int idx[2] = {-1, -1};
-    double tc[NLP];
+    double tc[2];
     int kdl = CC_KIND_DEAD;
-    if (r0 < r1) load_tile(r0, tc, kdl);
+    double cm = 0.0;
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
     for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
         const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
         CC_WAVE_SYNC();
 #pragma unroll
-        for (int q = 0; q < NLP; ++q) tile[lane + q * 64] = tc[q];
+        for (int q = 0; q < 2; ++q) {
+            tile[lane + q * 64] = (float)tc[q];
+            cm = __builtin_fmax(cm, __builtin_fabs(tc[q]));
+        }
         const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
         const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
         CC_WAVE_SYNC();
-        if (rt + CC_SCAN_TM < r1) load_tile(rt + CC_SCAN_TM, tc, kdl);
-        const cc_d2* t2 = reinterpret_cast<const cc_d2*>(__builtin_assume_aligned(tile, 16));
-        for (int m = 0; m < tm; ++m) {
-            const int rowg = rt + m;
-            double acc = 0.0;
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
+        auto update = [&](auto KC, float acc, int rowg) {
+            constexpr int K = decltype(KC)::value;
+            const bool lt = acc < best[K];  // strict: the first row in scan order keeps a tie (deterministic)
+            best[K] = lt ? acc : best[K];
+            idx[K] = lt ? rowg : idx[K];
+        };
+        // a tile of one kind (the usual case): four rows at a time - their LDS reads and sums are independent, only the
+        // running minimum is a chain; a mixed tile row by row
+        auto rows_of_kind = [&](auto KC) {
+            int m = 0;
+            for (; m + 4 <= tm; m += 4) {
+                float a[4];
 #pragma unroll
-            for (int h2 = 0; h2 < PRE / 2; ++h2) {
-                const cc_d2 c = t2[m * (PRE / 2) + h2];
-                const double x = p[2 * h2] - c.x, y = p[2 * h2 + 1] - c.y;
-                acc = (h2 == 0) ? x * x : __builtin_fma(x, x, acc);  // (a heuristic score: contraction is welcome)
-                acc = __builtin_fma(y, y, acc);
+                for (int u = 0; u < 4; ++u) a[u] = cc_prefix_score(p2, t4 + (m + u) * 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) update(KC, a[u], rt + m + u);
             }
-            auto update = [&](auto KC) {
-                constexpr int K = decltype(KC)::value;
-                const bool lt = acc < best[K];  // strict: the first row in scan order keeps a tie (deterministic)
-                best[K] = lt ? acc : best[K];
-                idx[K] = lt ? rowg : idx[K];
-            };
-            if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
-            else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
-        }
+            for (; m < tm; ++m) update(KC, cc_prefix_score(p2, t4 + m * 2), rt + m);
+        };
+        const unsigned full = (1u << tm) - 1u;
+        if (pmask == full) rows_of_kind(std::integral_constant<int, 0>{});
+        else if (omask == full) rows_of_kind(std::integral_constant<int, 1>{});
+        else
+            for (int m = 0; m < tm; ++m) {
+                const float acc = cc_prefix_score(p2, t4 + m * 2);
+                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{}, acc, rt + m);
+                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{}, acc, rt + m);
+            }
+    }
+    if (blockIdx.x == 0) {
+        for (int off = 32; off >= 1; off >>= 1) cm = __builtin_fmax(cm, __shfl_xor(cm, off));
+        if (lane == 0) atomicMax(cmax + win.q, (unsigned long long)__double_as_longlong(cm));  // (>= 0: bits order like values)
     }
     // every wave leaves its own winners: S x NW entries per point and kind for k_seed_merge to choose from
     if (!valid) return;
     SeedCand* o = spart + ((size_t)jj * nsub + sub) * 2;
-    o[0] = SeedCand{best[0], idx[0], 0};
-    o[1] = SeedCand{best[1], idx[1], 0};
+    o[0] = SeedCand{(double)best[0], idx[0], 0};
+    o[1] = SeedCand{(double)best[1], idx[1], 0};
 }
 
-// per point and kind (one thread each): the three best prefix scores of the S sub-ranges -> their exact distances (the
+// per point and kind (one thread each): the three best prefix scores of the sub-ranges -> their exact distances (the
 // scans' own operations, in their order; the three sums advance together) -> T = F x the smallest; +inf when the kind
-// has no row.
+// has no row.  And T32, the threshold phase A's SINGLE-PRECISION prefix sum is compared with.  Phase A abandons a row when
+//     Qf = smin * sum_{i < 8} fl32(fl32(p_i) - fl32(c_i))^2     exceeds T32,
+// and that must imply that the row's exact partial sum P = sum_i s_i (p_i - c_i)^2 (s_i = 1 or 1/k) exceeds T.  With
+// e = 2^-21 max(|p|, |c|) (twice the bound 2^-24 (|p_i| + |c_i| + |x_i|) on the error of a difference x_i),
+//     P >= sum s_i (|x_i| - e)^2 >= Q - 2 e sum s_i |x_i| >= Q - a sqrt(Q),   a = 2 e sqrt(8 smax),  Q = sum s_i x_i^2 >= smin sum x_i^2
+// (Cauchy-Schwarz), g(Q) = Q - a sqrt(Q) grows for sqrt(Q) > a / 2, so P > T follows from sqrt(Q) > u = (a + sqrt(a^2 + 4 T)) / 2.
+// The nine roundings of Qf (relative 2^-24 each, all terms >= 0) are covered by the factor 1 + 2^-19; T32 is rounded up.
 __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, const double* __restrict__ X,
                                                    const double* __restrict__ g_cen, const double* __restrict__ g_scl,
                                                    const SeedCand* __restrict__ spart, size_t spart_stride, int S,
-                                                   double* __restrict__ thr, size_t thr_stride, double F, int round,
-                                                   int mode)
+                                                   double* __restrict__ thr, float* __restrict__ thr32, size_t thr_stride,
+                                                   double F, int round, int mode, const unsigned long long* __restrict__ cmax)
 {
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1176,6 +1228,7 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
     const int d = ctl->d;
     spart += (size_t)win.q * spart_stride;
     thr += (size_t)win.q * thr_stride;
+    thr32 += (size_t)win.q * thr_stride;
     const double* p = X + (size_t)(win.cursor + j) * d;
     double b0 = CC_INF, b1 = CC_INF, b2 = CC_INF;
     int i0 = -1, i1 = -1, i2 = -1;
@@ -1204,28 +1257,44 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
         out = F * dmin;
     }
     thr[(size_t)j * 2 + K] = out;
+    float t32 = __builtin_inff();
+    if (out < CC_INF) {
+        double pm = 0.0;
+        for (int i = 0; i < CC_PRE; ++i) pm = __builtin_fmax(pm, __builtin_fabs(p[i]));
+        const double cmx = __longlong_as_double((long long)cmax[win.q]);
+        const double e = 0x1p-21 * __builtin_fmax(pm, cmx);
+        const double inv_k = ctl->inv_k;
+        const double smax = inv_k > 1.0 ? inv_k : 1.0, smin = inv_k < 1.0 ? inv_k : 1.0;
+        const double a = 2.0 * e * sqrt(8.0 * smax);
+        const double u = 0.5 * (a + sqrt(a * a + 4.0 * out)) * (1.0 + 0x1p-40);
+        // the kernel compares sum x^2 (without smin) with T32 = u^2 (1 + 2^-19) / smin
+        const double t64 = u * u * (1.0 + 0x1p-19) / smin * (1.0 + 0x1p-40);
+        t32 = (float)t64;
+        if ((double)t32 < t64) t32 = __uint_as_float(__float_as_uint(t32) + 1u);  // (t32 >= 0 and finite here: the next float up)
+    }
+    thr32[(size_t)j * 2 + K] = t32;
 }
 
 // Per wave and tile of 16 rows two phases:
-//   A  every row, straight-line: the partial sum over the first PA dimensions (mc_functions.py:37-41, the scans' own
-//      operations in their order), the wave-uniform test "some lane within its threshold", one bit per row; a row that
-//      no lane keeps only leaves its partial sum in the kind's bound.  Only the first PA dimensions of the tile's rows
-//      are fetched (centroid and distance operand: 2 x 16 x PA doubles, coalesced, staged in the wave's LDS tile and read
-//      back as wave-uniform broadcasts; the next tile's loads are in flight during the row loop of the current one) -
-//      the whole rows, as k_scan stages them, would be five times the bytes at d = 20 for 3 % of the rows, and the same
-//      lines are wanted by every point tile's workgroup at the same moment.  When every row of the tile is preferred
-//      in all of these dimensions (the usual case) the operand is the constant 1/k and the phase needs no scalar selects.
+//   A  every row, straight-line, in SINGLE precision: the sum over the first eight dimensions of (p - c)^2 (packed FP32
+//      instructions: 4 subtractions, 4 multiply-adds and an add per row) against the lane's threshold T32 (k_seed_merge:
+//      exceeding it implies that the row's exact partial sum exceeds T, whatever the row's preferred dimensions are),
+//      the wave-uniform test "some lane within its threshold", one bit per row; a row that no lane keeps leaves T in the
+//      kind's bound.  Only the first eight dimensions of the tile's rows are fetched (16 x 8 doubles, coalesced,
+//      converted and staged in the wave's LDS tile, read back as wave-uniform broadcasts; the next tile's loads are in
+//      flight during the row loop of the current one) - whole rows, as k_scan stages them, would be five times the bytes
+//      at d = 20 for 2 % of the rows, and the same lines are wanted by every point tile's workgroup at the same moment.
 //   B  the rows phase A kept (few): the whole distance from its first dimension with the reference's four operations
-//      per term (sub, square, scale, add - no fusion, so no CC_TINY condition to check), centroid and operand as scalar
-//      loads of eight dimensions at a time, the same test every eight dimensions beyond PA, then the best-two update of
-//      k_scan_u.
-template <int DP, int PA, int NW>
+//      per term in double precision (sub, square, scale, add - no fusion, so no CC_TINY condition to check), centroid
+//      and operand as scalar loads of eight dimensions at a time, the abandon test (now exact: partial sum against T)
+//      every eight dimensions, then the best-two update of k_scan_u.
+template <int DP, int NW>
 __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void k_scan_p(
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
-    const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr, size_t thr_stride,
-    Cand* __restrict__ part, int round, int mode, size_t part_stride)
+    const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
+    const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride)
 {
-    static_assert(DP % 2 == 0 && DP > 8 && DP <= 64 && PA == 8 && PA < DP, "k_scan_p shapes");
+    static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
@@ -1233,6 +1302,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
     if (j0 >= B) return;
     part += (size_t)win.q * part_stride;
     thr += (size_t)win.q * thr_stride;
+    thr32 += (size_t)win.q * thr_stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = gridDim.y;
@@ -1242,16 +1312,13 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
     const int r0 = sub * per;
     const int r1 = min(win.rows, r0 + per);
     const size_t n_pts = (size_t)ctl->xt_stride;
-    const double k = ctl->k;
-    const double inv_k = ctl->inv_k;
     const int jj = j0 + lane;
     const bool valid = jj < B;
 
-    constexpr int TILE_BYTES = NW * CC_SCAN_TM * PA * 8;
+    constexpr int TILE_BYTES = NW * CC_SCAN_TM * CC_PRE * 4;
     constexpr int MERGE_BYTES = (NW - 1) * 4 * 64 * (int)sizeof(Cand);
     __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
-    double* const tile = reinterpret_cast<double*>(smem) + (size_t)wv * CC_SCAN_TM * PA;
-    typedef double cc_d2 __attribute__((ext_vector_type(2)));
+    float* const tile = reinterpret_cast<float*>(smem) + (size_t)wv * CC_SCAN_TM * CC_PRE;
 
     double p[DP];
     {
@@ -1259,17 +1326,19 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
 #pragma unroll
         for (int i = 0; i < DP; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
     }
-    bool fuse_wave = k >= 0x1p-64 && k <= 0x1p64;
-    {
-        bool tn = false;
+    cc_f2 p2[CC_PRE / 2];
 #pragma unroll
-        for (int i = 0; i < PA; ++i) tn = tn || cc_is_tiny(p[i]);  // (phase A is the only fused arithmetic here)
-        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
-    }
-    // thresholds and the smallest abandoned partial sum, per kind; lanes without a point keep no row alive
+    for (int i = 0; i < CC_PRE / 2; ++i) p2[i] = cc_f2{(float)p[2 * i], (float)p[2 * i + 1]};
+    // thresholds (exact: th, single-precision prefix: th32) and the bound of what was abandoned, per kind; lanes without
+    // a point keep no row alive
     double th[2], lb[2] = {CC_INF, CC_INF};
-    th[0] = valid ? thr[(size_t)jj * 2 + 0] : -CC_INF;
-    th[1] = valid ? thr[(size_t)jj * 2 + 1] : -CC_INF;
+    float th32[2];
+#pragma unroll
+    for (int K = 0; K < 2; ++K) {
+        th[K] = valid ? thr[(size_t)jj * 2 + K] : -CC_INF;
+        th32[K] = valid ? thr32[(size_t)jj * 2 + K] : -__builtin_inff();
+    }
+    bool dropped[2] = {false, false};  // (wave-uniform) phase A abandoned a row of the kind: every lane's bound is its T
     double bd[2][2];
     int bs[2][2];
 #pragma unroll
@@ -1281,108 +1350,57 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
         }
     int n_rows = 0, n_full = 0;  // statistics (wave-uniform)
 
-    constexpr int NLP = CC_SCAN_TM * PA / 64;  // 2: lane + 64 q = 8 m + i
-    double tc[NLP], ts[NLP];
+    double tc[2];
     int kdl = CC_KIND_DEAD;
-    auto load_tile = [&](int rt) {
-        const int tm = min(CC_SCAN_TM, r1 - rt);
-#pragma unroll
-        for (int q = 0; q < NLP; ++q) {
-            const int e = lane + q * 64, m = e / PA, i = e - m * PA;
-            const bool in = m < tm;
-            tc[q] = in ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;
-            ts[q] = in ? g_scl[(size_t)(rt + m) * DP + i] : 1.0;
-        }
-        kdl = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
-    };
-    if (r0 < r1) load_tile(r0);
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
     for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
         const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
         CC_WAVE_SYNC();
-        unsigned long long wmask[NLP];  // bit 8 m' + i of word q: row 8 q + m' is scaled by 1/k in dimension i
-        bool tn = false, any_one = false;
 #pragma unroll
-        for (int q = 0; q < NLP; ++q) {
-            const int e = lane + q * 64;
-            tile[e] = tc[q];
-            tn = tn || cc_is_tiny(tc[q]);
-            wmask[q] = __builtin_amdgcn_ballot_w64(ts[q] != 1.0);
-            any_one = any_one || (e / PA < tm && ts[q] == 1.0);
-        }
-        const bool fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
-        const bool uni = __builtin_amdgcn_ballot_w64(any_one) == 0ull;  // all rows preferred in all of the first PA dimensions
+        for (int q = 0; q < 2; ++q) tile[lane + q * 64] = (float)tc[q];
         const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
         const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
         CC_WAVE_SYNC();
-        if (rt + CC_SCAN_TM < r1) load_tile(rt + CC_SCAN_TM);  // in flight during the row loops below
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
         n_rows += tm;
-        const cc_d2* t2 = reinterpret_cast<const cc_d2*>(__builtin_assume_aligned(tile, 16));
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
         const unsigned full = (1u << tm) - 1u;
-        const double one = 1.0;
 
         // ---- phase A ----
         unsigned surv = 0u;
-        auto phase_a = [&](auto UNIC, auto FUSEC, auto KSELC) {
-            constexpr bool UNI = decltype(UNIC)::value;
-            constexpr bool FUSE = decltype(FUSEC)::value;
+        auto verdict = [&](auto KSELC, int m, float q) {
             constexpr int KSEL = decltype(KSELC)::value;
-            for (int m = 0; m < tm; ++m) {
-                const cc_d2* r2 = t2 + m * (PA / 2);
-                unsigned mlo = 0u;
-                if constexpr (!UNI) mlo = (unsigned)((m < 8 ? wmask[0] : wmask[NLP - 1]) >> ((m & 7) * 8)) & 0xFFu;
-                double acc = 0.0;
-#ifdef CC_DBG_NO_PHASE_A_MATH
-                acc = 1e30 + (double)m;
-                if (false)
-#endif
-                cc_static_for<PA / 2>([&](auto QC) {
-                    constexpr int i = 2 * decltype(QC)::value;
-                    const cc_d2 c = r2[i / 2];
-                    double s0 = inv_k, s1 = inv_k;
-                    if constexpr (!UNI) cc_sel_scale2<i>(mlo, inv_k, one, s0, s1);
-                    double x = p[i] - c.x;
-                    double y = p[i + 1] - c.y;
-                    x = x * x;
-                    y = y * y;
-                    if (FUSE) {
-                        acc = (i == 0) ? x * s0 : __builtin_fma(x, s0, acc);  // :39 + :41 in one rounding, see CC_TINY
-                        acc = __builtin_fma(y, s1, acc);
-                    } else {
-                        x = x * s0;
-                        y = y * s1;
-                        acc = (i == 0) ? x : acc + x;
-                        acc = acc + y;
-                    }
-                });
-                const bool is_p = KSEL == 0 || (KSEL < 0 && ((pmask >> m) & 1u) != 0u);
-                if (is_p) {
-                    if (__builtin_amdgcn_ballot_w64(acc <= th[0]) != 0ull) surv |= 1u << m;
-                    else lb[0] = cc_vmin(lb[0], acc);
-                } else {
-                    if (__builtin_amdgcn_ballot_w64(acc <= th[1]) != 0ull) surv |= 1u << m;
-                    else lb[1] = cc_vmin(lb[1], acc);
-                }
+            const bool is_p = KSEL == 0 || (KSEL < 0 && ((pmask >> m) & 1u) != 0u);
+            if (is_p) {
+                if (__builtin_amdgcn_ballot_w64(q <= th32[0]) != 0ull) surv |= 1u << m;
+                else dropped[0] = true;
+            } else {
+                if (__builtin_amdgcn_ballot_w64(q <= th32[1]) != 0ull) surv |= 1u << m;
+                else dropped[1] = true;
             }
         };
-        auto phase_a_k = [&](auto UNIC, auto FUSEC) {
-            if (pmask == full) phase_a(UNIC, FUSEC, std::integral_constant<int, 0>{});
-            else if (omask == full) phase_a(UNIC, FUSEC, std::integral_constant<int, 1>{});
-            else phase_a(UNIC, FUSEC, std::integral_constant<int, -1>{});
+        auto phase_a = [&](auto KSELC) {
+            int m = 0;
+            for (; m + 4 <= tm; m += 4) {
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = cc_prefix_score(p2, t4 + (m + u) * 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) verdict(KSELC, m + u, a[u]);
+            }
+            for (; m < tm; ++m) verdict(KSELC, m, cc_prefix_score(p2, t4 + m * 2));
         };
-        if (fuse_tile) {
-            if (uni) phase_a_k(std::true_type{}, std::true_type{});
-            else phase_a_k(std::false_type{}, std::true_type{});
-        } else phase_a(std::false_type{}, std::false_type{}, std::integral_constant<int, -1>{});
+        if (pmask == full) phase_a(std::integral_constant<int, 0>{});
+        else if (omask == full) phase_a(std::integral_constant<int, 1>{});
+        else phase_a(std::integral_constant<int, -1>{});
 
         // ---- phase B: the rows that stayed ----
-#ifdef CC_DBG_NO_PHASE_B
-        surv = 0u;
-#endif
         while (surv != 0u) {
             const int m = __builtin_ctz(surv);
             surv &= surv - 1u;
             const int rowg = rt + m;
             const bool is_p = ((pmask >> m) & 1u) != 0u;
+            if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
             const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
             const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
             double acc = 0.0;
@@ -1403,7 +1421,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
                     x = x * sc[i];                         // :39 (the divisor is a power of two)
                     acc = (lo + i == 0) ? x : acc + x;     // :41
                 }
-                if constexpr (hi < DP && hi > PA) {
+                if constexpr (hi < DP) {
+                    // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
                     if (is_p) {
                         if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
                     } else {
@@ -1438,9 +1457,13 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
                 s0 = first ? rowg : s0;
             };
             if (is_p) update(std::integral_constant<int, 0>{});
-            else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+            else update(std::integral_constant<int, 1>{});
         }
     }
+    // rows abandoned in phase A: their exact partial sums exceed every lane's T (k_seed_merge), which is all that is
+    // recorded of them
+    if (dropped[0]) lb[0] = cc_vmin(lb[0], th[0]);
+    if (dropped[1]) lb[1] = cc_vmin(lb[1], th[1]);
     // statistics for the host's policy: a sample - the waves of the window's first point tile (atomics of every wave on
     // one address serialise: 30 000 of them cost more than the scan)
     if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
@@ -1457,8 +1480,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
         for (int r = 0; r < 2; ++r) bk[kd][r] = bs[kd][r] >= 0 ? g_key[bs[kd][r]] : CC_IDX_INF;
     Cand c0{bd[0][0], bk[0][0], bs[0][0]}, c1{bd[0][1], bk[0][1], bs[0][1]};
     Cand c2{bd[1][0], bk[1][0], bs[1][0]}, c3{bd[1][1], bk[1][1], bs[1][1]};
-    cc_top2_push(c0, c1, Cand{lb[0], -1, lb[0] < CC_INF ? CC_SLOT_BOUND : -1});
-    cc_top2_push(c2, c3, Cand{lb[1], -1, lb[1] < CC_INF ? CC_SLOT_BOUND : -1});
+    cc_top2_push(c0, c1, Cand{lb[0], -1, (valid && lb[0] < CC_INF) ? CC_SLOT_BOUND : -1});
+    cc_top2_push(c2, c3, Cand{lb[1], -1, (valid && lb[1] < CC_INF) ? CC_SLOT_BOUND : -1});
     Cand* s_m = reinterpret_cast<Cand*>(smem);
     auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 4 + c) * 64 + lane]; };
     __syncthreads();  // every wave is done with its tile: the same bytes now carry the candidate exchange
