@@ -213,11 +213,26 @@ def scan_roofline(acc, d, kernel):
     return {"bound": "fp64_valu", "kernel": kernel, "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
             "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
             "launches": int(acc["scan_launches"]), "avg_launch_us": 1e3 * acc["scan_ms"] / acc["scan_launches"],
-            "pair_dims_per_launch": acc["scan_pair_dims"] / acc["scan_launches"], "instr_per_pair_dim": 3.0}
+            "pair_dims_per_launch": acc["scan_pair_dims"] / acc["scan_launches"], "instr_per_pair_dim": 3.0,
+            "pruning": prune_note(acc)}
 
 
 def scan_kernel_name(s, d):
+    if s.get("scan_p_launches", 0) > 0:
+        return "k_seed<%d, 4> + k_seed_merge + k_scan_p<%d, 4> (pruned) / k_scan_u<%d, 4>" % (d, d, d)
     return ("k_scan_u<%d, 4>" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<%d, DIRTY=false>" % d
+
+
+def prune_note(acc):
+    """How much of the scans' algorithmic work the pruned launches really executed (sampled by the library)."""
+    if not acc.get("scan_p_launches"):
+        return None
+    return {"pruned_launches": int(acc["scan_p_launches"]), "of_scan_launches": int(acc["scan_u_launches"]),
+            "rows_evaluated_in_full_frac": (acc["pruned_scan_full_rows"] / acc["pruned_scan_rows"]) if acc["pruned_scan_rows"] else None,
+            "note": "`achieved` counts the ALGORITHMIC 3 fp64 instructions per (point, microcluster, dim); a pruned launch "
+                    "(k_seed -> k_seed_merge -> k_scan_p, timed as one) abandons a row as soon as its partial sum provably "
+                    "exceeds the point's threshold and evaluates only this fraction of the (wave, row) pairs over all "
+                    "dimensions - exactly (same labels, same tables): frac may exceed what an every-pair scan can reach"}
 
 
 def join_group(h, rank, world, group):
@@ -257,7 +272,8 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
         step()
     sync(h)
     t0 = time.perf_counter()
-    acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0)
+    acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0,
+               scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0)
     for _ in range(args.stream_steps):
         s, n_clusters = step()
         for k in acc:
@@ -336,7 +352,8 @@ def relaxed_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label
         step()
     sync(h)
     t0 = time.perf_counter()
-    acc = dict(scan_ms=0.0, scan_launches=0, scan_pair_dims=0.0)
+    acc = dict(scan_ms=0.0, scan_launches=0, scan_pair_dims=0.0, scan_p_launches=0, scan_u_launches=0,
+               pruned_scan_rows=0, pruned_scan_full_rows=0)
     for _ in range(args.stream_steps):
         s, arrays = step()
         for k in acc:
@@ -478,8 +495,11 @@ def main():
     scan_ms = scan_launches = 0.0
     pair_dims = table_rows = 0.0
     online_ms = 0.0
+    pacc = dict(scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0)
     for _ in range(args.steps):
         s, n_clusters = step()
+        for k in pacc:
+            pacc[k] += s[k]
         scan_ms += s["scan_ms"]
         scan_launches += s["scan_launches"]
         pair_dims += s["scan_pair_dims"]
@@ -533,6 +553,7 @@ def main():
                 "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
                 "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
                 "instr_per_pair_dim": 3.0, "pair_dims_per_launch": pair_dims / scan_launches,
+                "pruning": prune_note(pacc),
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
                         "note": "algorithmic bytes: the window's points (8d + 4 label bytes each) + the table columns "

@@ -132,7 +132,7 @@ struct cc_handle {
     double prune_F = 16.0;
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
     int prune_rounds4 = 8;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS)
-    DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range (two window parities)
+    DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range and kind (two window parities)
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
@@ -426,7 +426,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->v_tgt.ensure(w);
     h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2); h->v_unsafe.ensure(w);
     h->part_stride = w * seg * 4;
-    h->spart_stride = w * seg * 4 * 2;  // (entries per wave: seg workgroups x 4 waves)
+    h->spart_stride = w * seg * 2;
     h->thr_stride = w * 2;
     h->spart.ensure(2 * h->spart_stride);
     h->thr.ensure(2 * h->thr_stride);
@@ -511,7 +511,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                     hipLaunchKernelGGL((k_seed<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
                                        h->spart.p, round, mode, h->spart_stride, h->cmax.p);
                     hipLaunchKernelGGL(k_seed_merge, dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
-                                       rows.scl, h->spart.p, h->spart_stride, S * NW, h->thr.p, h->thr32.p, h->thr_stride,
+                                       rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
                                        h->prune_F, round, mode, h->cmax.p);
                     hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                        rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,

@@ -1048,10 +1048,9 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
 // microcluster whose live version is four times as far (in distance units) as the seed was.
 // ---------------------------------------------------------------------------------
 
-struct __attribute__((aligned(16))) SeedCand {
-    double part;  // unscaled squared distance over the first PRE dimensions
+struct __attribute__((aligned(8))) SeedCand {
+    float part;   // unscaled squared distance over the first eight dimensions (single precision)
     int row;      // -1: none
-    int pad;
 };
 
 // the window a snapshot scan works on: mode 0 = the current window (in place), 1 = the lookahead window of parity round & 1
@@ -1199,11 +1198,32 @@ __global__ __launch_bounds__(64 * NW, 8) void k_seed(const Ctl* __restrict__ ctl
         for (int off = 32; off >= 1; off >>= 1) cm = __builtin_fmax(cm, __shfl_xor(cm, off));
         if (lane == 0) atomicMax(cmax + win.q, (unsigned long long)__double_as_longlong(cm));  // (>= 0: bits order like values)
     }
-    // every wave leaves its own winners: S x NW entries per point and kind for k_seed_merge to choose from
-    if (!valid) return;
-    SeedCand* o = spart + ((size_t)jj * nsub + sub) * 2;
-    o[0] = SeedCand{(double)best[0], idx[0], 0};
-    o[1] = SeedCand{(double)best[1], idx[1], 0};
+    // the workgroup's winner per point and kind (the four waves' through LDS, in sub-range order: ties keep the lower
+    // row): S entries per point and kind for k_seed_merge to choose from
+    __shared__ float s_b[(NW > 1 ? NW - 1 : 1) * 2 * 64];
+    __shared__ int s_i[(NW > 1 ? NW - 1 : 1) * 2 * 64];
+    if (wv > 0) {
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            s_b[((wv - 1) * 2 + K) * 64 + lane] = best[K];
+            s_i[((wv - 1) * 2 + K) * 64 + lane] = idx[K];
+        }
+    }
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            const float b = s_b[(w * 2 + K) * 64 + lane];
+            const int ix = s_i[(w * 2 + K) * 64 + lane];
+            const bool lt = ix >= 0 && (idx[K] < 0 || b < best[K]);
+            best[K] = lt ? b : best[K];
+            idx[K] = lt ? ix : idx[K];
+        }
+    SeedCand* o = spart + ((size_t)jj * S + blockIdx.y) * 2;
+    o[0] = SeedCand{best[0], idx[0]};
+    o[1] = SeedCand{best[1], idx[1]};
 }
 
 // per point and kind (one thread each): the three best prefix scores of the sub-ranges -> their exact distances (the
@@ -1230,7 +1250,7 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
     thr += (size_t)win.q * thr_stride;
     thr32 += (size_t)win.q * thr_stride;
     const double* p = X + (size_t)(win.cursor + j) * d;
-    double b0 = CC_INF, b1 = CC_INF, b2 = CC_INF;
+    float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
     int i0 = -1, i1 = -1, i2 = -1;
     for (int s = 0; s < S; ++s) {
         const SeedCand c = spart[((size_t)j * S + s) * 2 + K];
@@ -1368,16 +1388,15 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
 
         // ---- phase A ----
         unsigned surv = 0u;
+        // straight-line: one compare per row, the wave's verdict as one bit (which kinds lost rows follows from the
+        // bits at the end of the tile)
         auto verdict = [&](auto KSELC, int m, float q) {
             constexpr int KSEL = decltype(KSELC)::value;
-            const bool is_p = KSEL == 0 || (KSEL < 0 && ((pmask >> m) & 1u) != 0u);
-            if (is_p) {
-                if (__builtin_amdgcn_ballot_w64(q <= th32[0]) != 0ull) surv |= 1u << m;
-                else dropped[0] = true;
-            } else {
-                if (__builtin_amdgcn_ballot_w64(q <= th32[1]) != 0ull) surv |= 1u << m;
-                else dropped[1] = true;
-            }
+            float t;
+            if constexpr (KSEL == 0) t = th32[0];
+            else if constexpr (KSEL == 1) t = th32[1];
+            else t = ((pmask >> m) & 1u) ? th32[0] : th32[1];
+            surv |= (__builtin_amdgcn_ballot_w64(q <= t) != 0ull) ? (1u << m) : 0u;
         };
         auto phase_a = [&](auto KSELC) {
             int m = 0;
@@ -1393,6 +1412,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void 
         if (pmask == full) phase_a(std::integral_constant<int, 0>{});
         else if (omask == full) phase_a(std::integral_constant<int, 1>{});
         else phase_a(std::integral_constant<int, -1>{});
+        if ((~surv & pmask & full) != 0u) dropped[0] = true;
+        if ((~surv & omask & full) != 0u) dropped[1] = true;
 
         // ---- phase B: the rows that stayed ----
         while (surv != 0u) {

@@ -1,34 +1,51 @@
-"""HBM-side traffic of the snapshot scan (k_scan_u) from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
-`bench.py --steps 1 --warmup 0 --no-cpu-baseline`).  Usage: pmc_summary.py <fetch_dir> <write_dir> <window> > json"""
+"""HBM-side traffic of the snapshot scan from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of
+`bench.py --steps 1 --warmup 0 --no-cpu-baseline`), per scan launch as bench.py counts them: a launch is one k_scan_u /
+clean k_scan dispatch or, when the scan is pruned, the chain k_seed -> k_seed_merge -> k_scan_p.  Records the SHA-256 of the
+kernel sources (bench.csrc_digest): bench.py only quotes the figure for the kernels it was measured on.
+Usage: pmc_summary.py <fetch_dir> <write_dir> <window> > json"""
 import glob
 import json
+import os
 import sys
 
 import pandas as pd
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
 
-def per_launch(d, counter):
+CHAIN = ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<")
+HEADS = ("k_scan_p<", "k_scan_u<")
+
+
+def totals(d, counter):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     df = pd.read_csv(f)
     df = df[df["Counter_Name"] == counter]
-    df = df[df["Kernel_Name"].str.contains("k_scan_u<20, 4>", regex=False)]
-    g = df.groupby("Dispatch_Id")["Counter_Value"].sum()
-    name = df["Kernel_Name"].iloc[0].split("(")[0]
-    # every launch of the kernel, like bench.py's avg_launch_us and algorithmic_bytes_per_launch (lookahead batches
-    # also enqueue the in-place scan, which returns at once when the window was scanned ahead)
-    return float(g.mean()), int(len(g)), name
+    per = {}
+    chains = 0
+    for pat in CHAIN:
+        g = df[df["Kernel_Name"].str.contains(pat, regex=False)].groupby("Dispatch_Id")["Counter_Value"].sum()
+        per[pat.rstrip("<")] = {"dispatches": int(len(g)), "KB_total": float(g.sum())}
+        if pat in HEADS:
+            chains += int(len(g))
+    return per, chains
 
 
 if __name__ == "__main__":
-    fetch_kb, n1, name = per_launch(sys.argv[1], "FETCH_SIZE")
-    write_kb, n2, _ = per_launch(sys.argv[2], "WRITE_SIZE")
-    out = {"points": 1000000, "dim": 20, "window": int(sys.argv[3]), "kernel": name, "launches": n1,
+    fetch, n1 = totals(sys.argv[1], "FETCH_SIZE")
+    write, n2 = totals(sys.argv[2], "WRITE_SIZE")
+    fetch_kb = sum(v["KB_total"] for v in fetch.values()) / max(n1, 1)
+    write_kb = sum(v["KB_total"] for v in write.values()) / max(n2, 1)
+    out = {"points": 1000000, "dim": 20, "window": int(sys.argv[3]), "csrc_sha256": bench.csrc_digest(),
+           "kernel": "snapshot scan: k_seed + k_seed_merge + k_scan_p chains and k_scan_u launches", "launches": n1,
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "k_scan_clean_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+           "per_kernel_FETCH_SIZE": fetch, "per_kernel_WRITE_SIZE": write,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `bench.py --steps 1 --warmup 0`; "
                    "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE reports half of "
                    "a wide coalesced read; narrower accesses are uncalibrated, so this is an upper estimate); includes "
-                   "Infinity-Cache hits; averaged over all launches of the kernel in the run (the start-up phase uses short "
-                   "windows, a few lookahead scans go unused). Most of it is the per-workgroup argmin partials (window x 8..16 x 64 B) that the "
-                   "scan writes and k_decide merges, not input data; scalar-cache fills of the row operands are not in these counters."}
+                   "Infinity-Cache hits; summed over the kernels of a scan launch (pruned: k_seed + k_seed_merge + k_scan_p) "
+                   "and averaged over all scan launches of the run (the start-up phase uses short windows and plain k_scan_u "
+                   "launches). Beyond the algorithmic bytes: the per-sub-range seed winners and candidate partials that "
+                   "the next kernel merges, and the table prefixes every point tile's workgroups re-read from L2."}
     print(json.dumps(out, indent=1))

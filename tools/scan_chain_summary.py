@@ -1,0 +1,39 @@
+"""The snapshot scan of a bench run as rocprofv3 saw it, beside the bench line's own HIP-event figure.
+
+A timed scan launch of bench.py is either one k_scan_u / k_scan launch or, when the scan is pruned, the chain
+k_seed -> k_seed_merge -> k_scan_p on one stream.  This sums the kernel-trace durations of all of them and divides by the
+number of chains (= k_scan_p + k_scan_u + clean k_scan dispatches), which is what `roofline.avg_launch_us` measures.
+Usage: scan_chain_summary.py <rocprof dir> <bench json> [leg name]"""
+import glob
+import json
+import sys
+
+import pandas as pd
+
+d = sys.argv[1]
+f = (glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*kernel_trace.csv"))[0]
+df = pd.read_csv(f)
+df["dur"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
+name = df["Kernel_Name"]
+parts = {"k_seed": name.str.contains("k_seed<"), "k_seed_merge": name.str.contains("k_seed_merge"),
+         "k_scan_p": name.str.contains("k_scan_p<"), "k_scan_u": name.str.contains("k_scan_u<"),
+         "k_scan (LDS-staged, clean)": name.str.contains(r"k_scan<\d+, (?:true|false), (?:true|false), false", regex=True)}
+out = {"kernels": {}}
+total = 0.0
+for k, m in parts.items():
+    g = df[m]
+    if len(g):
+        out["kernels"][k] = {"calls": int(len(g)), "total_ms": float(g["dur"].sum() / 1e3), "avg_us": float(g["dur"].mean())}
+        total += float(g["dur"].sum())
+chains = sum(out["kernels"].get(k, {}).get("calls", 0) for k in ("k_scan_p", "k_scan_u", "k_scan (LDS-staged, clean)"))
+out["scan_chains"] = chains
+out["rocprof_avg_chain_us"] = total / chains if chains else None
+line = json.load(open(sys.argv[2]))
+if len(sys.argv) > 3:
+    line = line.get(sys.argv[3], {})
+rf = line.get("roofline") or {}
+out["bench_line_launches"] = rf.get("launches")
+out["bench_line_avg_launch_us"] = rf.get("avg_launch_us")
+out["note"] = ("bench.py brackets every scan launch (the whole chain when pruned) with HIP events on its stream; the profiled run "
+               "includes the warm-up step(s), the bench line's figures only the timed ones")
+print(json.dumps(out, indent=1))
