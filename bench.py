@@ -427,6 +427,7 @@ def main():
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--lookahead", type=int, default=0, help="0/1 on (default), 2 off, 3 forced")
     ap.add_argument("--early-window", type=int, default=0, help="window while the table grows / is being promoted (0: 4096)")
+    ap.add_argument("--windows-per-sync", type=int, default=0, help="windows enqueued between host read-backs (0: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads of the all-cores CPU column (at most the usable cores)")
@@ -470,7 +471,8 @@ def main():
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
     h.set_tuning(window=args.window, rounds=args.rounds, segments=args.segments, lookahead=args.lookahead,
-                 early_window=args.early_window, time_kernels=0 if args.no_kernel_timing else 1)
+                 early_window=args.early_window, windows_per_sync=args.windows_per_sync,
+                 time_kernels=0 if args.no_kernel_timing else 1)
     set_params(h, cfg, n, d)
     h.points_upload(X)  # inputs are resident in HBM before the timed region
 

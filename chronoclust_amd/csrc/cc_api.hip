@@ -422,7 +422,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     const size_t w = (size_t)win, d = (size_t)std::max(h->d, h->d_alloc);
     h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_scl.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
-    h->v_dsq.ensure(w); h->v_tau.ensure(w); h->v_tile_dsq.ensure(w / 16 + 2);
+    h->v_dsq.ensure(w); h->v_tau.ensure(2 * w); h->v_tile_dsq.ensure(2 * (w / 16 + 2));
     h->v_tgt.ensure(w);
     h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2); h->v_unsafe.ensure(w);
     h->part_stride = w * seg * 4;
@@ -436,7 +436,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
     h->c_sclv.ensure(w * d); h->c_wv.ensure(w); h->c_c0.ensure(w * d); h->c_w0.ensure(w * d);
-    h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(w / 16 + 2);
+    h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(2 * (w / 16 + 2));
     h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
     h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;

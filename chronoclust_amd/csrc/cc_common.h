@@ -79,7 +79,7 @@ struct Carry {
     double* w0;    // [B, d] 1 / pref of the row before the commit
     int* kind0;    // kind before the commit; CC_KIND_DEAD: the row did not exist
     double* dsq;   // [B] squared displacement of the committed centroid from c0 in the w0 metric (see Versions::dsq)
-    unsigned long long* tile_dsq;  // per 16 rows: max of dsq, +inf bits if unbounded
+    unsigned long long* tile_dsq;  // [B / 16, 2] per 16 rows and kind: max of dsq (cc_dsq_code: 0 = no such row)
 };
 
 // Version rows of the current window: row j = state of point j's target microcluster right after point j
@@ -98,10 +98,11 @@ struct Versions {
     int* acc;   // 1 if point j was absorbed (radius test passed or new microcluster)
     int* tgt;   // target id of the chain this row belongs to
     // squared displacement of the version's centroid from its MC's window-start centroid, in the window-start
-    // metric; +inf for MCs created or promoted inside the window (k_chain).  tile_dsq[i / 16] = max over 16 rows.
+    // metric; +inf for MCs created or promoted inside the window or whose preferred dimensions changed (k_chain).
+    // tile_dsq[(i / 16) * 2 + kind] = max over the rows of that (current) kind among 16 (cc_dsq_code: 0 = none).
     double* dsq;
     unsigned long long* tile_dsq;
-    double* tau;  // per window point: a version with sqrt(dsq) below this cannot matter to it (k_dseed)
+    double* tau;  // [B, 2] per window point and kind: a version of the kind with sqrt(dsq) below this cannot matter to it (k_dseed)
     // per 64-point tile: 1 if no version row (skip) / no carried row (skip_car) can matter to any of its points,
     // so the dirty scan of the tile is not run and k_decide takes the seeds (k_dseed)
     int* skip;
@@ -123,7 +124,7 @@ struct Rows {
     const int* kind;
     const int* key;
     const int* next;  // only for version rows
-    const unsigned long long* tile_dsq;  // only for version rows (see Versions)
+    const unsigned long long* tile_dsq;  // only for version / carried rows (see Versions): [rows / 16, 2]
     const double* dsq;                   // only for version / carried rows: per-row squared displacement
     const double* tau;                   // only for version rows
     const int* skip;                     // dirty scans: per 64-point tile, 1 = nothing to do (Versions::skip)

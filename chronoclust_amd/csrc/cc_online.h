@@ -180,6 +180,17 @@ __device__ __forceinline__ void cc_static_for(F&& f)
 #define CC_TINY 0x1p-400
 __device__ __forceinline__ bool cc_is_tiny(double v) { return v != 0.0 && __builtin_fabs(v) < CC_TINY; }
 
+// Displacement maxima per 16 rows and kind (Versions::tile_dsq, Carry::tile_dsq): 0 = the tile holds no row of the kind,
+// else the bits of the largest squared displacement (>= 0: the bits order like the values; +inf: no bound) plus one.
+__device__ __forceinline__ unsigned long long cc_dsq_code(double dq) { return (unsigned long long)__double_as_longlong(dq) + 1ull; }
+// can a tile / a window whose maximum is `code` be ruled out for a threshold tau?  (no row of the kind: yes)
+__device__ __forceinline__ bool cc_dsq_below(unsigned long long code, double tau)
+{
+    if (code == 0ull) return true;
+    const double dq = __longlong_as_double((long long)(code - 1ull));
+    return dq < CC_INF && sqrt(dq) * (1.0 + 1e-9) < tau;
+}
+
 // wave-uniform operand of a dimension from bit BIT of its row mask: two scalar instructions (the compiler's own
 // selection takes three, and the scalar unit issues one instruction per wave turn like the vector unit)
 template <int BIT>
@@ -319,24 +330,29 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
     }
     // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave; when that
     // rules out every tile of the sub-range the wave only hands its seeds on and never loads its points
-    double wave_tau = -CC_INF;
+    // (per kind: a version competes in the list of its kind, against that list's threshold)
+    double wave_tau[2] = {-CC_INF, -CC_INF};
     bool any_tile = true;
     if (DIRTY) {
-        wave_tau = CC_INF;
 #pragma unroll
-        for (int t = 0; t < PT; ++t) {
-            const double tj = valid[t] ? rows.tau[jj[t]] : CC_INF;
-            wave_tau = tj < wave_tau ? tj : wave_tau;
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o = __shfl_xor(wave_tau, off);
-            wave_tau = o < wave_tau ? o : wave_tau;
+        for (int K = 0; K < 2; ++K) {
+            double wt = CC_INF;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const double tj = valid[t] ? rows.tau[(size_t)jj[t] * 2 + K] : CC_INF;
+                wt = tj < wt ? tj : wt;
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(wt, off);
+                wt = o < wt ? o : wt;
+            }
+            wave_tau[K] = wt;
         }
         any_tile = false;
-        for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
-            const double tdq = __longlong_as_double((long long)rows.tile_dsq[rt >> 4]);
-            if (!(tdq < CC_INF && sqrt(tdq) * (1.0 + 1e-9) < wave_tau)) any_tile = true;
-        }
+        for (int rt = r0; rt < r1; rt += CC_SCAN_TM)
+            if (!(cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
+                  cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1])))
+                any_tile = true;
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -394,8 +410,9 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
         const int tm = __builtin_amdgcn_readfirstlane(max(0, min(CC_SCAN_TM, r1 - rt)));
         if (tm == 0) break;
         if (DIRTY) {
-            const double tdq = __longlong_as_double((long long)rows.tile_dsq[rt >> 4]);
-            if (tdq < CC_INF && sqrt(tdq) * (1.0 + 1e-9) < wave_tau) continue;  // nothing in this tile can matter
+            if (cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
+                cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1]))
+                continue;  // nothing in this tile can matter
         }
         CC_WAVE_SYNC();
         bool fuse_tile = false;
@@ -467,7 +484,9 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
         unsigned rowmask = 0xFFFFu;
         if (DIRTY) {
             const double rq = (lane < tm) ? rows.dsq[rt + lane] : 0.0;
-            rowmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < tm && !(rq < CC_INF && sqrt(rq) * (1.0 + 1e-9) < wave_tau));
+            const int rk = (lane < tm) ? rows.kind[rt + lane] : CC_KIND_DEAD;
+            const double wt = (rk == CC_KIND_PCORE) ? wave_tau[0] : wave_tau[1];
+            rowmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < tm && rk != CC_KIND_DEAD && !(rq < CC_INF && sqrt(rq) * (1.0 + 1e-9) < wt));
         }
         CC_WAVE_SYNC();
 
@@ -1716,21 +1735,29 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     if (blockIdx.x * blockDim.x >= B) return;
     const bool la_mode = ctl->mode != 0;
     // largest displacement of any version row / carried row (the workgroup is one wave)
-    double maxd = 0.0, maxd_car = 0.0;
+    // (per kind, in cc_dsq_code form: 0 = the window / the carry set holds no row of the kind)
+    unsigned long long maxd[2] = {0ull, 0ull}, maxd_car[2] = {0ull, 0ull};
     {
-        unsigned long long m = 0ull, mc = 0ull;
-        for (int i = threadIdx.x; i < (B + 15) / 16; i += 64) { const unsigned long long v = ver.tile_dsq[i]; m = v > m ? v : m; }
-        if (la_mode)
-            for (int i = threadIdx.x; i < (ctl->car_n + 15) / 16; i += 64) { const unsigned long long v = car.tile_dsq[i]; mc = v > mc ? v : mc; }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long o = __shfl_xor(m, off), oc = __shfl_xor(mc, off);
-            m = o > m ? o : m;
-            mc = oc > mc ? oc : mc;
+        for (int i = threadIdx.x; i < 2 * ((B + 15) / 16); i += 64) {
+            const unsigned long long v = ver.tile_dsq[i];
+            if (i & 1) maxd[1] = v > maxd[1] ? v : maxd[1];
+            else maxd[0] = v > maxd[0] ? v : maxd[0];
         }
-        maxd = __longlong_as_double((long long)m);      // displacements are >= 0: their bit patterns order like the values
-        maxd_car = __longlong_as_double((long long)mc);
+        if (la_mode)
+            for (int i = threadIdx.x; i < 2 * ((ctl->car_n + 15) / 16); i += 64) {
+                const unsigned long long v = car.tile_dsq[i];
+                if (i & 1) maxd_car[1] = v > maxd_car[1] ? v : maxd_car[1];
+                else maxd_car[0] = v > maxd_car[0] ? v : maxd_car[0];
+            }
+#pragma unroll
+        for (int K = 0; K < 2; ++K)
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned long long o = __shfl_xor(maxd[K], off), oc = __shfl_xor(maxd_car[K], off);
+                maxd[K] = o > maxd[K] ? o : maxd[K];
+                maxd_car[K] = oc > maxd_car[K] ? oc : maxd_car[K];
+            }
     }
-    double tau_out = CC_INF;  // lanes past the window do not constrain the tile
+    double tau_out[2] = {CC_INF, CC_INF};  // lanes past the window do not constrain the tile
     bool flag_unprov = false, flag_unsafe = false;
     if (j < B) {
     const Par par = cc_load_par(ctl);
@@ -1741,7 +1768,13 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     Cand first0 = Cand{CC_INF, CC_IDX_INF, -1}, first1 = Cand{CC_INF, CC_IDX_INF, -1};
     double cap[2] = {CC_INF, CC_INF};
     bool provable = par.k > 0.0;  // false: some live version of a list MC could not be located -> no pruning
-    const double K = par.k >= 1.0 ? par.k : 1.0 / par.k;  // worst-case ratio of a dimension's weight before / after
+    // Ratio of a dimension's weight before / after, for the rows the threshold below is applied to: 1.  A version whose
+    // preferred dimensions differ from its MC's at window start carries no bound (k_chain, k_chain_long, k_commit_b give
+    // it dsq = +inf like a new or promoted MC), so every bounded row has the window-start metric itself and the bound is
+    // the plain triangle inequality.  (With the worst-case ratio k instead, a list whose MCs are all far from the point -
+    // second-best < k x best: every noise point, every point of a stream with a few stale outlier MCs - could never be
+    // pruned, and one such point keeps its whole tile's dirty scans running.)
+    const double K = 1.0;
 
     const unsigned long long wseq = ctl->window_seq;
     // Four lookups per point - best and second-best snapshot candidate of either kind -, each a chain of dependent
@@ -1944,7 +1977,9 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     //     sqrt(dsq_v) < sqrt(d2) - sqrt(K * cap).
     // Live versions of the list MCs themselves are seeded above.  With the pdim filter on, pcore MCs outside the
     // list may be closer than d2 (they were filtered out), so nothing is pruned for that kind.
-    double tau = CC_INF;
+    // One threshold per kind: a version competes in the list of its (current) kind.  A kind without any version row in
+    // the window constrains nothing - stale outlier MCs that no point touches must not cost anything.
+    bool ok_v = true, ok_c = true;
     for (int kd = 0; kd < 2; ++kd) {
         double t;
         if (kd == 0 && filter) t = -CC_INF;
@@ -1954,14 +1989,14 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
             const double ce = fb < cap[kd] ? fb : cap[kd];
             t = (d2v[kd] == CC_INF) ? CC_INF : (sqrt(d2v[kd]) - sqrt(K * ce));
         }
-        tau = t < tau ? t : tau;
+        if (!provable) t = -CC_INF;
+        t = (t == CC_INF) ? CC_INF : t * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
+        tau_out[kd] = t;
+        ver.tau[(size_t)j * 2 + kd] = t;
+        // the same test as for the tile below, for this point alone
+        ok_v = ok_v && cc_dsq_below(maxd[kd], t);
+        ok_c = ok_c && (!la_mode || cc_dsq_below(maxd_car[kd], t));
     }
-    if (!provable) tau = -CC_INF;
-    tau_out = (tau == CC_INF) ? CC_INF : tau * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
-    ver.tau[j] = tau_out;
-    // the same test as for the tile below, for this point alone
-    const bool ok_v = maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tau_out;
-    const bool ok_c = !la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tau_out);
     ver.unsafe[j] = (ok_v && ok_c) ? 0 : 1;
     flag_unprov = !provable;
     flag_unsafe = !(ok_v && ok_c);
@@ -1974,15 +2009,17 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     }
     // the tile as a whole: when even the largest displacement stays below every point's threshold, no row can matter
     // to any point of the tile and its dirty scan is not run at all (the same test k_scan makes per 16 rows)
-    double tile_tau = tau_out;
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(tile_tau, off);
-        tile_tau = o < tile_tau ? o : tile_tau;
-    }
+    double tile_tau[2] = {tau_out[0], tau_out[1]};
+#pragma unroll
+    for (int K = 0; K < 2; ++K)
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(tile_tau[K], off);
+            tile_tau[K] = o < tile_tau[K] ? o : tile_tau[K];
+        }
     if (threadIdx.x == 0) {
-        const int sk = (maxd < CC_INF && sqrt(maxd) * (1.0 + 1e-9) < tile_tau) ? 1 : 0;
+        const int sk = (cc_dsq_below(maxd[0], tile_tau[0]) && cc_dsq_below(maxd[1], tile_tau[1])) ? 1 : 0;
         ver.skip[blockIdx.x] = sk;  // (k_commit_a counts the tiles of the last round for the host's window policy)
-        ver.skip_car[blockIdx.x] = (!la_mode || (maxd_car < CC_INF && sqrt(maxd_car) * (1.0 + 1e-9) < tile_tau)) ? 1 : 0;
+        ver.skip_car[blockIdx.x] = (!la_mode || (cc_dsq_below(maxd_car[0], tile_tau[0]) && cc_dsq_below(maxd_car[1], tile_tau[1]))) ? 1 : 0;
     }
 }
 
@@ -2159,7 +2196,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
-        if ((j & 15) == 0) ver.tile_dsq[j >> 4] = 0ull;  // the next k_chain takes maxima into it
+        if ((j & 15) == 0) {  // the next k_chain takes maxima into them
+            ver.tile_dsq[(size_t)(j >> 4) * 2] = 0ull;
+            ver.tile_dsq[(size_t)(j >> 4) * 2 + 1] = 0ull;
+        }
         // (claims on the first scan_rows table rows are gathered by k_claims instead, without atomics)
         if (T >= 0 && !(T < M0 && T < scan_rows)) {
             // first / last point of this window that targets T, for the round that replays these claims
@@ -2436,13 +2476,18 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                     dq += df * df * w0[h];
                 }
                 dq = cc_group_sum_any_order(dq);  // (valid in the lane that stores it)
-                if (isnew || bkind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+                // (a change of the preferred dimensions since the snapshot takes the bound away as well: k_dseed's
+                // threshold assumes the window-start metric)
+                bool mv = false;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) mv = mv || ((1.0 / bpr[h]) != w0[h]);
+                if (isnew || bkind != kind0 || !(dq >= 0.0) || cc_group_ballot(mv) != 0u) dq = CC_INF;
                 if (gl == 0) {
                     ver.w[cur] = bw;
                     ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
                     ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
                     ver.dsq[cur] = dq;
-                    atomicMax(&ver.tile_dsq[cur >> 4], (unsigned long long)__double_as_longlong(dq));
+                    atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * 2 + (bkind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
                 }
             }
         }
@@ -2508,6 +2553,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
     __shared__ int s_queue[CC_LONG_QUEUE];
     __shared__ double s_b1[64], s_b2[64], s_bcen[64], s_bpref[64], s_c0[64], s_w0[64];  // running state / snapshot metric
     __shared__ double s_bw, s_bdq;
+    __shared__ unsigned long long s_m0, s_bmask;  // preferred dimensions in the snapshot / of the running state (bit i)
     __shared__ int s_wsum[4];
     __shared__ int s_first_fail, s_first_up;
     double* const xs = s_xy;
@@ -2547,6 +2593,13 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
             dq += df * df * s_w0[i];
         }
         s_bdq = dq;
+        unsigned long long m0 = 0ull, bm = 0ull;
+        for (int i = 0; i < d; ++i) {
+            m0 |= (s_w0[i] != 1.0) ? (1ull << i) : 0ull;
+            bm |= (s_bpref[i] != 1.0) ? (1ull << i) : 0ull;
+        }
+        s_m0 = m0;
+        s_bmask = bm;
     }
 
     const int4* T4 = reinterpret_cast<const int4*>(T);  // (the claims buffer is padded to whole 128-entry blocks)
@@ -2683,7 +2736,9 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
             const bool promoted = u >= 0 && k >= u;
             const int kind = promoted ? CC_KIND_PCORE : bkind;
             double dq = (src >= 0) ? s_dq[src] : s_bdq;
-            if (kind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+            // (no bound either when the preferred dimensions differ from the snapshot's, see k_chain)
+            const unsigned long long vmask = (src >= 0) ? s_mask[src] : s_bmask;
+            if (kind != kind0 || !(dq >= 0.0) || vmask != s_m0) dq = CC_INF;
             const int nx = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (CC_LONG_QUEUE - 1)] : CC_IDX_INF;
             ver.w[m] = (src >= 0) ? s_w[src] : s_bw;
             ver.tgt[m] = t;
@@ -2693,7 +2748,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
             ver.acc[m] = (k < n_ok) ? 1 : 0;
             ver.next[m] = nx;
             ver.dsq[m] = dq;
-            atomicMax(&ver.tile_dsq[m >> 4], (unsigned long long)__double_as_longlong(dq));
+            atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * 2 + (kind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
         }
         __syncthreads();  // every read of the running state and of the queue slots is done
 
@@ -2705,7 +2760,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
                 s_bcen[tid] = xs[l * d + tid] / s_w[l];
                 s_bpref[tid] = ((s_mask[l] >> tid) & 1ull) ? par.k : 1.0;
             }
-            if (tid == 64) { s_bw = s_w[l]; s_bdq = s_dq[l]; }
+            if (tid == 64) { s_bw = s_w[l]; s_bdq = s_dq[l]; s_bmask = s_mask[l]; }
         }
         if (u >= 0) {
             bkind = CC_KIND_PCORE; bkey = pk_base + up_point; bupg = up_point;
@@ -2842,7 +2897,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const bool la_ok = ctl->la_on != 0 && n == B && next_b > 0 && ctl->la_b[qn] == next_b &&
                        ctl->la_cursor[qn] == next_cursor;
     if (la_ok)
-        for (int i = tid; i < (B + 15) / 16 + 1; i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into it
+        for (int i = tid; i < 2 * ((B + 15) / 16 + 1); i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into them
     if (tid == 0) {
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         rec->carry = la_ok ? 1 : 0;
@@ -2932,6 +2987,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
         else key = tab.key[row];
         const int kind0 = (t < M0) ? tab.kind[row] : CC_KIND_DEAD;
         double dq = 0.0;
+        bool metric_moved = false;  // the preferred dimensions differ from what the snapshot held
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = gl + 32 * h;
@@ -2941,6 +2997,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
             if (carry) {
                 const double oc = (t < M0) ? tab.cen[e] : 0.0;
                 const double ow = (t < M0) ? 1.0 / tab.pref[e] : 0.0;
+                metric_moved = metric_moved || (t < M0 && npref != tab.pref[e]);
                 car.c0[v] = oc; car.w0[v] = ow;
                 car.cf1[v] = n1; car.cf2[v] = n2; car.cen[v] = ncen; car.pref[v] = npref; car.scl[v] = nscl;
                 const double df = ncen - oc;
@@ -2954,7 +3011,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
         }
         if (carry) {
             for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
-            if (kind0 == CC_KIND_DEAD || kind != kind0 || !(dq >= 0.0)) dq = CC_INF;
+            if (kind0 == CC_KIND_DEAD || kind != kind0 || !(dq >= 0.0) || cc_group_ballot(metric_moved) != 0u) dq = CC_INF;
         }
         if (gl == 0) {
             tab.w[row] = ver.w[j];
@@ -2979,7 +3036,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                 car.slot[j] = (int)row;
                 car.kind0[j] = kind0;
                 car.dsq[j] = dq;
-                atomicMax(&car.tile_dsq[j >> 4], (unsigned long long)__double_as_longlong(dq));
+                atomicMax(&car.tile_dsq[(size_t)(j >> 4) * 2 + (kind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
                 tab.carry_of[row] = (rec->next_seq << 20) | (unsigned long long)j;
             }
         }
