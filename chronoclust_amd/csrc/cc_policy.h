@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <limits>
 
 #include "../../include/chronoclust_hip.h"
 
@@ -46,7 +47,8 @@ public:
         nodirty_ = false;
         shard_on_ = policy_want_shard(c_, m_rows);
         prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_;
-        prune_hold_ = 0;
+        prune_resume_at_ = 0;
+        prune_backoff_ = 65536;
         stalled_ = 0;
         first_batch_ = true;
         prev_ = cc_policy_obs{};
@@ -75,13 +77,21 @@ public:
         // ---- pruned scans: on while the rows they still evaluate in full stay a minority ----
         const unsigned long long pr = o.prune_rows - prev_.prune_rows, pfu = o.prune_full - prev_.prune_full;
         if (prune_on_) {
-            // more than half of the (wave, row) pairs evaluated in full: the prefix scan and the tests cost more than
-            // they save (start-up: the points' own microclusters do not exist yet; overlapping data)
-            if (pr > 0 && pfu * 2 > pr) prune_hold_ = 4;
+            // More than one (wave, row) pair in twelve evaluated in full: the prefix scan and the tests cost more than
+            // they save (start-up: the points' own microclusters do not exist yet; overlapping data).  A completed row
+            // costs about ten times a row of the plain scan - its operands arrive by scalar loads nothing hides -, so the
+            // break-even share is 15 - 25 % (d = 20 .. 40), not one half.
+            // The plain scan then runs for a stretch of points before the next try: 65 536 after the first failed try,
+            // twice as many after each further one in a row (a stream that is all start-up - forty points per
+            // microcluster - should not pay for a try every few batches), back to 65 536 after a try that paid.
+            if (pr > 0 && pfu * 12 > pr) {
+                prune_resume_at_ = o.cursor + prune_backoff_;
+                prune_backoff_ = std::min<long long>(1ll << 20, prune_backoff_ * 2);
+            } else if (pr > 0) prune_backoff_ = 65536;
             // a window that commits nothing although its first point is always decidable: cannot happen with exact
             // first candidates - should it, the plain scan takes over for good
-            if (done == done_before && !nodirty_) prune_hold_ = 1 << 30;
-        } else if (prune_hold_ > 0) --prune_hold_;
+            if (done == done_before && !nodirty_) prune_resume_at_ = std::numeric_limits<long long>::max();
+        }
         // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused for want
         // of the dirty scans idle the rest of their batch), not three times in a row
         stalled_ = (done == done_before) ? stalled_ + 1 : 0;
@@ -149,7 +159,11 @@ public:
         const bool shard_flip = shard_next != shard_on_;
         shard_on_ = shard_next;
         const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_ &&
-                                ((c_.prune_mode == 2 && prune_hold_ < (1 << 29)) || prune_hold_ == 0);
+                                ((c_.prune_mode == 2 && prune_resume_at_ != std::numeric_limits<long long>::max()) ||
+                                 o.cursor >= prune_resume_at_ ||
+                                 // a settled stream (no tile needed its dirty scan: nothing created, promoted or moved far)
+                                 // is where pruned scans pay: tried at once, whatever the earlier tries said
+                                 (nodirty_ && prune_resume_at_ != std::numeric_limits<long long>::max()));
         const bool prune_flip = prune_next != prune_on_;
         prune_on_ = prune_next;
         const bool more = done < c_.n_end;
@@ -198,7 +212,8 @@ private:
     cc_policy_config c_;
     cc_policy_carry k_;
     cc_policy_obs prev_{};
-    int win_cfg_ = 0, rcur_ = 0, batch_windows_ = 2, prune_hold_ = 0, stalled_ = 0;
+    int win_cfg_ = 0, rcur_ = 0, batch_windows_ = 2, stalled_ = 0;
+    long long prune_resume_at_ = 0, prune_backoff_ = 65536;  // pruned scans are tried again from this point on / stretch after the next failed try
     bool la_on_ = false, nodirty_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
 };
 
