@@ -445,7 +445,7 @@ def main():
     ap.add_argument("--relaxed-points", type=int, default=5_000_000)
     ap.add_argument("--relaxed-minibatch", type=int, default=65536, help="points per rank and super-step")
     ap.add_argument("--no-c2-legs", action="store_true", help="skip the two C2-shaped strong-scaling legs")
-    ap.add_argument("--only-leg", default=None, help="profiling: skip the headline's CPU baseline and run only this leg")
+    ap.add_argument("--only-leg", default=None, help="profiling: only this leg, after a token headline (20 000 points, 100 microclusters, no CPU baseline)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints its path when a communicator is
@@ -467,6 +467,8 @@ def main():
 
     from chronoclust_amd import _lib
     n, d, g = args.points, args.dim, args.blobs
+    if args.only_leg:
+        n, g = min(n, 20_000), min(g, 100)  # (a token headline: the profile should hold the leg's launches, not the headline's)
     X = make_blobs(multi.stream_seed(42, rank), n, d, g)
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)

@@ -4,9 +4,9 @@ by any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK (`python -m torch.distr
 used, no `import torch` happens in the ranks).
 
 Rank 0 listens on an ephemeral port and publishes it in a file that every rank of the job can name: the directory is
-$TMPDIR (default /tmp), the name is built from MASTER_PORT, TORCHELASTIC_RUN_ID, TORCHELASTIC_RESTART_COUNT and the
-launcher's pid (the parent of every rank), or given by CHRONOCLUST_RDZV_FILE.  The launcher's own port (MASTER_PORT)
-is left alone: with `torch.distributed.run` the agent's store is bound to it.
+$TMPDIR (default /tmp), the name is built from MASTER_PORT, TORCHELASTIC_RUN_ID and TORCHELASTIC_RESTART_COUNT (without
+a MASTER_PORT: from the launcher's pid, the parent of every rank), or given by CHRONOCLUST_RDZV_FILE.  The launcher's
+own port (MASTER_PORT) is left alone: with `torch.distributed.run` the agent's store is bound to it.
 
 The operations are what the harness needs, star-shaped through rank 0, payloads are small:
     all_gather_bytes(b)  -> [bytes of rank 0, ..., bytes of rank W-1] on every rank
@@ -161,8 +161,11 @@ def default_rdzv_file():
     explicit = os.environ.get("CHRONOCLUST_RDZV_FILE")
     if explicit:
         return explicit
-    key = "_".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
-                                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), os.getppid()))
+    port = os.environ.get("MASTER_PORT")
+    # two jobs of one user at once differ in MASTER_PORT (a launcher cannot bind the same one twice); only a job started
+    # without one falls back on the launcher's pid, which ranks behind a wrapper script would not share
+    key = "_".join(str(x) for x in (port or "0", os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                    os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), "p" if port else os.getppid()))
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), "chronoclust_rdzv_%s_%d" % (key, os.getuid()))
 
 

@@ -1,0 +1,125 @@
+"""The pruned snapshot scan (k_seed -> k_seed_merge -> k_scan_p) against the oracle and against the
+plain scan, with the pruning FORCED for every window (CHRONOCLUST_HIP_PRUNE=2) - also where the library's own policy would
+not use it (start-up, overlapping data): abandoned rows leave bounds instead of candidates, and every decision must
+still be the reference's.  The knob is read when a handle is created, so each case sets it around the constructor."""
+import os
+
+import numpy as np
+import pytest
+
+import scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+class _env(object):
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _hdd(cfg, prune, F=None, **tuning):
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    kv = dict(CHRONOCLUST_HIP_PRUNE=prune)
+    if F is not None:
+        kv["CHRONOCLUST_HIP_PRUNE_F"] = F
+    with _env(**kv):
+        return HDDStream(cfg, tuning=tuning or None)
+
+
+def _same_state(a, b):
+    assert np.array_equal(a.labels_uid, b.labels_uid) and np.array_equal(a.labels_path, b.labels_path)
+    assert (a.pcore_MC_last_id, a.outlier_MC_last_id) == (b.pcore_MC_last_id, b.outlier_MC_last_id)
+    for kind in (0, 1):
+        x, y = a.table(kind), b.table(kind)
+        for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+            assert np.array_equal(x[key], y[key]), (kind, key)
+    assert [c.members_in_merge_order for c in a.final_clusters] == [c.members_in_merge_order for c in b.final_clusters]
+
+
+def _against_oracle(h, o):
+    assert np.array_equal(h.labels_uid, o.labels_uid) and np.array_equal(h.labels_path, o.paths)
+    assert (h.pcore_MC_last_id, h.outlier_MC_last_id) == o.counters
+    for kind in (0, 1):
+        a, b = h.table(kind), o.table(kind)
+        for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+            assert np.array_equal(a[key], b[key]), (kind, key)
+    assert [c.members_in_merge_order for c in h.final_clusters] == [[int(x) for x in c["members"]] for c in o.clusters]
+
+
+CASES = [
+    # (seed, n, d, g, sigma, parameter overrides, tuning, shift): the widths the pruned scan is compiled for
+    (21, 9000, 20, 300, 0.01, {}, dict(window=2048), 0.0),
+    (22, 9000, 14, 120, 0.01, {}, dict(window=1024, lookahead=3), 0.0),
+    (23, 6000, 40, 150, 0.01, {}, dict(window=4096), 0.0),
+    (24, 5000, 16, 60, 0.02, dict(param_k=8), dict(window=512, lookahead=2), 0.0),
+    (25, 5000, 32, 60, 0.01, dict(param_k=2), dict(window=1024), 0.0),
+    (26, 4000, 64, 30, 0.01, {}, dict(window=1024), 0.0),
+    # k < 1 (1 / k > 1: a preferred dimension weighs MORE - the other branch of s_min / s_max in the T32 bound)
+    (27, 6000, 20, 100, 0.01, dict(param_k=0.5), dict(window=1024), 0.0),
+    # heavy overlap: nearly every row survives the prefix and is completed in phase B
+    (28, 5000, 20, 12, 0.15, dict(param_epsilon=0.2), dict(window=512), 0.0),
+    # coordinates around 1 000 (sigma 0.01): single precision resolves 6e-5 there - the bound must absorb it
+    (29, 6000, 20, 200, 0.01, {}, dict(window=2048), 1000.0),
+    (30, 6000, 14, 100, 0.01, {}, dict(window=1024), -250000.0),
+]
+
+
+@pytest.mark.parametrize("seed,n,d,g,sigma,over,tuning,shift", CASES)
+def test_forced_pruning_matches_the_oracle(seed, n, d, g, sigma, over, tuning, shift):
+    from oracle import oracle as O
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, **over))
+    h = _hdd(cfg, 2, **tuning)
+    o = O.OracleHDDStream(cfg)
+    full = rows = launches = 0
+    for t in range(3):
+        X = scenarios.make_blobs(seed * 100 + t, n, d, g, sigma) + shift
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _against_oracle(h, o)
+        s = h.stats()
+        launches += s["scan_p_launches"]
+        rows += s["pruned_scan_rows"]
+        full += s["pruned_scan_full_rows"]
+    assert launches > 0 and rows > 0  # the pruned kernels really ran
+    print("seed %d d %d: %d pruned launches, %.1f %% of the sampled (wave, row) pairs completed" % (seed, d, launches, 100.0 * full / rows))
+
+
+@pytest.mark.parametrize("F", [1, 2, 64, 4096])
+def test_threshold_factor_never_changes_a_result(F):
+    """F = 1 (thresholds equal to the seed's distance: bounds everywhere, the second-best almost never exact) up to
+    F = 4096 (next to nothing abandoned): window after window the same labels and tables as the plain scan."""
+    n, d, g = 12000, 20, 400
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_omicron=0.0002, param_lambda=2))
+    sc = dict(seed=77, n=n, d=d, g=g, sigma=0.01, timepoints=3, drift=0.01, churn=0.08)
+    Xs = scenarios.make_blob_timepoints(sc, raw=True)
+    plain = _hdd(cfg, 0, window=2048)
+    pruned = _hdd(cfg, 2, F=F, window=2048)
+    for t, X in enumerate(Xs):
+        plain.online_microcluster_maintenance(X, t)
+        pruned.online_microcluster_maintenance(X, t)
+        _same_state(pruned, plain)
+    assert pruned.stats()["scan_p_launches"] > 0 and plain.stats()["scan_p_launches"] == 0
+
+
+def test_default_policy_uses_it_in_the_steady_state_and_not_while_microclusters_are_created():
+    n, d, g = 400_000, 20, 2000
+    X = scenarios.make_blobs(5, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    auto, plain = _hdd(cfg, 1), _hdd(cfg, 0)
+    auto.online_microcluster_maintenance(X, 0)
+    plain.online_microcluster_maintenance(X, 0)
+    _same_state(auto, plain)
+    s = auto.stats()
+    assert 0 < s["scan_p_launches"] < s["scan_u_launches"]  # (scan_u_launches counts both kinds of launch)
+    assert s["pruned_scan_full_rows"] < 0.2 * s["pruned_scan_rows"]

@@ -21,10 +21,12 @@ def full_launches(d, pat):
     t = df.groupby("Dispatch_Id").agg(s=("Start_Timestamp", "first"), e=("End_Timestamp", "first"), grid=("Grid_Size", "first"))
     g["us"] = (t["e"] - t["s"]) / 1e3
     g["grid"] = t["grid"]
-    # the full-window launches: the most frequent grid, and of those the ones that did their work (a launch whose
-    # window was scanned ahead returns at once)
+    # the full-window launches: the most frequent grid, and of those the typical ones - within a factor of 1.5 of the
+    # median duration (a launch whose window was scanned ahead returns at once; the launches of the build-up run, where
+    # every other row still survives its prefix, take several times as long as the steady state's)
     common = g[g["grid"] == g["grid"].mode().iloc[0]]
-    full = common[common["us"] > 0.6 * common["us"].max()]
+    med = common["us"].median()
+    full = common[(common["us"] > med / 1.5) & (common["us"] < med * 1.5)]
     return full.mean(), int(len(full))
 
 

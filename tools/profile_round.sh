@@ -2,14 +2,20 @@
 # Measurements of record for a round, run on the GPU box from the repo root:  bash tools/profile_round.sh <outdir>
 # (bench line; rocprofv3 kernel trace + stats of the headline and of the C5- / C4-shaped legs; PMC passes in runs of
 # their own).  The summaries are copied to profiles/ by hand afterwards (profiles/README.md says which).
+# SECTIONS="bench trace legs traffic valu" (the default: all of them) picks the parts to run.
 set -o pipefail
 OUT=${1:-gpurun_out/final}
+SECTIONS=${SECTIONS:-bench trace legs traffic valu}
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}" || exit 1
+B="python bench.py --no-cpu-baseline --no-one-stream --no-relaxed --no-c2-legs"
+if want bench; then
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
 echo "bench done"
-B="python bench.py --no-cpu-baseline --no-one-stream --no-relaxed --no-c2-legs"
+fi
+if want trace; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o r -- $B --steps 4 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 python tools/prof_summary.py $OUT/trace > $OUT/kernel_summary.txt
 python tools/scan_chain_summary.py $OUT/trace $OUT/bench_under_rocprof.json > $OUT/scan_chain.json
@@ -17,6 +23,8 @@ echo "trace done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_nola -o r -- $B --steps 4 --warmup 1 --lookahead 2 > $OUT/bench_under_rocprof_nolookahead.json 2> $OUT/trace_nola.err || exit 1
 python tools/prof_summary.py $OUT/trace_nola > $OUT/kernel_summary_nolookahead.txt
 echo "trace nola done"
+fi
+if want legs; then
 # the two legs whose scans run at d = 40 / d = 14 (one_stream_exact: C5-shaped, events_sharded_relaxed: C4-shaped)
 for LEG in one_stream_exact events_sharded_relaxed; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$LEG -o r -- python bench.py --only-leg $LEG --steps 1 --warmup 0 > $OUT/bench_leg_$LEG.json 2> $OUT/trace_$LEG.err || exit 1
@@ -24,10 +32,14 @@ for LEG in one_stream_exact events_sharded_relaxed; do
   python tools/scan_chain_summary.py $OUT/trace_$LEG $OUT/bench_leg_$LEG.json $LEG > $OUT/scan_chain_leg_$LEG.json
 done
 echo "legs done"
+fi
+if want traffic; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $B --steps 1 --warmup 0 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $B --steps 1 --warmup 0 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write 24576 > $OUT/pmc_traffic.json
 echo "pmc traffic done"
+fi
+if want valu; then
 # VALU counters of the snapshot-scan kernels of full windows running alone (tools/steady.py, LA=2), at d = 20, 40, 14
 for SH in "20 5000 1000000" "40 50000 2000000" "14 2000 2000000"; do
   set -- $SH
@@ -36,6 +48,7 @@ for SH in "20 5000 1000000" "40 50000 2000000" "14 2000 2000000"; do
   python tools/pmc_valu_summary.py $OUT/pmc_valu_a_d$1 $OUT/pmc_valu_b_d$1 $1 $2 > $OUT/pmc_valu_d$1.json
 done
 echo "pmc valu done"
+fi
 # (the raw traces and counter files are large: only the summaries made above travel back)
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*counter_collection.csv" -delete
