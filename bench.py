@@ -533,7 +533,7 @@ def main():
                                    "exact sequential semantics; online + offline phases per step; one independent "
                                    "stream per GPU" % (n, d, g),
                        "points": n, "dim": d, "microclusters": int(s["rows"]), "clusters": n_clusters,
-                       "streams": world, "window": args.window or 24576, "windows_per_step": int(s["windows"]),
+                       "streams": world, "window": int(s["window"]), "windows_per_step": int(s["windows"]),
                        "lookahead_windows_per_step": int(s["lookahead_windows"]),
                        "validation_rounds_per_step": int(s["rounds"]), "truncated_windows_per_step": int(s["truncated"])},
             "online_only_points_per_s": n * args.steps / (online_ms * 1e-3) if online_ms else None,

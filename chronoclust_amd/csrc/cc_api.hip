@@ -23,6 +23,11 @@
 #include "cc_csv.h"
 #include "cc_policy.h"
 
+// compute units the lookahead-scan stream may use (0: all of them; see cc_create); CHRONOCLUST_HIP_SCAN_CUS overrides
+#ifndef CC_SCAN_CUS_DEFAULT
+#define CC_SCAN_CUS_DEFAULT 0
+#endif
+
 namespace {
 
 struct HipErr {
@@ -143,6 +148,7 @@ struct cc_handle {
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
     int n_cus = 256;            // compute units of the device (hipDeviceProp_t::multiProcessorCount)
+    int scan_mask_cus = 0;      // > 0: the second stream (lookahead scans) is confined to this many of them
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -508,8 +514,9 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 if (h->prune_now && shard_world == 1) {
                     // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them
                     ++h->stats.scan_p_launches;
-                    hipLaunchKernelGGL((k_seed<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
-                                       h->spart.p, round, mode, h->spart_stride, h->cmax.p);
+                    // (k_seed holds two points per lane: point tiles of 128)
+                    hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                       rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p);
                     hipLaunchKernelGGL(k_seed_merge, dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
                                        rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
                                        h->prune_F, round, mode, h->cmax.p);
@@ -569,17 +576,17 @@ int scan_u_wgs_per_cu()
     return n;
 }
 
-int scan_resident_wgs(const cc_handle* h)
+int scan_resident_wgs(const cc_handle* h, int n_cus)
 {
     const int d = h->d;
-    if (d == 4 && scan_u_applies(h, 4)) return h->n_cus * scan_u_wgs_per_cu<4>();
-    if (d == 8 && scan_u_applies(h, 8)) return h->n_cus * scan_u_wgs_per_cu<8>();
-    if (d == 14 && scan_u_applies(h, 14)) return h->n_cus * scan_u_wgs_per_cu<14>();
-    if (d == 16 && scan_u_applies(h, 16)) return h->n_cus * scan_u_wgs_per_cu<16>();
-    if (d == 20 && scan_u_applies(h, 20)) return h->n_cus * scan_u_wgs_per_cu<20>();
-    if (d == 32 && scan_u_applies(h, 32)) return h->n_cus * scan_u_wgs_per_cu<32>();
-    if (d == 40 && scan_u_applies(h, 40)) return h->n_cus * scan_u_wgs_per_cu<40>();
-    if (d == 64 && scan_u_applies(h, 64)) return h->n_cus * scan_u_wgs_per_cu<64>();
+    if (d == 4 && scan_u_applies(h, 4)) return n_cus * scan_u_wgs_per_cu<4>();
+    if (d == 8 && scan_u_applies(h, 8)) return n_cus * scan_u_wgs_per_cu<8>();
+    if (d == 14 && scan_u_applies(h, 14)) return n_cus * scan_u_wgs_per_cu<14>();
+    if (d == 16 && scan_u_applies(h, 16)) return n_cus * scan_u_wgs_per_cu<16>();
+    if (d == 20 && scan_u_applies(h, 20)) return n_cus * scan_u_wgs_per_cu<20>();
+    if (d == 32 && scan_u_applies(h, 32)) return n_cus * scan_u_wgs_per_cu<32>();
+    if (d == 40 && scan_u_applies(h, 40)) return n_cus * scan_u_wgs_per_cu<40>();
+    if (d == 64 && scan_u_applies(h, 64)) return n_cus * scan_u_wgs_per_cu<64>();
     int per_cu;
     if (d <= 4) per_cu = ScanShape<4, false>::WGS;
     else if (d <= 8) per_cu = ScanShape<8, false>::WGS;
@@ -589,7 +596,7 @@ int scan_resident_wgs(const cc_handle* h)
     else if (d <= 32) per_cu = ScanShape<32, false>::WGS;
     else if (d <= 40) per_cu = ScanShape<40, false>::WGS;
     else per_cu = ScanShape<64, false>::WGS;
-    return h->n_cus * per_cu;
+    return n_cus * per_cu;
 }
 
 // Partials per point for a batch whose windows have `tiles` point tiles: at most S, not less than S / 2, chosen so that
@@ -685,15 +692,30 @@ int cc_create(int device, cc_handle** out)
         // the validation kernels (first stream) are short latency chains, the lookahead scans (second stream) fill the
         // machine: when both have workgroups pending the validation ones go first
         int prio_lo = 0, prio_hi = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
-        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
-        h->ctl.ensure(1);
-        h->badflag.ensure(1);
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
+        // A lookahead scan's workgroups stay resident for the whole launch and fill every CU's registers: a validation
+        // kernel enqueued meanwhile waits for one of them to retire, whatever its priority.  With a CU mask on the scan
+        // stream a few compute units per XCD stay free of scans (mask bit i is CU i / 8 of XCD i % 8: the low N bits
+        // leave every XCD N / 8 of its CUs), and the validation kernels - a few hundred short workgroups - start at once.
+        {
+            int want = CC_SCAN_CUS_DEFAULT;
+            if (const char* e = getenv("CHRONOCLUST_HIP_SCAN_CUS")) want = atoi(e);
+            want -= want % 8;
+            if (want >= 8 && want < h->n_cus) {
+                std::vector<uint32_t> mask((size_t)(h->n_cus + 31) / 32, 0u);
+                for (int i = 0; i < want; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+                if (hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()) == hipSuccess) h->scan_mask_cus = want;
+                else (void)hipGetLastError();
+            }
+        }
+        if (h->scan_mask_cus == 0) HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+        h->ctl.ensure(1);
+        h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
-        h->tun.window = 24576;
+        h->tun.window = 32768;
         h->tun.rounds = 3;
         h->tun.segments = 64;
         h->tun.windows_per_sync = 16;
@@ -772,7 +794,7 @@ const char* cc_last_error(const cc_handle* h) { return h ? h->err.c_str() : "nul
 int cc_set_tuning(cc_handle* h, const cc_tuning* t)
 {
     if (!h || !t) return CC_ERR_BAD_ARG;
-    if (t->window > 0) h->tun.window = std::min(t->window, 32768);
+    if (t->window > 0) h->tun.window = std::min(t->window, CC_MAX_WINDOW);
     if (t->rounds > 0) h->tun.rounds = std::min(t->rounds, CC_MAX_ROUNDS);
     if (t->segments > 0) h->tun.segments = std::min(t->segments, 1024);
     if (t->windows_per_sync > 0) h->tun.windows_per_sync = t->windows_per_sync;
@@ -1425,8 +1447,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // A pruned scan spends a few VALU instructions per row, so a wave must own many rows for its fixed costs
             // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
             // the machine once (about a fifth of the plain scan's partials at the full window).
-            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (h->n_cus * h->prune_rounds4) / std::max(1, (gw + 63) / 64)))
-                                       : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h));
+            // (lookahead scans run on the second stream: on the CUs its mask leaves it)
+            const int scan_cus = (la_on && h->scan_mask_cus > 0) ? h->scan_mask_cus : h->n_cus;
+            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * h->prune_rounds4) / std::max(1, (gw + 63) / 64)))
+                                       : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
             const int decide_threads = h->decide_threads;
             const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
             const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
@@ -2417,6 +2441,7 @@ int cc_get_stats(cc_handle* h, cc_stats* out)
 {
     if (!h || !out) return CC_ERR_BAD_ARG;
     *out = h->stats;
+    out->window = h->tun.window;
     return CC_OK;
 }
 

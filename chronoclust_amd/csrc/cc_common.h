@@ -57,6 +57,9 @@ struct Table {
 
 // Candidate slots >= CC_CAR_BASE refer to carried rows (index = slot - CC_CAR_BASE), below to version rows.
 #define CC_CAR_BASE (1 << 24)
+// Largest window (points validated together): k_commit_a ranks a window's creations and promotions in 16-bit counts and
+// stages one flag byte per point in LDS.
+#define CC_MAX_WINDOW 49152
 #define CC_CHAIN_MEMB 32
 #define CC_CHAIN_AHEAD 4  // k_chain: points of a chain requested ahead of the step that absorbs them
 

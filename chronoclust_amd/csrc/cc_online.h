@@ -1128,19 +1128,28 @@ __device__ __forceinline__ float cc_prefix_score(const cc_f2 (&p2)[CC_PRE / 2], 
     return acc.x + acc.y;
 }
 
+// k_seed: per point, kind and sub-range of rows the row with the smallest squared distance over the first eight
+// dimensions, in single precision.  Two points per lane (a workgroup covers 128 window points: a row's prefix is read
+// from LDS once for both), and the score in its expanded form: with p' = p - o, c' = c - o (o = the prefix of table
+// row 0: keeps the magnitudes at the size of the data's spread whatever its offset)
+//     |p' - c'|^2 = |p'|^2 - 2 (p' . c' - |c'|^2 / 2),
+// so the nearest row is the one with the LARGEST g = p' . c' - h, h = |c'|^2 / 2 staged with the tile: four packed
+// multiply-adds, an add, a compare and two selects per row and point (the round-3 kernel's difference form - four
+// packed subtractions more, one point per lane - took 61 us where this one takes 54, `profiles/r03_tool_seed.txt`).
+// The cancellation costs a few units of 2^-24 |c'|^2: immaterial for a heuristic.
 // cmax[q] (bits of a double): the largest |centroid coordinate| among the prefixes of the scanned rows, left by the
 // workgroups of the window's first point tile (every row is in exactly one of their waves' sub-ranges)
 template <int DP, int NW>
-__global__ __launch_bounds__(64 * NW, 8) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
-                                                  const double* __restrict__ g_cen, const int* __restrict__ g_kind,
-                                                  SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride,
-                                                  unsigned long long* __restrict__ cmax)
+__global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                   const double* __restrict__ g_cen, const int* __restrict__ g_kind,
+                                                   SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride,
+                                                   unsigned long long* __restrict__ cmax)
 {
-    static_assert(CC_PRE <= DP, "prefix dimensions");
+    static_assert(CC_PRE == 8 && CC_PRE <= DP, "prefix dimensions");
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
-    const int j0 = (int)blockIdx.x * 64;
+    const int j0 = (int)blockIdx.x * 128;
     if (j0 >= B) return;
     spart += (size_t)win.q * spart_stride;
     const int lane = threadIdx.x & 63;
@@ -1152,21 +1161,33 @@ __global__ __launch_bounds__(64 * NW, 8) void k_seed(const Ctl* __restrict__ ctl
     const int r0 = sub * per;
     const int r1 = min(win.rows, r0 + per);
     const size_t n_pts = (size_t)ctl->xt_stride;
-    const int jj = j0 + lane;
-    const bool valid = jj < B;
-    cc_f2 p2[CC_PRE / 2];
-    {
-        const double* xp = Xt + win.cursor + (valid ? jj : 0);
+    double org[CC_PRE];
+#pragma unroll
+    for (int i = 0; i < CC_PRE; ++i) org[i] = g_cen[i];  // (wave-uniform: scalar loads)
+    int jj[2];
+    bool valid[2];
+    cc_f2 p2[2][CC_PRE / 2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        jj[u] = j0 + u * 64 + lane;
+        valid[u] = jj[u] < B;
+        const double* xp = Xt + win.cursor + (valid[u] ? jj[u] : 0);
 #pragma unroll
         for (int i = 0; i < CC_PRE / 2; ++i)
-            p2[i] = cc_f2{valid ? (float)xp[(size_t)(2 * i) * n_pts] : 0.f, valid ? (float)xp[(size_t)(2 * i + 1) * n_pts] : 0.f};
+            p2[u][i] = cc_f2{valid[u] ? (float)(xp[(size_t)(2 * i) * n_pts] - org[2 * i]) : 0.f,
+                             valid[u] ? (float)(xp[(size_t)(2 * i + 1) * n_pts] - org[2 * i + 1]) : 0.f};
     }
-    // per wave: the prefixes of a tile of 16 rows in LDS (the wave is the only reader and writer of its tile), read
-    // back as wave-uniform broadcasts; the next tile's values are requested before the row loop of the current one
+    // per wave: the centred prefixes of a tile of 16 rows and their h in LDS, read back as wave-uniform broadcasts
     __shared__ __attribute__((aligned(16))) float s_pre[NW * CC_SCAN_TM * CC_PRE];
+    __shared__ float s_h[NW * CC_SCAN_TM];
     float* const tile = s_pre + (size_t)wv * CC_SCAN_TM * CC_PRE;
-    float best[2] = {__builtin_inff(), __builtin_inff()};
-    int idx[2] = {-1, -1};
+    float* const th = s_h + (size_t)wv * CC_SCAN_TM;
+    float best[2][2];
+    int idx[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) { best[u][K] = -__builtin_inff(); idx[u][K] = -1; }
     double tc[2];
     int kdl = CC_KIND_DEAD;
     double cm = 0.0;
@@ -1176,73 +1197,113 @@ __global__ __launch_bounds__(64 * NW, 8) void k_seed(const Ctl* __restrict__ ctl
         CC_WAVE_SYNC();
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            tile[lane + q * 64] = (float)tc[q];
             cm = __builtin_fmax(cm, __builtin_fabs(tc[q]));
+            const float v = (float)(tc[q] - org[lane & 7]);
+            tile[lane + q * 64] = v;
+            // h of the row: the eight lanes that hold it add their squares (every lane ends up with the sum)
+            float hsum = v * v;
+            hsum += __shfl_xor(hsum, 1);
+            hsum += __shfl_xor(hsum, 2);
+            hsum += __shfl_xor(hsum, 4);
+            if ((lane & 7) == 0) th[(lane >> 3) + q * 8] = 0.5f * hsum;
         }
         const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
         const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
         CC_WAVE_SYNC();
         if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
         const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
-        auto update = [&](auto KC, float acc, int rowg) {
-            constexpr int K = decltype(KC)::value;
-            const bool lt = acc < best[K];  // strict: the first row in scan order keeps a tie (deterministic)
-            best[K] = lt ? acc : best[K];
-            idx[K] = lt ? rowg : idx[K];
+        auto score2 = [&](int m, float (&g)[2]) {
+            const cc_f4 c01 = t4[m * 2], c23 = t4[m * 2 + 1];
+            const float h = th[m];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                cc_f2 acc = p2[u][0] * cc_f2{c01.x, c01.y};
+                acc = __builtin_elementwise_fma(p2[u][1], cc_f2{c01.z, c01.w}, acc);
+                acc = __builtin_elementwise_fma(p2[u][2], cc_f2{c23.x, c23.y}, acc);
+                acc = __builtin_elementwise_fma(p2[u][3], cc_f2{c23.z, c23.w}, acc);
+                g[u] = (acc.x + acc.y) - h;
+            }
         };
-        // a tile of one kind (the usual case): four rows at a time - their LDS reads and sums are independent, only the
-        // running minimum is a chain; a mixed tile row by row
+        auto update = [&](auto KC, const float (&g)[2], int rowg) {
+            constexpr int K = decltype(KC)::value;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool gt = g[u] > best[u][K];  // strict: the first row in scan order keeps a tie (deterministic)
+                best[u][K] = gt ? g[u] : best[u][K];
+                idx[u][K] = gt ? rowg : idx[u][K];
+            }
+        };
         auto rows_of_kind = [&](auto KC) {
             int m = 0;
-            for (; m + 4 <= tm; m += 4) {
-                float a[4];
+            for (; m + 2 <= tm; m += 2) {
+                float a[2][2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) a[u] = cc_prefix_score(p2, t4 + (m + u) * 2);
+                for (int v = 0; v < 2; ++v) score2(m + v, a[v]);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) update(KC, a[u], rt + m + u);
+                for (int v = 0; v < 2; ++v) update(KC, a[v], rt + m + v);
             }
-            for (; m < tm; ++m) update(KC, cc_prefix_score(p2, t4 + m * 2), rt + m);
+            for (; m < tm; ++m) {
+                float a[2];
+                score2(m, a);
+                update(KC, a, rt + m);
+            }
         };
         const unsigned full = (1u << tm) - 1u;
         if (pmask == full) rows_of_kind(std::integral_constant<int, 0>{});
         else if (omask == full) rows_of_kind(std::integral_constant<int, 1>{});
         else
             for (int m = 0; m < tm; ++m) {
-                const float acc = cc_prefix_score(p2, t4 + m * 2);
-                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{}, acc, rt + m);
-                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{}, acc, rt + m);
+                float a[2];
+                score2(m, a);
+                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{}, a, rt + m);
+                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{}, a, rt + m);
             }
     }
     if (blockIdx.x == 0) {
         for (int off = 32; off >= 1; off >>= 1) cm = __builtin_fmax(cm, __shfl_xor(cm, off));
         if (lane == 0) atomicMax(cmax + win.q, (unsigned long long)__double_as_longlong(cm));  // (>= 0: bits order like values)
     }
-    // the workgroup's winner per point and kind (the four waves' through LDS, in sub-range order: ties keep the lower
-    // row): S entries per point and kind for k_seed_merge to choose from
-    __shared__ float s_b[(NW > 1 ? NW - 1 : 1) * 2 * 64];
-    __shared__ int s_i[(NW > 1 ? NW - 1 : 1) * 2 * 64];
+    // back to squared prefix distances (what k_seed_merge ranks the sub-ranges' winners by): |p'|^2 - 2 g, never below 0
+    float pp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        cc_f2 acc = p2[u][0] * p2[u][0];
+#pragma unroll
+        for (int i = 1; i < CC_PRE / 2; ++i) acc = __builtin_elementwise_fma(p2[u][i], p2[u][i], acc);
+        pp[u] = acc.x + acc.y;
+#pragma unroll
+        for (int K = 0; K < 2; ++K) best[u][K] = idx[u][K] >= 0 ? __builtin_fmaxf(0.f, pp[u] - 2.f * best[u][K]) : __builtin_inff();
+    }
+    __shared__ float s_b[(NW > 1 ? NW - 1 : 1) * 4 * 64];
+    __shared__ int s_i[(NW > 1 ? NW - 1 : 1) * 4 * 64];
     if (wv > 0) {
 #pragma unroll
-        for (int K = 0; K < 2; ++K) {
-            s_b[((wv - 1) * 2 + K) * 64 + lane] = best[K];
-            s_i[((wv - 1) * 2 + K) * 64 + lane] = idx[K];
-        }
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                s_b[((wv - 1) * 4 + u * 2 + K) * 64 + lane] = best[u][K];
+                s_i[((wv - 1) * 4 + u * 2 + K) * 64 + lane] = idx[u][K];
+            }
     }
     __syncthreads();
-    if (wv != 0 || !valid) return;
+    if (wv != 0) return;
 #pragma unroll
-    for (int w = 0; w < NW - 1; ++w)
+    for (int u = 0; u < 2; ++u) {
+        if (!valid[u]) continue;
 #pragma unroll
-        for (int K = 0; K < 2; ++K) {
-            const float b = s_b[(w * 2 + K) * 64 + lane];
-            const int ix = s_i[(w * 2 + K) * 64 + lane];
-            const bool lt = ix >= 0 && (idx[K] < 0 || b < best[K]);
-            best[K] = lt ? b : best[K];
-            idx[K] = lt ? ix : idx[K];
-        }
-    SeedCand* o = spart + ((size_t)jj * S + blockIdx.y) * 2;
-    o[0] = SeedCand{best[0], idx[0]};
-    o[1] = SeedCand{best[1], idx[1]};
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                const float b = s_b[(w * 4 + u * 2 + K) * 64 + lane];
+                const int ix = s_i[(w * 4 + u * 2 + K) * 64 + lane];
+                const bool lt = ix >= 0 && (idx[u][K] < 0 || b < best[u][K]);
+                best[u][K] = lt ? b : best[u][K];
+                idx[u][K] = lt ? ix : idx[u][K];
+            }
+        SeedCand* o = spart + ((size_t)jj[u] * S + blockIdx.y) * 2;
+        o[0] = SeedCand{best[u][0], idx[u][0]};
+        o[1] = SeedCand{best[u][1], idx[u][1]};
+    }
 }
 
 // per point and kind (one thread each): the three best prefix scores of the sub-ranges -> their exact distances (the
@@ -2843,9 +2904,9 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
 
     // Per point: bit 0 "creates a MC", bit 1 "its add promoted the MC"; read with coalesced loads into LDS, then
     // every thread ranks a contiguous run of points (packed counts, unsigned: low 16 bits creations, high 16 bits
-    // promotions; B <= 32768, and a point either creates or promotes, so creations <= 32768 < 2^16 never carry
-    // into the promotions and promotions <= 32768 fit the upper 16 bits).
-    __shared__ unsigned char sflag[32768];
+    // promotions; B <= CC_MAX_WINDOW < 2^16, so creations never carry into the promotions and promotions fit the upper
+    // 16 bits; readers take the upper half as unsigned).
+    __shared__ unsigned char sflag[CC_MAX_WINDOW];
     // (steady state: nothing was created or promoted in this window - nothing to rank, k_commit_b never reads rk)
     const bool events = ctl->any_new[r - 1] != 0 || ctl->any_up[r] != 0;
     if (threadIdx.x == 0) tot = 0u;
@@ -2879,7 +2940,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     for (int q = 0; q < per; ++q) {
         const int j = tid * per + q;
         if (j < B) {
-            rk[j] = (int)run;  // exclusive prefix: at most 32767 promotions before j, fits 31 bits
+            rk[j] = (int)run;  // exclusive prefix (two unsigned 16-bit counts)
             const unsigned f = (unsigned)sflag[j];
             run += (f & 1u) | ((f & 2u) << 15);
         }
@@ -2982,7 +3043,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
         const int u = ver.upg[j];
         const int kind = ver.kind[j];
         int key;
-        if (u >= 0) key = rec->pk0 + (rk[u] >> 16);
+        if (u >= 0) key = rec->pk0 + (int)((unsigned)rk[u] >> 16);
         else if (t >= M0) key = rec->ok0 + (rk[c] & 0xFFFF);
         else key = tab.key[row];
         const int kind0 = (t < M0) ? tab.kind[row] : CC_KIND_DEAD;
@@ -3018,7 +3079,7 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
             tab.kind[row] = kind;
             if (u >= 0) {
                 tab.key[row] = key;
-                tab.id[row] = rec->pid0 + (rk[u] >> 16);
+                tab.id[row] = rec->pid0 + (long long)((unsigned)rk[u] >> 16);
             } else if (t >= M0) {
                 tab.key[row] = key;
                 tab.id[row] = rec->oid0 + (rk[c] & 0xFFFF);

@@ -72,7 +72,7 @@ typedef struct cc_params {
 
 /* Tuning knobs of the exact windowed online path (0 = library default). */
 typedef struct cc_tuning {
-    int32_t window;          /* points speculated per window (<= 32768, default 24576) */
+    int32_t window;          /* points speculated per window (<= 49152, default 32768) */
     int32_t rounds;          /* max validation rounds per window                 */
     int32_t segments;        /* microcluster-range segments per point tile       */
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */
@@ -111,6 +111,7 @@ typedef struct cc_stats {
     int64_t pruned_scan_rows;      /* (wave, row) pairs the pruned scans visited (sampled: the
                                     * first point tile of every window) ...              */
     int64_t pruned_scan_full_rows; /* ... and of those, pairs evaluated over all dimensions */
+    int64_t window;          /* configured window of the run (cc_tuning.window or the default)  */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

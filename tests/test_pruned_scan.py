@@ -123,3 +123,52 @@ def test_default_policy_uses_it_in_the_steady_state_and_not_while_microclusters_
     s = auto.stats()
     assert 0 < s["scan_p_launches"] < s["scan_u_launches"]  # (scan_u_launches counts both kinds of launch)
     assert s["pruned_scan_full_rows"] < 0.2 * s["pruned_scan_rows"]
+
+
+def _fuzz_case(seed):
+    """Random small streams inside the pruned scan's domain (k a power of two, no pdim filter, a compiled width > 8):
+    duplicates and exact distance ties (grid data), sigma = 0, one-point timepoints, windows of any size."""
+    rng = np.random.default_rng(7000 + seed)
+    d = int(rng.choice([14, 16, 20, 32, 40, 64]))
+    n = int(rng.choice([1, 17, 300, 1500, 4000]))
+    g = int(rng.choice([1, 2, 5, 12, 40, 150]))
+    sigma = float(rng.choice([0.0, 0.001, 0.02, 0.08, 0.3]))
+    grid = bool(rng.random() < 0.3)
+    cfg = {
+        "beta": float(rng.choice([0.1, 0.5, 0.9, 1.0])),
+        "delta": float(rng.choice([0.0, 0.01, 0.05, 0.3, 1.0])),
+        "epsilon": float(rng.choice([0.001, 0.03, 0.1, 0.5, 3.0])),
+        "lambda": float(rng.choice([0.0, 0.5, 2.0, 5.0])),
+        "k": float(rng.choice([0.5, 1.0, 2.0, 4.0, 16.0])),
+        "mu": float(rng.choice([0.0005, 0.002, 0.01, 0.1])),
+        "pi": int(rng.choice([0, d, d + 3])),
+        "omicron": float(rng.choice([0.0, 1e-5, 1e-3, 0.05])),
+        "upsilon": float(rng.choice([0.5, 1.0, 3.0, 6.5, 20.0])),
+    }
+    window = int(rng.choice([5, 64, 700, 4096]))
+    lookahead = int(rng.choice([0, 2, 3]))
+    F = float(rng.choice([1.0, 2.0, 16.0, 16.0, 1024.0]))
+    shift = float(rng.choice([0.0, 0.0, 100.0, -3.0e4]))
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    Xs = []
+    for t in range(3):
+        nt = max(1, int(n * rng.choice([1.0, 0.5, 0.1]))) if t else n
+        lab = rng.integers(0, g, nt)
+        X = np.clip(centres[lab] + rng.normal(0.0, 1.0, (nt, d)) * sigma, 0.0, 1.0)
+        if grid:
+            X = np.round(X * 8) / 8
+        Xs.append(np.ascontiguousarray(X + shift))
+        centres = np.clip(centres + rng.normal(0, 0.02, centres.shape), 0, 1)
+    return cfg, window, lookahead, F, Xs
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_forced_pruning_fuzz(seed):
+    from oracle import oracle as O
+    cfg, window, lookahead, F, Xs = _fuzz_case(seed)
+    h = _hdd(cfg, 2, F=F, window=window, lookahead=lookahead)
+    o = O.OracleHDDStream(cfg)
+    for t, X in enumerate(Xs):
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _against_oracle(h, o)

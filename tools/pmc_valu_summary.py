@@ -1,6 +1,6 @@
 """VALU utilisation of the snapshot-scan kernels from two rocprofv3 --pmc passes over tools/steady.py (LA=2: scans run alone).
 Usage: pmc_valu_summary.py <dir of pass a: GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU>
-                           <dir of pass b: GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES> <d> <rows>"""
+                           <dir of pass b: GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES> <d> <rows> [window]"""
 import glob
 import json
 import sys
@@ -8,7 +8,7 @@ import sys
 import pandas as pd
 
 D, ROWS = int(sys.argv[3]), int(sys.argv[4])
-WINDOW = 24576
+WINDOW = int(sys.argv[5]) if len(sys.argv) > 5 else 32768  # the library's default window
 
 
 def full_launches(d, pat):
