@@ -23,11 +23,6 @@
 #include "cc_csv.h"
 #include "cc_policy.h"
 
-// compute units the lookahead-scan stream may use (0: all of them; see cc_create); CHRONOCLUST_HIP_SCAN_CUS overrides
-#ifndef CC_SCAN_CUS_DEFAULT
-#define CC_SCAN_CUS_DEFAULT 0
-#endif
-
 namespace {
 
 struct HipErr {
@@ -148,7 +143,6 @@ struct cc_handle {
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
     int n_cus = 256;            // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-    int scan_mask_cus = 0;      // > 0: the second stream (lookahead scans) is confined to this many of them
 
     // points + labels of the current call
     DevBuf<double> X, Xt;
@@ -696,22 +690,7 @@ int cc_create(int device, cc_handle** out)
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) h->n_cus = cus;
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
-        // A lookahead scan's workgroups stay resident for the whole launch and fill every CU's registers: a validation
-        // kernel enqueued meanwhile waits for one of them to retire, whatever its priority.  With a CU mask on the scan
-        // stream a few compute units per XCD stay free of scans (mask bit i is CU i / 8 of XCD i % 8: the low N bits
-        // leave every XCD N / 8 of its CUs), and the validation kernels - a few hundred short workgroups - start at once.
-        {
-            int want = CC_SCAN_CUS_DEFAULT;
-            if (const char* e = getenv("CHRONOCLUST_HIP_SCAN_CUS")) want = atoi(e);
-            want -= want % 8;
-            if (want >= 8 && want < h->n_cus) {
-                std::vector<uint32_t> mask((size_t)(h->n_cus + 31) / 32, 0u);
-                for (int i = 0; i < want; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
-                if (hipExtStreamCreateWithCUMask(&h->stream2, (uint32_t)mask.size(), mask.data()) == hipSuccess) h->scan_mask_cus = want;
-                else (void)hipGetLastError();
-            }
-        }
-        if (h->scan_mask_cus == 0) HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
+        HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
         h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
@@ -1447,8 +1426,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // A pruned scan spends a few VALU instructions per row, so a wave must own many rows for its fixed costs
             // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
             // the machine once (about a fifth of the plain scan's partials at the full window).
-            // (lookahead scans run on the second stream: on the CUs its mask leaves it)
-            const int scan_cus = (la_on && h->scan_mask_cus > 0) ? h->scan_mask_cus : h->n_cus;
+            const int scan_cus = h->n_cus;
             const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * h->prune_rounds4) / std::max(1, (gw + 63) / 64)))
                                        : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
             const int decide_threads = h->decide_threads;
