@@ -511,7 +511,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                     // (k_seed holds two points per lane: point tiles of 128)
                     hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                        rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p);
-                    hipLaunchKernelGGL(k_seed_merge, dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
+                    hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
                                        rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
                                        h->prune_F, round, mode, h->cmax.p);
                     hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
@@ -1507,17 +1507,17 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 } else {
                     timed_scan(sA, 0, 0);
                 }
-                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
-                                   dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr, h->T0.p,
-                                   h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer);
+                // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
+                // of the previous commit (cc_apply_carry, extra workgroups of this launch: before this window's commit
+                // overwrites the carry set), then, in k_commit_b, this window's own
+                const ScanCopy sc_now = scopy[seq_host & 1ull];
+                const int ac_blocks = la_on ? rblocks : 0;
+                hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                   dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
+                                   h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
+                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
-                // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
-                // of the previous commit (before this window's commit overwrites the carry set), then, in k_commit_b,
-                // this window's own
-                const ScanCopy sc_now = scopy[seq_host & 1ull];
-                if (la_on)
-                    hipLaunchKernelGGL(k_apply_carry, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, car, sc_now, h->d, h->hc.filter);
                 for (int r = 1; r <= Rcur; ++r) {
                     const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
@@ -1534,7 +1534,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
-                                       dec_inner, dec_outer);
+                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }

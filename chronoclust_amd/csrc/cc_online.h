@@ -1315,6 +1315,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl
 //     P >= sum s_i (|x_i| - e)^2 >= Q - 2 e sum s_i |x_i| >= Q - a sqrt(Q),   a = 2 e sqrt(8 smax),  Q = sum s_i x_i^2 >= smin sum x_i^2
 // (Cauchy-Schwarz), g(Q) = Q - a sqrt(Q) grows for sqrt(Q) > a / 2, so P > T follows from sqrt(Q) > u = (a + sqrt(a^2 + 4 T)) / 2.
 // The nine roundings of Qf (relative 2^-24 each, all terms >= 0) are covered by the factor 1 + 2^-19; T32 is rounded up.
+template <int DP>
 __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, const double* __restrict__ X,
                                                    const double* __restrict__ g_cen, const double* __restrict__ g_scl,
                                                    const SeedCand* __restrict__ spart, size_t spart_stride, int S,
@@ -1325,7 +1326,7 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t >> 1, K = t & 1;
     if (j >= win.B) return;
-    const int d = ctl->d;
+    constexpr int d = DP;  // (the pruned scan runs for d == DP only: every loop below unrolls, its loads go out together)
     spart += (size_t)win.q * spart_stride;
     thr += (size_t)win.q * thr_stride;
     thr32 += (size_t)win.q * thr_stride;
@@ -1344,12 +1345,25 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
         const bool h1 = i1 >= 0, h2 = i2 >= 0;
         const size_t o0 = (size_t)i0 * d, o1 = (size_t)(h1 ? i1 : i0) * d, o2 = (size_t)(h2 ? i2 : i0) * d;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int i = 0; i < d; ++i) {
-            const double pi = p[i];
-            double x0 = pi - g_cen[o0 + i], x1 = pi - g_cen[o1 + i], x2 = pi - g_cen[o2 + i];
-            x0 = x0 * x0; x1 = x1 * x1; x2 = x2 * x2;
-            x0 = x0 * g_scl[o0 + i]; x1 = x1 * g_scl[o1 + i]; x2 = x2 * g_scl[o2 + i];
-            a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2;
+        // eight dimensions of the three rows per pass: 56 loads in flight, the sums left to right
+        for (int i0 = 0; i0 < d; i0 += 8) {
+            double pv[8], c0[8], c1[8], c2[8], s0[8], s1[8], s2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = (i0 + u < d) ? i0 + u : d - 1;
+                pv[u] = p[i];
+                c0[u] = g_cen[o0 + i]; c1[u] = g_cen[o1 + i]; c2[u] = g_cen[o2 + i];
+                s0[u] = g_scl[o0 + i]; s1[u] = g_scl[o1 + i]; s2[u] = g_scl[o2 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < d) {
+                    double x0 = pv[u] - c0[u], x1 = pv[u] - c1[u], x2 = pv[u] - c2[u];
+                    x0 = x0 * x0; x1 = x1 * x1; x2 = x2 * x2;
+                    x0 = x0 * s0[u]; x1 = x1 * s1[u]; x2 = x2 * s2[u];
+                    a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2;
+                }
+            }
         }
         double dmin = a0;
         dmin = a1 < dmin ? a1 : dmin;
@@ -2084,6 +2098,63 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     }
 }
 
+// Scan copies of the table (lookahead).  Lookahead scans do not read the table but one of two copies of the columns a
+// scan needs, so that a commit never waits for a scan that is still reading.  The copy with the parity of window W
+// is read by the snapshot scan of W (which saw the table two commits earlier... one commit before W - 1's) and is
+// brought up to date during W's validation: first the rows the previous commit changed (its carry set,
+// k_apply_carry), then the rows W's own commit changes (k_commit_b).  It is next read by the scan of W + 2.
+struct ScanCopy {
+    double* cen;
+    double* scl;
+    double* cf1;  // cf1, cf2, w: read by the pdim filter only
+    double* cf2;
+    double* w;
+    int* kind;
+    int* key;
+};
+
+struct CommitRec {
+    int n;        // validated prefix length
+    int M0;       // table rows at window start
+    int pk0, ok0; // list-order key bases
+    long long pid0, oid0;
+    const int* T; // the claims the prefix was validated against
+    long long cursor;  // first point of the window in the call's input
+    int carry;    // 1: the next window is a lookahead window -> k_commit_b also writes the carry set
+    unsigned long long next_seq;  // its window_seq
+};
+
+// The rows the previous commit changed (its carry set) into the scan copy of this window's parity.  Runs as extra
+// workgroups of k_decide's round-0 launch (`part` of `parts`): nothing it writes is read by k_decide, and a launch of its
+// own would cost the validation chain one more kernel slot per window.
+__device__ __forceinline__ void cc_apply_carry(const CommitRec* __restrict__ rec, const Carry& car, const ScanCopy& sc, int d,
+                                               int filter, int part, int parts)
+{
+    if (rec->carry == 0) return;
+    const int n = rec->n;
+    const int gl = threadIdx.x & 31;
+    const int groups = (parts * (int)blockDim.x) >> 5;
+    for (int j = (part * (int)blockDim.x + (int)threadIdx.x) >> 5; j < n; j += groups) {
+        const int kind = car.kind[j];
+        if (kind == CC_KIND_DEAD) continue;  // a later point holds the last version of this MC
+        const size_t row = (size_t)car.slot[j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = gl + 32 * h;
+            if (i >= d) continue;
+            const size_t e = row * d + i, v = (size_t)j * d + i;
+            sc.cen[e] = car.cen[v];
+            sc.scl[e] = car.scl[v];
+            if (filter) { sc.cf1[e] = car.cf1[v]; sc.cf2[e] = car.cf2[v]; }
+        }
+        if (gl == 0) {
+            sc.kind[row] = kind;
+            sc.key[row] = car.key[j];
+            if (filter) sc.w[row] = car.w[j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // k_decide: one 32-lane group per window point.  Segment partials are merged inside each row of 16 lanes with DPP
 // exchanges (per-point argmin over the MC range), then the reference's decision procedure runs group-uniformly.
@@ -2096,9 +2167,15 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const Cand* __restrict__ dseed,
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
-                                                int scan_rows, int part_inner, size_t part_outer)
+                                                int scan_rows, int part_inner, size_t part_outer,
+                                                const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks)
 {
     CC_LATENCY_KERNEL();
+    // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
+    if (ac_blocks > 0 && (int)blockIdx.x >= (int)gridDim.x - ac_blocks) {
+        cc_apply_carry(ac_rec, car, ac_sc, ctl->d, ctl->filter, (int)blockIdx.x - ((int)gridDim.x - ac_blocks), ac_blocks);
+        return;
+    }
     const int B = ctl->win_b;
     if (B == 0) return;
     if (round > 0 && ctl->fc[round - 1] >= B) return;
@@ -2844,32 +2921,6 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
 // touched MC back into the table.
 // ---------------------------------------------------------------------------------
 
-// Scan copies of the table (lookahead).  Lookahead scans do not read the table but one of two copies of the columns a
-// scan needs, so that a commit never waits for a scan that is still reading.  The copy with the parity of window W
-// is read by the snapshot scan of W (which saw the table two commits earlier... one commit before W - 1's) and is
-// brought up to date during W's validation: first the rows the previous commit changed (its carry set,
-// k_apply_carry), then the rows W's own commit changes (k_commit_b).  It is next read by the scan of W + 2.
-struct ScanCopy {
-    double* cen;
-    double* scl;
-    double* cf1;  // cf1, cf2, w: read by the pdim filter only
-    double* cf2;
-    double* w;
-    int* kind;
-    int* key;
-};
-
-struct CommitRec {
-    int n;        // validated prefix length
-    int M0;       // table rows at window start
-    int pk0, ok0; // list-order key bases
-    long long pid0, oid0;
-    const int* T; // the claims the prefix was validated against
-    long long cursor;  // first point of the window in the call's input
-    int carry;    // 1: the next window is a lookahead window -> k_commit_b also writes the carry set
-    unsigned long long next_seq;  // its window_seq
-};
-
 __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver, Carry car,
                                                    const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
                                                    int* __restrict__ rk, CommitRec* __restrict__ rec)
@@ -3104,34 +3155,6 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
     }
 }
 
-// the carry set of the previous commit -> the scan copy of the current window's parity; one 32-lane group per carried row
-__global__ __launch_bounds__(256) void k_apply_carry(const CommitRec* __restrict__ rec, Carry car, ScanCopy sc, int d,
-                                                     int filter)
-{
-    if (rec->carry == 0) return;
-    const int n = rec->n;
-    const int gl = threadIdx.x & 31;
-    const int groups = (gridDim.x * blockDim.x) >> 5;
-    for (int j = (blockIdx.x * blockDim.x + threadIdx.x) >> 5; j < n; j += groups) {
-        const int kind = car.kind[j];
-        if (kind == CC_KIND_DEAD) continue;  // a later point holds the last version of this MC
-        const size_t row = (size_t)car.slot[j];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int i = gl + 32 * h;
-            if (i >= d) continue;
-            const size_t e = row * d + i, v = (size_t)j * d + i;
-            sc.cen[e] = car.cen[v];
-            sc.scl[e] = car.scl[v];
-            if (filter) { sc.cf1[e] = car.cf1[v]; sc.cf2[e] = car.cf2[v]; }
-        }
-        if (gl == 0) {
-            sc.kind[row] = kind;
-            sc.key[row] = car.key[j];
-            if (filter) sc.w[row] = car.w[j];
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------
 // k_seq: the reference's loop taken literally (hddstream.py:220-237), for streams on which speculation does not pay:
