@@ -131,7 +131,7 @@ struct cc_handle {
     int prune_mode = 1;
     double prune_F = 16.0;
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
-    int prune_rounds4 = 8;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS)
+    int prune_rounds4 = 0;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS; 0: by width, see S)
     DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range and kind (two window parities)
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
@@ -1427,7 +1427,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
             // the machine once (about a fifth of the plain scan's partials at the full window).
             const int scan_cus = h->n_cus;
-            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * h->prune_rounds4) / std::max(1, (gw + 63) / 64)))
+            // (measured, `profiles/r03_tool_prune_split.txt`: four rounds of the resident workgroups at d <= 20 - k_scan_p is
+            // compiled for four per CU there -, eight of the three per CU beyond)
+            const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? 16 : 24);
+            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * prune_wgs) / std::max(1, (gw + 63) / 64)))
                                        : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
             const int decide_threads = h->decide_threads;
             const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point

@@ -1402,8 +1402,11 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
 //      per term in double precision (sub, square, scale, add - no fusion, so no CC_TINY condition to check), centroid
 //      and operand as scalar loads of eight dimensions at a time, the abandon test (now exact: partial sum against T)
 //      every eight dimensions, then the best-two update of k_scan_u.
+#ifndef CC_SCANP_WGS20
+#define CC_SCANP_WGS20 4  // workgroups per CU k_scan_p is compiled for at d <= 20
+#endif
 template <int DP, int NW>
-__global__ __launch_bounds__(64 * NW, (DP <= 20 ? 4 : (DP <= 40 ? 3 : 2))) void k_scan_p(
+__global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3 : 2))) void k_scan_p(
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
     const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride)
