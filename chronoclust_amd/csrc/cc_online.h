@@ -35,7 +35,7 @@
 // Carry) and enters the next window's validation like version rows that precede its
 // first point (k_dseed, k_scan<DIRTY=true, mode 1>, k_decide, k_chain, k_commit_b).
 // Lookahead scans read one of two scan copies of the table (struct ScanCopy), kept
-// up to date by k_apply_carry and k_commit_b, so that a commit never waits for them.
+// up to date by cc_apply_carry and k_commit_b, so that a commit never waits for them.
 //
 // Beside the window pipeline:
 //   k_chain_long      long chains on small tables (few MCs absorb every point): sequential CF additions per
@@ -2105,7 +2105,7 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
 // scan needs, so that a commit never waits for a scan that is still reading.  The copy with the parity of window W
 // is read by the snapshot scan of W (which saw the table two commits earlier... one commit before W - 1's) and is
 // brought up to date during W's validation: first the rows the previous commit changed (its carry set,
-// k_apply_carry), then the rows W's own commit changes (k_commit_b).  It is next read by the scan of W + 2.
+// cc_apply_carry), then the rows W's own commit changes (k_commit_b).  It is next read by the scan of W + 2.
 struct ScanCopy {
     double* cen;
     double* scl;

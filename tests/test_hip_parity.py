@@ -299,7 +299,8 @@ def test_quiet_stream_then_new_populations(lookahead, wps, window):
         _check_against_oracle(h, o)
 
 
-@pytest.mark.parametrize("g,window,lookahead", [(8, 16384, 0), (3, 8192, 3), (40, 24576, 0), (150, 24576, 2)])
+@pytest.mark.parametrize("g,window,lookahead", [(8, 16384, 0), (3, 8192, 3), (40, 24576, 0), (150, 24576, 2),
+                                                (150, 49152, 0), (40, 49152, 3), (300, 32768, 0)])  # 49 152: CC_MAX_WINDOW
 def test_long_chains(g, window, lookahead):
     """Few microclusters and large windows: every MC absorbs hundreds to thousands of points per window, so the chains
     k_chain replays are far longer than the 32-entry member lists, and k_dseed finds live versions by reading the
@@ -313,6 +314,32 @@ def test_long_chains(g, window, lookahead):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
         _check_against_oracle(h, o)
+
+
+def test_windows_with_more_than_32767_creations():
+    """k_commit_a ranks a window's creations and promotions in two 16-bit counts packed into one word: a window at
+    the largest size (49 152 points) in which EVERY point creates a microcluster (uniform points, a radius threshold
+    nothing passes) takes the creation count past 2^15 - ids, list order and labels must still be the reference's.
+    (A call on a table of 1 024 rows or more opens with the configured window: the table comes from a saved state.)"""
+    from oracle import oracle as O
+    n0, n1, d = 1100, 52_000, 4
+    rng = np.random.default_rng(99)
+    X0 = np.ascontiguousarray(rng.uniform(0.0, 1.0, (n0, d)))
+    X1 = np.ascontiguousarray(rng.uniform(0.0, 1.0, (n1, d)))
+    cfg = scenarios.params_to_config(scenarios.blob_params(n1, param_epsilon=1e-7, param_k=2))
+    o = O.OracleHDDStream(cfg)
+    first = _hdd(cfg)
+    first.online_microcluster_maintenance(X0, 0)
+    o.online_microcluster_maintenance(X0, 0)
+    _check_against_oracle(first, o)
+    h = _hdd(cfg, window=49152, early_window=49152)
+    h.set_state(first.get_state())
+    h.online_microcluster_maintenance(X1, 0)  # (the same daystamp: no decay in between)
+    o.online_microcluster_maintenance(X1, 0)
+    _check_against_oracle(h, o)
+    s = h.stats()
+    assert h.outlier_MC_last_id == n0 + n1  # every point created one
+    assert s["windows"] <= 2, s  # 49 152 + 2 848
 
 
 def test_prefetched_upload_changes_nothing():

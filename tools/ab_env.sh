@@ -5,7 +5,7 @@ name=$1; shift
 for v in "$@"; do
   export $name=$v
   echo "=== $name=$v"
-  N=4000000 LA=2 REPS=1 timeout -k 5 200 python tools/steady.py 2>&1 | grep "steady run" || exit 1
-  N=4000000 LA=0 REPS=1 timeout -k 5 200 python tools/steady.py 2>&1 | grep "steady run" || exit 1
-  timeout -k 5 300 python bench.py --no-cpu-baseline --no-one-stream --no-relaxed --steps 3 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read()); print('bench value %.2f M  ms/step %.2f  scan avg %.1f us frac %.3f' % (o['value']/1e6, o['ms_per_step'], o['roofline']['avg_launch_us'], o['roofline']['frac']))" || exit 1
+  LA=2 REPS=1 timeout -k 5 200 python tools/steady.py 2>&1 | grep "steady run" || exit 1
+  LA=0 REPS=2 timeout -k 5 200 python tools/steady.py 2>&1 | grep "steady run" || exit 1
+  timeout -k 5 300 python bench.py --no-cpu-baseline --no-one-stream --no-relaxed --no-c2-legs --steps 5 2>/dev/null | python -c "import sys,json; o=json.loads(sys.stdin.read()); print('bench value %.2f M  ms/step %.2f  scan avg %.1f us frac %.3f' % (o['value']/1e6, o['ms_per_step'], o['roofline']['avg_launch_us'], o['roofline']['frac']))" || exit 1
 done

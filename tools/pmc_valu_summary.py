@@ -50,6 +50,10 @@ for pat in ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<"):
         "wave_time_waiting_to_issue": float(b["SQ_WAIT_INST_ANY"] / b["SQ_WAVE_CYCLES"]),
         "wave_time_parked_on_waitcnt": float(b["SQ_WAIT_ANY"] / b["SQ_WAVE_CYCLES"]),
     }
+if "k_scan_p" in out["kernels"] and "k_scan_u" in out["kernels"]:
+    # (with the pruned scan on, k_scan_u only ran on the short windows of the build-up run: its per-row figures would
+    # be scaled by the wrong window; the plain scan's own are in the *_plain.json file, measured with CHRONOCLUST_HIP_PRUNE=0)
+    del out["kernels"]["k_scan_u"]
 out["note"] = ("two PMC passes of five counters; SQ_* count quad-cycles; valu_busy_fraction = SQ_ACTIVE_INST_VALU x 4 cycles / 1024 "
                "SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs); instructions per (wave, row): the plain scan k_scan_u spends 3 d of them on "
                "the distance terms alone (60 at d = 20, 120 at d = 40)")
