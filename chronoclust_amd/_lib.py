@@ -177,11 +177,12 @@ def comm_init_local(handles):
         raise ChronoclustHipError("cc_comm_init_local failed: %s" % _ERRORS.get(rc, rc))
 
 
-def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=65536):
+def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=65536, out=None):
     """The body of cluster_points_D{t}.csv (app.py:357-360, DataFrame.to_csv(index=False)) as bytes: one line per row of
     `values` [n, d] - "<id>,<label>,<repr(float)>,..." -, ids counting from first_id, labels[label_idx[r]] as the label
     (already CSV-quoted where needed; index -1 = the last label).  Formatted by cc_format_points_csv in chunks on a few
-    threads (ctypes releases the GIL)."""
+    threads (ctypes releases the GIL).  With `out` (a binary file object) the chunks are written to it in order as they
+    become ready - the threads format ahead of the writer, nothing is joined in memory - and the byte count is returned."""
     from concurrent.futures import ThreadPoolExecutor
     lib = load()
     values = _f64(values)
@@ -195,19 +196,31 @@ def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=6553
 
     def work(a):
         b = min(n, a + chunk)
-        buf = C.create_string_buffer(per_row * (b - a))
+        buf = np.empty(per_row * (b - a), np.uint8)  # (not zeroed: the formatter says how much of it it filled)
         got = lib.cc_format_points_csv(values[a:b].ctypes.data_as(_dp), b - a, d, first_id + a,
                                        label_idx[a:b].ctypes.data_as(_i32p), blob, offs.ctypes.data_as(_i32p), len(enc),
-                                       buf, len(buf))
+                                       buf.ctypes.data, buf.size)
         if got < 0:
             raise ChronoclustHipError("cc_format_points_csv failed: %s" % _ERRORS.get(got, got))
-        return buf.raw[:got]
+        return memoryview(buf)[:got]
 
-    starts = range(0, n, chunk)
     if n == 0:
-        return b""
-    with ThreadPoolExecutor(max_workers=max(1, threads)) as ex:
-        return b"".join(ex.map(work, starts))
+        return 0 if out is not None else b""
+    starts = list(range(0, n, chunk))
+    workers = max(1, threads)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        if out is None:
+            return b"".join(ex.map(work, starts))
+        # a bounded number of chunks in flight: the formatters run at most 2 x workers chunks ahead of the writer
+        total, pending, nxt = 0, [], 0
+        while nxt < len(starts) or pending:
+            while nxt < len(starts) and len(pending) < 2 * workers:
+                pending.append(ex.submit(work, starts[nxt]))
+                nxt += 1
+            part = pending.pop(0).result()
+            out.write(part)
+            total += len(part)
+        return total
 
 
 def policy_replay(config, carry, start, observations):

@@ -192,9 +192,8 @@ def write_datapoints_details(dataset_attributes, clusters, hddstream, raw, clust
     else:
         values = raw
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    body = _lib.format_points_csv(values, 0, idx, labels, threads=max(1, min(16, usable)))
     with open(cluster_points_filename, 'ab') as f:
-        f.write(body)
+        _lib.format_points_csv(values, 0, idx, labels, threads=max(1, min(16, usable)), out=f)
 
 
 def save_program_state(hddstream, output_dir, tracker_by_association, tracker_by_lineage):

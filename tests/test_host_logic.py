@@ -163,6 +163,13 @@ def test_points_csv_formatter_writes_repr_bytes():
     pd.DataFrame(cols).to_csv(f, index=False, header=False)
     assert got == f.getvalue().encode()
     assert _lib.format_points_csv(np.empty((0, 3)), 0, np.empty(0, np.int32), ["None"]) == b""
+    # streamed to a file object: the same bytes, chunk by chunk in order, however many chunks are in flight
+    import io
+    for threads, chunk in ((1, 100), (3, 512), (16, 7)):
+        sink = io.BytesIO()
+        assert _lib.format_points_csv(Y, 0, idx, quoted, threads=threads, chunk=chunk, out=sink) == len(got)
+        assert sink.getvalue() == got
+    assert _lib.format_points_csv(np.empty((0, 3)), 0, np.empty(0, np.int32), ["None"], out=io.BytesIO()) == 0
 
 
 def test_rounded_weights_equal_the_reference_expression():
