@@ -164,6 +164,7 @@ struct cc_handle {
     DevBuf<int> c_kind, c_key, c_slot, c_kind0;
     DevBuf<unsigned long long> c_tile_dsq;
     DevBuf<int> T0, T1, rk;
+    DevBuf<int> long_list;    // [2][CC_LONG_CAP] MCs whose chain k_chain_long replays (tables beyond k_claims' reach)
     DevBuf<CommitRec> rec;
     // scan copy of the table for lookahead scans (see ScanCopy)
     DevBuf<double> sh_cen[2], sh_scl[2], sh_cf1[2], sh_cf2[2], sh_w[2];
@@ -438,6 +439,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->c_sclv.ensure(w * d); h->c_wv.ensure(w); h->c_c0.ensure(w * d); h->c_w0.ensure(w * d);
     h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(2 * (w / 16 + 2));
     h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
+    h->long_list.ensure(2 * CC_LONG_CAP);
     h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
@@ -1284,6 +1286,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_lookahead = 0;
         c.stat_tiles = c.stat_dirty_tiles = 0;
         c.stat_unprovable = c.stat_unsafe = 0;
+        c.stat_long = 0;
+        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.n_long[i] = 0;
         c.stat_trunc_unknown = 0;
         c.stat_table_rows = 0;
         c.stat_seq_points = 0;
@@ -1361,6 +1365,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->prune_now = dec.prune != 0;
         nodirty = dec.nodirty != 0;
         long long cursor_prev = range_a;
+        long long long_prev = 0;   // Ctl::stat_long at the end of the previous batch
+        bool long_seen = false;    // ... and whether that batch added to it
+        long long long_launches = 0;
         unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
             ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
@@ -1444,6 +1451,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // ... and their long chains (more than CC_CHAIN_MEMB claimants; k_claims leaves the exact count) are replayed
             // by k_chain_long, one workgroup per MC, instead of one point after the other
             const int long_rows = h->allow_long ? scan_rows : 0;
+            // On a larger table long chains are rare on evenly spread data and the rule on skewed data (one population
+            // that takes a third of the events): k_chain_long is launched, over the list k_decide keeps, in the batches
+            // that follow one in which such chains were seen (a function of device counters: every rank decides alike)
+            const bool long_listed = h->allow_long && scan_rows == 0 && long_seen;
+            int* const long_list = long_listed ? h->long_list.p : nullptr;
             // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
             // a batch, then kept up commit by commit
             ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
@@ -1518,7 +1530,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                    dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                    h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks);
+                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 for (int r = 1; r <= Rcur; ++r) {
@@ -1528,7 +1540,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                                        h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
                     if (long_rows > 0)
                         hipLaunchKernelGGL(k_chain_long, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                           told, r, long_rows);
+                                           told, r, long_rows, (const int*)nullptr);
+                    else if (long_listed && ++long_launches > 0)
+                        hipLaunchKernelGGL(k_chain_long, dim3(CC_LONG_CAP), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                           told, r, 0, (const int*)long_list);
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, told, r);
                     if (!nodirty) {
@@ -1537,7 +1552,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
-                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0);
+                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
@@ -1562,6 +1577,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 const long long pts_b = h->hc.cursor - cursor_prev;
                 if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
                 cursor_prev = h->hc.cursor;
+                long_seen = h->hc.stat_long > long_prev;
+                long_prev = h->hc.stat_long;
             }
             {
                 // what the device counted, and the policy's decision for the next batch
@@ -1650,6 +1667,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.lookahead_windows += h->hc.stat_lookahead;
         h->stats.pruned_scan_rows += (int64_t)h->hc.stat_prune_rows;
         h->stats.pruned_scan_full_rows += (int64_t)h->hc.stat_prune_full;
+        h->stats.long_chains += (int64_t)h->hc.stat_long;
+        h->stats.long_chain_launches += long_launches;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {

@@ -61,7 +61,15 @@ struct Table {
 // stages one flag byte per point in LDS.
 #define CC_MAX_WINDOW 49152
 #define CC_CHAIN_MEMB 32
+// Chains longer than the member list: on a table of more than 1 024 rows (no k_claims) the claimant that finds the list
+// full enters the MC in a list of long chains (at most CC_LONG_CAP per round) and marks the counter word with
+// CC_LONG_LISTED; k_chain leaves such a chain to k_chain_long, which replays it in batches of 128 steps instead of one
+// step after the other.
+#define CC_LONG_CAP 512
+#define CC_LONG_LISTED (1ull << 23)
+#ifndef CC_CHAIN_AHEAD
 #define CC_CHAIN_AHEAD 4  // k_chain: points of a chain requested ahead of the step that absorbs them
+#endif
 
 // Lookahead.  While window W is validated, the snapshot scan of window W + 1 already runs - against the table as
 // it is before W's commit.  What that scan could not see is exactly the set of rows W's commit changes or adds:
@@ -155,6 +163,10 @@ struct Ctl {
     // any_new[r]: some decision of round r creates a MC (k_decide); any_up[r]: some add replayed in round r promotes
     // one (k_chain).  Plain flags; while both are clear k_commit_a has nothing to rank.
     int any_new[CC_MAX_ROUNDS + 2], any_up[CC_MAX_ROUNDS + 2];
+    // n_long[r]: chains of existing MCs with more than CC_CHAIN_MEMB claimants that round r replays with k_chain_long
+    // (k_decide of round r - 1 lists them, see CC_LONG_LISTED); stat_long: how many such chains the call has seen
+    int n_long[CC_MAX_ROUNDS + 2];
+    long long stat_long;
     // parameters (cc_params, see include/chronoclust_hip.h)
     double eps_sq, delta_sq, k, inv_k, beta_mu, mu, omicron;
     int pi;

@@ -2171,7 +2171,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 const int* __restrict__ Told, int* __restrict__ Tnew,
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
                                                 int scan_rows, int part_inner, size_t part_outer,
-                                                const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks)
+                                                const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
+                                                int* __restrict__ long_list)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -2363,6 +2364,17 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                 pos = (int)(atomicAdd(cw, 1ull) & 0xFFFFFFull);  // somebody else of this launch restarted it meanwhile
             }
             if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)T * CC_CHAIN_MEMB + pos] = j;
+            else if (pos == CC_CHAIN_MEMB && T < M0) {
+                // the one claimant that finds the list full: a long chain of an existing MC
+                atomicAdd((unsigned long long*)&ctl->stat_long, 1ull);
+                if (long_list != nullptr) {
+                    const int idx = atomicAdd(&ctl->n_long[round + 1], 1);
+                    if (idx < CC_LONG_CAP) {
+                        long_list[(size_t)((round + 1) & 1) * CC_LONG_CAP + idx] = T;
+                        atomicOr(cw, CC_LONG_LISTED);
+                    }
+                }
+            }
         }
     }
 }
@@ -2452,7 +2464,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
     const bool listed = n_memb <= CC_CHAIN_MEMB;
     // a long chain on one of the first long_rows table rows is replayed by k_chain_long (launched right after)
-    if (!listed && t < long_rows && t < ctl->m_rows) return;
+    if (!listed && ((t < long_rows && t < ctl->m_rows) || (cw & CC_LONG_LISTED) != 0ull)) return;
     int sorted_memb = CC_IDX_INF;
     if (listed) {
         const int mine = (gl < n_memb) ? tab.memb[(size_t)t * CC_CHAIN_MEMB + gl] : CC_IDX_INF;
@@ -2660,15 +2672,24 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 
 __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                     Versions ver, Carry car, const int* __restrict__ T, int round,
-                                                    int scan_rows)
+                                                    int scan_rows, const int* __restrict__ long_list)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
-    const int t = blockIdx.x;
     const int M0 = ctl->m_rows;
-    if (t >= M0 || t >= scan_rows) return;
+    // small tables (k_claims): one workgroup per table row; otherwise one per entry of the round's list of long chains
+    int t;
+    if (long_list == nullptr) {
+        t = blockIdx.x;
+        if (t >= scan_rows) return;
+    } else {
+        const int n_listed = min(ctl->n_long[round], CC_LONG_CAP);
+        if ((int)blockIdx.x >= n_listed) return;
+        t = long_list[(size_t)(round & 1) * CC_LONG_CAP + blockIdx.x];
+    }
+    if (t >= M0) return;
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
     const size_t rd = (size_t)(round & 1) * tab.cap + (size_t)t;
     const unsigned long long ft = tab.touch[rd], lt = tab.last[rd];
@@ -3059,7 +3080,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->last_round = 0;
         ctl->fc[0] = 0;
         for (int i = 1; i < CC_MAX_ROUNDS + 2; ++i) ctl->fc[i] = CC_IDX_INF;
-        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) { ctl->any_new[i] = 0; ctl->any_up[i] = 0; }
+        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) { ctl->any_new[i] = 0; ctl->any_up[i] = 0; ctl->n_long[i] = 0; }
     }
 }
 

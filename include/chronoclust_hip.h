@@ -112,6 +112,10 @@ typedef struct cc_stats {
                                     * first point tile of every window) ...              */
     int64_t pruned_scan_full_rows; /* ... and of those, pairs evaluated over all dimensions */
     int64_t window;          /* configured window of the run (cc_tuning.window or the default)  */
+    int64_t long_chains;     /* chains of existing microclusters with more than 32 claimants in a window
+                              * (per validation round) ...                                      */
+    int64_t long_chain_launches; /* ... and launches of k_chain_long over the list of such chains (tables
+                              * of more than 1 024 rows; smaller ones always run it)             */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

@@ -316,6 +316,31 @@ def test_long_chains(g, window, lookahead):
         _check_against_oracle(h, o)
 
 
+@pytest.mark.parametrize("window,lookahead,heavy", [(16384, 0, 0.3), (32768, 3, 0.5), (8192, 2, 0.1), (32768, 0, 0.02)])
+def test_long_chains_on_a_large_table(window, lookahead, heavy):
+    """Skewed populations on a table k_claims does not serve (more than 1 024 microclusters): three of 2 000 blobs take
+    the share `heavy` of the events, so their chains run to thousands of members per window - listed by k_decide,
+    replayed by k_chain_long from the second batch on (the first one still walks them in k_chain) - while the others
+    stay on k_chain's listed path.  heavy = 0.02: chains just over the list's 32 entries."""
+    from oracle import oracle as O
+    n, d, g = 120_000, 6, 2000
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.08))
+    h, o = _hdd(cfg, window=window, lookahead=lookahead), O.OracleHDDStream(cfg)
+    rng = np.random.default_rng(4242)
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    for t in range(2):
+        lab = rng.integers(3, g, n)
+        big = rng.random(n) < heavy
+        lab[big] = rng.integers(0, 3, int(big.sum()))
+        X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 0.004, (n, d)), 0.0, 1.0))
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+    s = h.stats()
+    assert s["rows"] > 1024
+    assert s["long_chains"] > 0 and s["long_chain_launches"] > 0, s
+
+
 def test_windows_with_more_than_32767_creations():
     """k_commit_a ranks a window's creations and promotions in two 16-bit counts packed into one word: a window at
     the largest size (49 152 points) in which EVERY point creates a microcluster (uniform points, a radius threshold
