@@ -4,8 +4,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchronoclust_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("cc_api.hip", "cc_common.h", "cc_online.h", "cc_offline.h", "cc_comm.h", "cc_csv.h",
-                                                   "cc_policy.h")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("cc_api.hip", "cc_common.h", "cc_online.h", "cc_scan.h", "cc_validate.h", "cc_seq.h",
+                                                   "cc_relaxed.h", "cc_points.h", "cc_offline.h", "cc_comm.h", "cc_csv.h", "cc_policy.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "chronoclust_hip.h")
 
 

@@ -1,0 +1,1461 @@
+// chronoclust_amd/csrc: the snapshot scans - k_scan (LDS-staged rows; also the dirty scans), k_scan_u (rows as scalar operands), the pruned chain k_seed / k_seed_merge / k_scan_p, k_merge_partials.  (included by cc_online.h; one translation unit, cc_api.hip)
+#pragma once
+
+// ---------------------------------------------------------------------------------
+// k_scan: points (one or PT per lane, in registers) x MC rows (wave-uniform, staged in LDS)
+// ---------------------------------------------------------------------------------
+
+#define CC_SCAN_TM 16     // MC rows per LDS tile
+// window points per lane of the clean scan at DP == 20 / workgroups per CU it is compiled for (build-time knobs)
+#ifndef CC_SCAN_PT_CLEAN
+#define CC_SCAN_PT_CLEAN 1
+#endif
+#ifndef CC_SCAN_WGS_CLEAN
+#define CC_SCAN_WGS_CLEAN 4
+#endif
+#ifndef CC_SCAN_WGS_CLEAN40
+#define CC_SCAN_WGS_CLEAN40 3
+#endif
+#ifndef CC_SCAN_WGS_DIRTY32
+#define CC_SCAN_WGS_DIRTY32 3
+#endif
+#ifndef CC_SCAN_NW_CLEAN
+#define CC_SCAN_NW_CLEAN 4
+#endif
+template <int DP, bool DIRTY>
+struct ScanShape {
+    static constexpr int PT = (!DIRTY && DP == 20) ? CC_SCAN_PT_CLEAN : 1;
+    // waves per workgroup: same points, disjoint MC sub-ranges, merged through LDS (8 halve the partials but measured
+    // 5 % slower on C2)
+    static constexpr int NW = (!DIRTY && DP == 20) ? CC_SCAN_NW_CLEAN : 4;
+    static constexpr int WGS = (!DIRTY && DP == 20) ? CC_SCAN_WGS_CLEAN
+                               : (DP <= 20 ? 4 : (DP <= 40 ? (DIRTY ? CC_SCAN_WGS_DIRTY32 : (DP == 40 ? CC_SCAN_WGS_CLEAN40 : 3)) : 2));
+};
+// waves per workgroup (template parameter NW): same points, disjoint MC sub-ranges, merged through LDS
+
+
+// One workgroup = NW waves that hold the same 64*PT points in registers.  The MC rows of the launch
+// are split into gridDim.y * NW sub-ranges; each wave streams its sub-range through its own LDS tile
+// (centroid and 1/pref are wave-uniform broadcast reads), keeps the two best candidates per kind and point, and
+// the workgroup writes ONE partial per point (merged in LDS), so the argmin partials in HBM stay small.
+template <int DP, bool FILTER, bool POW2, bool DIRTY, int NW>
+__global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(const Ctl* __restrict__ ctl,
+                                                             const double* __restrict__ X,
+                                                             const double* __restrict__ Xt, Rows rows,
+                                                             const Cand* __restrict__ clean,
+                                                             Cand* __restrict__ part, int round, int mode,
+                                                             size_t part_stride, int shard_rank, int shard_world)
+{
+    constexpr int PT = ScanShape<DP, DIRTY>::PT;  // window points per lane
+    if (DIRTY) CC_LATENCY_KERNEL();
+    // Which window, which rows:
+    //   clean, mode 0: the current window against the table as it is (only if the window has no lookahead scan)
+    //   clean, mode 1: lookahead - the window after the current one (parity `round` of its window_seq), while the
+    //                  current one is being validated; its parameters sit in their own slot of the control block
+    //   dirty, mode 0: the current window against its own version rows
+    //   dirty, mode 1: the current window against the carry set of the previous window (lookahead windows only)
+    int B, m_rows_scan;
+    long long cursor;
+    if (!DIRTY && mode == 1) {
+        const int q = round & 1;
+        B = ctl->la_b[q];
+        m_rows_scan = ctl->la_rows[q];
+        cursor = ctl->la_cursor[q];
+        part += (size_t)q * part_stride;
+    } else {
+        B = ctl->win_b;
+        m_rows_scan = ctl->m_rows;
+        cursor = ctl->cursor;
+        if (!DIRTY) {
+            if (ctl->mode != 0) return;  // this window's snapshot scan ran ahead
+            part += (size_t)(ctl->window_seq & 1ull) * part_stride;
+        }
+    }
+    if (B == 0) return;
+    if (DIRTY && ctl->fc[round - 1] >= B) return;  // already at a fixed point
+    const bool carried = DIRTY && mode == 1;
+    const int car_n = carried ? ((ctl->mode != 0) ? ctl->car_n : 0) : 0;
+    if (carried && car_n == 0) return;
+    const int bx = (int)blockIdx.x;
+    {
+    const int j0 = bx * (64 * PT);
+    if (j0 >= B) return;
+    if (DIRTY && rows.skip[bx] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
+    const int d = ctl->d;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
+    const int S = gridDim.y;  // partials per point
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    // a version row i only matters to points j > i: the dirty scan of this tile covers rows [0, j0 + 64*PT - 1)
+    // (a carried row matters to every point up to the first one that targets its MC)
+    // Exact multi-GPU path: the table is replicated, rank r of `shard_world` scans the rows
+    // [r * ceil(M / world), (r + 1) * ceil(M / world)) of the snapshot and the ranks exchange their per-point
+    // candidates afterwards (k_merge_partials + all-gather); shard_world == 1: the whole table.
+    int row_lo = 0, row_hi = DIRTY ? (carried ? car_n : min(B, j0 + 64 * PT - 1)) : m_rows_scan;
+    if (!DIRTY && shard_world > 1) cc_shard_range(m_rows_scan, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int nrows = row_hi - row_lo;
+    // dirty scan: sub-ranges are whole 16-row tiles so that the per-tile displacement maxima line up
+    const int per = DIRTY ? (((nrows + nsub - 1) / nsub + CC_SCAN_TM - 1) / CC_SCAN_TM) * CC_SCAN_TM
+                          : (nrows + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
+    const int ntiles = (per + CC_SCAN_TM - 1) / CC_SCAN_TM;  // the same for every wave of the workgroup
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const Par par = cc_load_par(ctl);
+    const double inv_k = par.inv_k;
+    const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    // FILTER = false: the host knows that the pdim filter of hddstream.py:317-321 is vacuous (pi >= d)
+    const bool filter = FILTER && par.filter != 0;
+
+    // LDS: per-wave tiles while scanning, then (same bytes) the candidate exchange of the final merge
+    constexpr int TILE_DOUBLES = NW * CC_SCAN_TM * DP;
+    constexpr int TILE_BYTES = TILE_DOUBLES * 16 + NW * CC_SCAN_TM * 12;
+    constexpr int MERGE_BYTES = (NW - 1) * PT * 4 * 64 * (int)sizeof(Cand);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
+    double* const s_c_base = reinterpret_cast<double*>(smem) + (size_t)wv * CC_SCAN_TM * DP;
+    double* const s_s_base = reinterpret_cast<double*>(smem) + TILE_DOUBLES + (size_t)wv * CC_SCAN_TM * DP;
+    int* const s_int = reinterpret_cast<int*>(smem + (size_t)TILE_DOUBLES * 16) + wv * CC_SCAN_TM * 3;
+    int* const s_kind_w = s_int;
+    int* const s_key_w = s_int + CC_SCAN_TM;
+    int* const s_next_w = s_int + 2 * CC_SCAN_TM;
+
+    double p[PT][DP];
+    int jj[PT];
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        jj[t] = j0 + t * 64 + lane;
+        valid[t] = jj[t] < B;
+    }
+    // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave; when that
+    // rules out every tile of the sub-range the wave only hands its seeds on and never loads its points
+    // (per kind: a version competes in the list of its kind, against that list's threshold)
+    double wave_tau[2] = {-CC_INF, -CC_INF};
+    bool any_tile = true;
+    if (DIRTY) {
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            double wt = CC_INF;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const double tj = valid[t] ? rows.tau[(size_t)jj[t] * 2 + K] : CC_INF;
+                wt = tj < wt ? tj : wt;
+            }
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(wt, off);
+                wt = o < wt ? o : wt;
+            }
+            wave_tau[K] = wt;
+        }
+        any_tile = false;
+        for (int rt = r0; rt < r1; rt += CC_SCAN_TM)
+            if (!(cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
+                  cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1])))
+                any_tile = true;
+    }
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[t][i] = 0.0;
+        if (!any_tile) continue;
+        // Xt is the dimension-major copy of the points: consecutive lanes read consecutive doubles
+        const double* xp = Xt + cursor + (valid[t] ? jj[t] : 0);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[t][i] = (valid[t] && i < d) ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    // fused distance terms (see cc_fma_term) are exact for this wave's points?
+    bool fuse_wave = POW2 && par.k >= 0x1p-64 && par.k <= 0x1p64;
+    if (POW2) {
+        bool tn = false;
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int i = 0; i < DP; ++i) tn = tn || cc_is_tiny(p[t][i]);
+        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+    }
+
+    // running best-two per kind and point: [kind][pt][rank]
+    double bd[2][PT][2];
+    int bk[2][PT][2], bs[2][PT][2];
+    double cap[2][PT];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                bd[kd][t][r] = (DIRTY || valid[t]) ? CC_INF : -CC_INF;
+                bk[kd][t][r] = CC_IDX_INF;
+                bs[kd][t][r] = -1;
+            }
+            cap[kd][t] = CC_INF;
+        }
+    if (DIRTY) {
+        // caps and first candidates prepared once per point by k_dseed (`clean` is the seed table here)
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            if (!valid[t]) continue;
+#pragma unroll
+            for (int kd = 0; kd < 2; ++kd) {
+                const Cand sd = clean[(size_t)jj[t] * 4 + kd * 2];
+                cap[kd][t] = clean[(size_t)jj[t] * 4 + kd * 2 + 1].dist;
+                bd[kd][t][0] = sd.dist; bk[kd][t][0] = sd.key; bs[kd][t][0] = sd.slot;
+            }
+        }
+    }
+
+    for (int tt = 0; tt < ntiles; ++tt) {
+        const int rt = r0 + tt * CC_SCAN_TM;
+        const int tm = __builtin_amdgcn_readfirstlane(max(0, min(CC_SCAN_TM, r1 - rt)));
+        if (tm == 0) break;
+        if (DIRTY) {
+            if (cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
+                cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1]))
+                continue;  // nothing in this tile can matter
+        }
+        CC_WAVE_SYNC();
+        bool fuse_tile = false;
+        int rm_lo = 0, rm_hi = 0;  // lane m < CC_SCAN_TM: which dimensions of tile row m are scaled by 1/k
+        {
+            // the tile is one contiguous block of tm * d doubles per column: a straight copy, all loads of the
+            // tile in flight before the first LDS store (LDS row stride = d; dimensions d..DP-1 are never read)
+            constexpr int NL = (CC_SCAN_TM * DP + 63) / 64;
+            const double* gc = rows.cen + (size_t)rt * d;
+            const double* gs = rows.scl + (size_t)rt * d;
+            double tc[NL], ts[NL];
+            // LDS rows are DP doubles long (compile-time stride); when d < DP the padding holds (0, 1): zero terms
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;  // index into the padded tile
+                const int m = e / DP, i = e - m * DP;
+                const bool in = (m < tm) && (i < d);
+                const int ge = m * d + i;     // index into the contiguous global block (== e when d == DP)
+                tc[q] = in ? gc[ge] : 0.0;
+                ts[q] = in ? gs[ge] : 1.0;
+            }
+            bool tn = false;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;
+                if (e < CC_SCAN_TM * DP) { s_c_base[e] = tc[q]; s_s_base[e] = ts[q]; }
+                if (POW2) tn = tn || cc_is_tiny(tc[q]);
+            }
+            if (POW2) fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+            if (POW2 && !DIRTY) {
+                // When k is a power of two the distance operand of a dimension is 1 or 1/k: one bit.  The 64 * NL
+                // staged operands give NL ballot words = the tile's CC_SCAN_TM * DP bits in row order; lane m keeps
+                // the DP bits of row m, and the fused row loop builds its operands from them with scalar selects
+                // instead of reading them from LDS (the loop is bound by wave-uniform LDS reads otherwise).
+                unsigned long long rmask = 0ull;
+                const int off = (lane & (CC_SCAN_TM - 1)) * DP;
+#pragma unroll
+                for (int q = 0; q < NL; ++q) {
+                    const unsigned long long w = __builtin_amdgcn_ballot_w64(ts[q] != 1.0);
+                    const int rel = off - 64 * q;
+                    const unsigned long long a = (rel >= 0 && rel < 64) ? (w >> (rel & 63)) : 0ull;
+                    const unsigned long long b = (rel < 0 && rel > -DP) ? (w << ((-rel) & 63)) : 0ull;
+                    rmask |= a | b;
+                }
+                if (DP < 64) rmask &= (1ull << (DP & 63)) - 1ull;
+                rm_lo = (int)(unsigned)(rmask & 0xFFFFFFFFull);
+                rm_hi = (int)(unsigned)(rmask >> 32);
+            }
+        }
+        // kinds of the tile's rows as two wave-uniform bit masks (clean scan) / LDS columns (dirty scan)
+        unsigned pmask = 0, omask = 0;
+        if (!DIRTY) {
+            const int kd = (lane < tm) ? rows.kind[rt + lane] : CC_KIND_DEAD;
+            pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
+            omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
+        } else if (lane < tm) {
+            s_kind_w[lane] = rows.kind[rt + lane];
+            s_key_w[lane] = rows.key[rt + lane];
+            if (!carried) s_next_w[lane] = rows.next[rt + lane];
+            else if (rows.kind[rt + lane] == CC_KIND_DEAD) s_next_w[lane] = -1;  // not a carried row (no slot either)
+            else {
+                // a carried row is live up to and including the first point of this window that targets its MC
+                const unsigned long long tc = rows.touch[(size_t)(round & 1) * rows.cap + (size_t)rows.slot[rt + lane]];
+                s_next_w[lane] = ((tc >> 20) == stamp) ? (0xFFFFF - (int)(tc & 0xFFFFFull)) : CC_IDX_INF;
+            }
+        }
+        // dirty scan: the rows of the tile that can matter to some point of the wave (the per-tile test above, per row;
+        // while MCs are being created or promoted almost every tile holds a row without a bound, but few rows do)
+        unsigned rowmask = 0xFFFFu;
+        if (DIRTY) {
+            const double rq = (lane < tm) ? rows.dsq[rt + lane] : 0.0;
+            const int rk = (lane < tm) ? rows.kind[rt + lane] : CC_KIND_DEAD;
+            const double wt = (rk == CC_KIND_PCORE) ? wave_tau[0] : wave_tau[1];
+            rowmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < tm && rk != CC_KIND_DEAD && !(rq < CC_INF && sqrt(rq) * (1.0 + 1e-9) < wt));
+        }
+        CC_WAVE_SYNC();
+
+        if (!DIRTY) {
+            // Clean scan: a lean row loop.  Rows run to the last dimension (the second-best bound is never tight
+            // enough to drop a row early on 64 unrelated points: measured), so there are no exit checks.  The
+            // running best-two hold (distance, row) only; while no distance of the wave equals a held one the
+            // update is pure selection (min / max and three selects).  Exact ties - the only place where the
+            // list-order keys decide (hddstream.py:326/373: strict `<`, first in list order wins) - and the pdim
+            // filter take the general path, which fetches the keys it needs.
+            // KSEL: 0 / 1 = every row of the tile is a pcore / outlier MC (no kind test per row, the running pair of that
+            // kind stays in its registers), -1 = mixed tile
+            auto clean_rows = [&](auto FUSEC, auto KSELC) {
+            constexpr bool FUSE = decltype(FUSEC)::value;
+            constexpr int KSEL = decltype(KSELC)::value;
+            for (int m = 0; m < tm; ++m) {
+                double acc[PT];
+                // (rows of an even DP start on 16-byte boundaries: ds_read_b128)
+                const double* rc = (DP % 2 == 0) ? (const double*)__builtin_assume_aligned(s_c_base + m * DP, 16) : s_c_base + m * DP;
+                const double* rs = (DP % 2 == 0) ? (const double*)__builtin_assume_aligned(s_s_base + m * DP, 16) : s_s_base + m * DP;
+                const unsigned mlo = FUSE ? (unsigned)__builtin_amdgcn_readlane(rm_lo, m) : 0u;
+                const unsigned mhi = (FUSE && DP > 32) ? (unsigned)__builtin_amdgcn_readlane(rm_hi, m) : 0u;
+                const double one = 1.0;
+                // centroid of the row, two dimensions per LDS read
+                typedef double cc_d2 __attribute__((ext_vector_type(2)));
+                static_assert(DP % 2 == 0, "padded dimensionalities are even");
+                const cc_d2* rc2 = reinterpret_cast<const cc_d2*>(rc);
+                auto dim_step = [&](auto IC) {
+                    constexpr int i = decltype(IC)::value;
+                    const cc_d2 cp = rc2[i >> 1];
+                    const double c = (i & 1) ? cp.y : cp.x;
+                    // fused: the operand comes from the row's bit mask (wave-uniform, a scalar select)
+                    double sc;
+                    if constexpr (FUSE) sc = cc_sel_scale<(i & 31)>(i < 32 ? mlo : mhi, inv_k, one);
+                    else sc = rs[i];
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        double x = p[t][i] - c;       // mc_functions.py:37
+                        x = x * x;                    // :38
+                        // :39 + :41, left to right; the terms are >= +0, so 0.0 + x is x and the first one starts the sum
+                        if (FUSE) {
+                            acc[t] = (i == 0) ? x * sc : __builtin_fma(x, sc, acc[t]);  // see CC_TINY
+                        } else {
+                            x = POW2 ? x * sc : x / sc;
+                            acc[t] = (i == 0) ? x : acc[t] + x;
+                        }
+                    }
+                };
+                cc_static_for<DP>(dim_step);
+                const int rowg = rt + m;
+                auto update = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) {
+                        const double a = acc[t];
+                        double& d0 = bd[K][t][0];
+                        double& d1 = bd[K][t][1];
+                        int& s0 = bs[K][t][0];
+                        int& s1 = bs[K][t][1];
+                        // (lanes without a point hold -inf and never enter; no wave-level skip: with the few rows a
+                        // wave sees, some lane enters on almost every row, and straight-line code updates in place)
+                        bool ins = a < d1;    // enters the pair
+                        bool first = a < d0;  // ... as its first element
+                        const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                        const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                        if ((e1 | e0) != 0ull) {
+                            if (a == d1 || a == d0) {
+                                const int key = rows.key[rowg];
+                                if (a == d1) ins = key < (s1 >= 0 ? rows.key[s1] : CC_IDX_INF);
+                                if (a == d0) first = key < (s0 >= 0 ? rows.key[s0] : CC_IDX_INF);
+                            }
+                        }
+                        if (K == 0 && filter) {
+                            if (ins) {
+                                // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                                int ne1 = 0;
+                                cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
+                                                    rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
+                                if (ne1 > par.pi) ins = false;
+                            }
+                            first = first && ins;
+                            d1 = first ? d0 : (ins ? a : d1);
+                            d0 = first ? a : d0;
+                        } else {
+                            // every row enters on distance alone: the distances of the pair are a plain selection
+                            d1 = cc_vmin(d1, cc_vmax(d0, a));
+                            d0 = cc_vmin(d0, a);
+                        }
+                        s1 = first ? s0 : (ins ? rowg : s1);
+                        s0 = first ? rowg : s0;
+                    }
+                };
+                if constexpr (KSEL == 0) update(std::integral_constant<int, 0>{});
+                else if constexpr (KSEL == 1) update(std::integral_constant<int, 1>{});
+                else {
+                    if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+                    else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+                }
+            }
+            };
+            const unsigned full = (tm >= 32) ? 0xFFFFFFFFu : ((1u << tm) - 1u);
+            if (POW2 && fuse_tile) {
+                if (pmask == full) clean_rows(std::true_type{}, std::integral_constant<int, 0>{});
+                else if (omask == full) clean_rows(std::true_type{}, std::integral_constant<int, 1>{});
+                else clean_rows(std::true_type{}, std::integral_constant<int, -1>{});
+            } else clean_rows(std::false_type{}, std::integral_constant<int, -1>{});
+            continue;
+        }
+
+        // The dirty scan (few waves, early exit after 4 dimensions) takes two MC rows per iteration: two
+        // independent accumulation chains hide each other's latency.  The clean scan mostly runs rows to the end,
+        // where pairing only adds work, and takes one.
+        constexpr bool RB2 = DIRTY;
+        auto dirty_rows = [&](auto FUSEC) {
+        constexpr bool FUSE = decltype(FUSEC)::value;
+        for (int m = 0; m < tm; m += (RB2 ? 2 : 1)) {
+            const int kindA = ((rowmask >> m) & 1u) ? __builtin_amdgcn_readfirstlane(s_kind_w[m]) : CC_KIND_DEAD;
+            const int kindB = (RB2 && m + 1 < tm && ((rowmask >> (m + 1)) & 1u))
+                                  ? __builtin_amdgcn_readfirstlane(s_kind_w[m + 1]) : CC_KIND_DEAD;
+            double boundA[PT], boundB[PT];
+            auto row_bounds = [&](int mm, int kind, double (&bound)[PT]) -> bool {
+                if (kind == CC_KIND_DEAD) {
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) bound[t] = -1.0;
+                    return false;
+                }
+                const int rowg = rt + mm;
+                bool anyact = false;
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    bool a = valid[t];
+                    if (DIRTY) {
+                        const int nx = __builtin_amdgcn_readfirstlane(s_next_w[mm]);
+                        a = a && (carried || rowg < jj[t]) && jj[t] <= nx;
+                        const double b1 = (kind == 0) ? bd[0][t][0] : bd[1][t][0];
+                        const double cp = (kind == 0) ? cap[0][t] : cap[1][t];
+                        bound[t] = b1 < cp ? b1 : cp;
+                    } else {
+                        bound[t] = (kind == 0) ? bd[0][t][1] : bd[1][t][1];
+                    }
+                    if (!a) bound[t] = -1.0;
+                    anyact = anyact || a;
+                }
+                return __builtin_amdgcn_ballot_w64(anyact) != 0ull;
+            };
+            const bool liveA = row_bounds(m, kindA, boundA);
+            const bool liveB = RB2 ? row_bounds(m + 1, kindB, boundB) : false;
+            if (!liveA && !liveB) continue;
+
+            double accA[PT], accB[PT];
+#pragma unroll
+            for (int t = 0; t < PT; ++t) { accA[t] = 0.0; accB[t] = 0.0; }
+            bool alive = true;
+            const int mB = (m + 1 < CC_SCAN_TM) ? m + 1 : m;
+#pragma unroll
+            for (int i0 = 0; i0 < DP; i0 += 4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = i0 + q;
+                    if (i < DP) {
+                        const double cA = s_c_base[m * DP + i], sA = s_s_base[m * DP + i];
+                        const double cB = s_c_base[mB * DP + i], sB = s_s_base[mB * DP + i];
+#pragma unroll
+                        for (int t = 0; t < PT; ++t) {
+                            double x = p[t][i] - cA;  // mc_functions.py:37
+                            x = x * x;                // :38
+                            if (FUSE) accA[t] = __builtin_fma(x, sA, accA[t]);  // :39 + :41 in one rounding, see CC_TINY
+                            else {
+                                x = POW2 ? x * sA : x / sA; // :39
+                                accA[t] = accA[t] + x;    // :41, left to right
+                            }
+                            if (RB2) {
+                                double y = p[t][i] - cB;
+                                y = y * y;
+                                if (FUSE) accB[t] = __builtin_fma(y, sB, accB[t]);
+                                else {
+                                    y = POW2 ? y * sB : y / sB;
+                                    accB[t] = accB[t] + y;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (i0 + 4 < DP) {
+                    // terms are >= 0: once every point of the wave is past its bound for both rows, neither MC
+                    // can enter any candidate list, whatever the remaining dimensions add
+                    bool q = false;
+#pragma unroll
+                    for (int t = 0; t < PT; ++t) q = q || (accA[t] <= boundA[t]) || (RB2 && accB[t] <= boundB[t]);
+                    if (__builtin_amdgcn_ballot_w64(q) == 0ull) {
+                        alive = false;
+                        break;
+                    }
+                }
+            }
+            if (!alive) continue;
+
+            auto insert_row = [&](int mm, int kind, const double (&acc)[PT], const double (&bound)[PT]) {
+                const int rowg = rt + mm;
+                const int rowc = carried ? CC_CAR_BASE + rowg : rowg;  // what the candidate's slot says
+                const int key = s_key_w[mm];
+#pragma unroll
+                for (int t = 0; t < PT; ++t) {
+                    if (!(acc[t] <= bound[t])) continue;
+                    auto consider = [&](auto KC) {
+                        constexpr int K = decltype(KC)::value;
+                        constexpr int R = DIRTY ? 0 : 1;  // rank that a newcomer has to beat
+                        if (!cand_less(acc[t], key, bd[K][t][R], bk[K][t][R])) return;
+                        if (K == 0 && filter) {
+                            // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                            int ne1 = 0;
+                            cc_tentative_radius(rows.cf1 + (size_t)rowg * d, rows.cf2 + (size_t)rowg * d,
+                                                rows.w[rowg], X + (cursor + jj[t]) * d, d, par, nullptr, &ne1);
+                            if (ne1 > par.pi) return;
+                        }
+                        if (cand_less(acc[t], key, bd[K][t][0], bk[K][t][0])) {
+                            bd[K][t][1] = bd[K][t][0]; bk[K][t][1] = bk[K][t][0]; bs[K][t][1] = bs[K][t][0];
+                            bd[K][t][0] = acc[t]; bk[K][t][0] = key; bs[K][t][0] = rowc;
+                        } else {
+                            bd[K][t][1] = acc[t]; bk[K][t][1] = key; bs[K][t][1] = rowc;
+                        }
+                    };
+                    if (kind == 0) consider(std::integral_constant<int, 0>{});
+                    else consider(std::integral_constant<int, 1>{});
+                }
+            };
+            if (liveA) insert_row(m, kindA, accA, boundA);
+            if (RB2 && liveB) insert_row(m + 1, kindB, accB, boundB);
+        }
+        };
+        if (POW2 && fuse_tile) dirty_rows(std::true_type{});
+        else dirty_rows(std::false_type{});
+    }
+
+    if (!DIRTY) {
+        // the clean scan kept (distance, row) only: the list-order keys of the survivors
+#pragma unroll
+        for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+            for (int t = 0; t < PT; ++t)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) bk[kd][t][r] = bs[kd][t][r] >= 0 ? rows.key[bs[kd][t][r]] : CC_IDX_INF;
+    }
+    // merge the waves' candidates through LDS; wave 0 writes the workgroup's partial
+    Cand* const s_m = reinterpret_cast<Cand*>(smem);  // [NW - 1][PT][4][64], reuses the tile bytes
+    auto s_m_at = [&](int w, int t, int c) -> Cand& { return s_m[((w * PT + t) * 4 + c) * 64 + lane]; };
+    __syncthreads();  // every wave is done with its tile
+    if (wv > 0) {
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            s_m_at(wv - 1, t, 0) = Cand{bd[0][t][0], bk[0][t][0], bs[0][t][0]};
+            s_m_at(wv - 1, t, 1) = Cand{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
+            s_m_at(wv - 1, t, 2) = Cand{bd[1][t][0], bk[1][t][0], bs[1][t][0]};
+            s_m_at(wv - 1, t, 3) = Cand{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+        }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        if (!valid[t]) continue;
+        Cand c0{bd[0][t][0], bk[0][t][0], bs[0][t][0]}, c1{bd[0][t][1], bk[0][t][1], bs[0][t][1]};
+        Cand c2{bd[1][t][0], bk[1][t][0], bs[1][t][0]}, c3{bd[1][t][1], bk[1][t][1], bs[1][t][1]};
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) {
+            cc_top2_push(c0, c1, s_m_at(w, t, 0));
+            cc_top2_push(c0, c1, s_m_at(w, t, 1));
+            cc_top2_push(c2, c3, s_m_at(w, t, 2));
+            cc_top2_push(c2, c3, s_m_at(w, t, 3));
+        }
+        if (DIRTY) {
+            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 2;
+            o[0] = c0;
+            o[1] = c2;
+        } else {
+            Cand* o = part + ((size_t)jj[t] * S + blockIdx.y) * 4;
+            o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+        }
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// k_scan_u: the snapshot scan with the MC rows as scalar operands.  Same result as k_scan<DP, false, true, false>
+// for d == DP (no pdim filter, k a power of two).  A row's centroid is the same for all 64 points of a wave: it is
+// read with scalar loads (through the scalar cache, into SGPRs) and enters the FP64 instructions as their scalar
+// operand; nothing of the row loop goes through LDS, whose data return rate k_scan's wave-uniform reads are bound by.
+// The loads run one chunk (up to ten dimensions) ahead of the arithmetic: a chunk is requested right after the first
+// use of the one before it, the first chunk of the next row after the first use of a row's last one (scalar loads
+// return out of order, so a wait is always for everything outstanding: at each wait exactly one chunk is).
+// Per tile of 16 rows the wave still reads the tile's 1/pref values (and the centroids, for the CC_TINY test) with
+// coalesced vector loads: the ballots of `!= 1` give every row's bit mask, from which the scaled operands of two
+// dimensions at a time are selected (scalar instructions), as in k_scan.
+// ---------------------------------------------------------------------------------
+// workgroups per CU the kernel is compiled for (register budget): the points of a lane alone are 2 * DP registers
+#ifndef CC_SCANU_WGS40
+#define CC_SCANU_WGS40 4  // (d = 40 at four per CU spills two registers and still measured 6 % faster than three per CU)
+#endif
+template <int DP>
+struct ScanUShape {
+    static constexpr int WGS = DP <= 32 ? 4 : (DP <= 40 ? CC_SCANU_WGS40 : 2);
+};
+// operands of dimensions BIT and BIT + 1 from a row's bit mask
+template <int BIT>
+__device__ __forceinline__ void cc_sel_scale2(unsigned mask, double scaled, double one, double& o0, double& o1)
+{
+    asm("s_bitcmp1_b32 %2, %3\n\ts_cselect_b64 %0, %5, %6\n\ts_bitcmp1_b32 %2, %4\n\ts_cselect_b64 %1, %5, %6"
+        : "=&s"(o0), "=&s"(o1)
+        : "s"(mask), "n"(BIT), "n"(BIT + 1), "s"(scaled), "s"(one)
+        : "scc");
+}
+
+// `row`, usable only once `dep` has been computed: orders a scalar load after the first use of the previous one's data
+__device__ __forceinline__ int cc_after(int row, double dep)
+{
+    asm("" : "+s"(row) : "v"(dep));
+    return row;
+}
+
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                                 const double* __restrict__ g_cen,
+                                                                 const double* __restrict__ g_scl,
+                                                                 const int* __restrict__ g_kind,
+                                                                 const int* __restrict__ g_key, Cand* __restrict__ part,
+                                                                 int round, int mode, size_t part_stride, int shard_rank,
+                                                                 int shard_world)
+{
+    static_assert(DP % 2 == 0 && DP >= 4 && DP <= 64, "padded dimensionalities are even");
+    // a row is read in NC chunks of whole pairs of dimensions (at most ten dimensions: 20 SGPRs), alternately into two
+    // buffers; NC is even, so the first chunk of the next row follows the last one of a row in the other buffer
+    constexpr int NP = DP / 2;
+    constexpr int NC = 2 * ((NP + 9) / 10);
+    constexpr int CH_MAX = 2 * ((NP + NC - 1) / NC);
+    int B, m_rows_scan;
+    long long cursor;
+    if (mode == 1) {
+        const int q = round & 1;
+        B = ctl->la_b[q];
+        m_rows_scan = ctl->la_rows[q];
+        cursor = ctl->la_cursor[q];
+        part += (size_t)q * part_stride;
+    } else {
+        B = ctl->win_b;
+        m_rows_scan = ctl->m_rows;
+        cursor = ctl->cursor;
+        if (ctl->mode != 0) return;  // this window's snapshot scan ran ahead
+        part += (size_t)(ctl->window_seq & 1ull) * part_stride;
+    }
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 64;
+    if (j0 >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    int row_lo = 0, row_hi = m_rows_scan;
+    if (shard_world > 1) cc_shard_range(m_rows_scan, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int nrows = row_hi - row_lo;
+    const int per = (nrows + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const double k = ctl->k;
+    const double inv_k = ctl->inv_k;
+    const int jj = j0 + lane;
+    const bool valid = jj < B;
+
+    double p[DP];
+    {
+        const double* xp = Xt + cursor + (valid ? jj : 0);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    bool fuse_wave = k >= 0x1p-64 && k <= 0x1p64;
+    {
+        bool tn = false;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) tn = tn || cc_is_tiny(p[i]);
+        fuse_wave = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+    }
+    // running best-two per kind: distances and rows ([kind][rank]); lanes without a point never enter
+    double bd[2][2];
+    int bs[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bd[kd][r] = valid ? CC_INF : -CC_INF;
+            bs[kd][r] = -1;
+        }
+
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        // first half of the tile's first row (in flight during the tile's vector loads; the row loop then keeps half a
+        // row ahead)
+        double buf[2][CH_MAX];
+        {
+            const double* __restrict__ c0 = g_cen + (size_t)rt * DP;
+#pragma unroll
+            for (int i = 0; i < 2 * (NP / NC); ++i) buf[0][i] = c0[i];
+        }
+        // the tile's 1/pref values and centroids, coalesced: bit masks of the rows, CC_TINY test
+        constexpr int NL = (CC_SCAN_TM * DP + 63) / 64;
+        int rm_lo = 0, rm_hi = 0;
+        bool fuse_tile;
+        {
+            const double* gc = g_cen + (size_t)rt * DP;
+            const double* gs = g_scl + (size_t)rt * DP;
+            unsigned long long rmask = 0ull;
+            bool tn = false;
+            const int off = (lane & (CC_SCAN_TM - 1)) * DP;
+#pragma unroll
+            for (int q = 0; q < NL; ++q) {
+                const int e = lane + q * 64;
+                const bool in = e < tm * DP;
+                const double tc = in ? gc[e] : 0.0;
+                const double ts = in ? gs[e] : 1.0;
+                tn = tn || cc_is_tiny(tc);
+                const unsigned long long w = __builtin_amdgcn_ballot_w64(ts != 1.0);
+                const int rel = off - 64 * q;
+                const unsigned long long a = (rel >= 0 && rel < 64) ? (w >> (rel & 63)) : 0ull;
+                const unsigned long long b = (rel < 0 && rel > -DP) ? (w << ((-rel) & 63)) : 0ull;
+                rmask |= a | b;
+            }
+            if (DP < 64) rmask &= (1ull << (DP & 63)) - 1ull;
+            rm_lo = (int)(unsigned)(rmask & 0xFFFFFFFFull);
+            rm_hi = (int)(unsigned)(rmask >> 32);
+            fuse_tile = fuse_wave && __builtin_amdgcn_ballot_w64(tn) == 0ull;
+        }
+        unsigned pmask, omask;
+        {
+            const int kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+            pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
+            omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
+        }
+        auto rows_of_tile = [&](auto FUSEC, auto KSELC) {
+            constexpr bool FUSE = decltype(FUSEC)::value;
+            constexpr int KSEL = decltype(KSELC)::value;
+            for (int m = 0; m < tm; ++m) {
+                const unsigned mlo = (unsigned)__builtin_amdgcn_readlane(rm_lo, m);
+                const unsigned mhi = (DP > 32) ? (unsigned)__builtin_amdgcn_readlane(rm_hi, m) : 0u;
+                const int rowg = rt + m;
+                const int rown = min(rowg + 1, rt + tm - 1);  // (the last row of a tile requests its own first half again)
+                const double one = 1.0;
+                double acc = 0.0;
+                // one pair of dimensions: mc_functions.py:37-41, left to right
+                auto pair_step = [&](auto IC, double c0, double c1, double x0) {
+                    constexpr int i = decltype(IC)::value;
+                    double s0, s1;
+                    cc_sel_scale2<(i & 31)>(i < 32 ? mlo : mhi, inv_k, one, s0, s1);
+                    double x = x0;            // p[i] - c0, made by the caller
+                    double y = p[i + 1] - c1;
+                    x = x * x;
+                    y = y * y;
+                    if (FUSE) {
+                        acc = (i == 0) ? x * s0 : __builtin_fma(x, s0, acc);  // :39 + :41 in one rounding, see CC_TINY
+                        acc = __builtin_fma(y, s1, acc);
+                    } else {
+                        x = x * s0;  // :39 (the divisor is a power of two)
+                        y = y * s1;
+                        acc = (i == 0) ? x : acc + x;  // :41
+                        acc = acc + y;
+                    }
+                };
+                cc_static_for<NC>([&](auto CC) {
+                    constexpr int c = decltype(CC)::value;
+                    constexpr int lo = 2 * (c * NP / NC), hi = 2 * ((c + 1) * NP / NC);        // this chunk's dimensions
+                    constexpr int cn = (c + 1) % NC;                                          // the chunk requested now
+                    constexpr int nlo = 2 * (cn * NP / NC), nhi = 2 * ((cn + 1) * NP / NC);
+                    // first use of the chunk requested one chunk ago: the wait is here, with nothing else outstanding
+                    const double x0 = p[lo] - buf[c & 1][0];
+                    // wave-uniform address: scalar loads; of this row, or of the next one after the last chunk
+                    const double* __restrict__ nx = g_cen + (size_t)cc_after(c + 1 < NC ? rowg : rown, x0) * DP;
+#pragma unroll
+                    for (int i = 0; i < nhi - nlo; ++i) buf[cn & 1][i] = nx[nlo + i];
+                    cc_static_for<(hi - lo) / 2>([&](auto QC) {
+                        constexpr int i = 2 * decltype(QC)::value;
+                        pair_step(std::integral_constant<int, lo + i>{}, buf[c & 1][i], buf[c & 1][i + 1],
+                                  (i == 0) ? x0 : p[lo + i] - buf[c & 1][i]);
+                    });
+                });
+                auto update = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+                    const double a = acc;
+                    double& d0 = bd[K][0];
+                    double& d1 = bd[K][1];
+                    int& s0 = bs[K][0];
+                    int& s1 = bs[K][1];
+                    bool ins = a < d1;
+                    bool first = a < d0;
+                    // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+                    const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                    const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                    if ((e1 | e0) != 0ull) {
+                        if (a == d1 || a == d0) {
+                            const int key = g_key[rowg];
+                            if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                            if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                        }
+                    }
+                    d1 = cc_vmin(d1, cc_vmax(d0, a));
+                    d0 = cc_vmin(d0, a);
+                    s1 = first ? s0 : (ins ? rowg : s1);
+                    s0 = first ? rowg : s0;
+                };
+                if constexpr (KSEL == 0) update(std::integral_constant<int, 0>{});
+                else if constexpr (KSEL == 1) update(std::integral_constant<int, 1>{});
+                else {
+                    if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{});
+                    else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{});
+                }
+            }
+        };
+        const unsigned full = (1u << tm) - 1u;
+        if (fuse_tile) {
+            if (pmask == full) rows_of_tile(std::true_type{}, std::integral_constant<int, 0>{});
+            else if (omask == full) rows_of_tile(std::true_type{}, std::integral_constant<int, 1>{});
+            else rows_of_tile(std::true_type{}, std::integral_constant<int, -1>{});
+        } else rows_of_tile(std::false_type{}, std::integral_constant<int, -1>{});
+    }
+
+    // the list-order keys of the survivors, then the waves' candidates merged through LDS as in k_scan
+    int bk[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bk[kd][r] = bs[kd][r] >= 0 ? g_key[bs[kd][r]] : CC_IDX_INF;
+    __shared__ Cand s_m[(NW > 1 ? NW - 1 : 1) * 4 * 64];
+    auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 4 + c) * 64 + lane]; };
+    if (wv > 0) {
+        s_m_at(wv - 1, 0) = Cand{bd[0][0], bk[0][0], bs[0][0]};
+        s_m_at(wv - 1, 1) = Cand{bd[0][1], bk[0][1], bs[0][1]};
+        s_m_at(wv - 1, 2) = Cand{bd[1][0], bk[1][0], bs[1][0]};
+        s_m_at(wv - 1, 3) = Cand{bd[1][1], bk[1][1], bs[1][1]};
+    }
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+    Cand c0{bd[0][0], bk[0][0], bs[0][0]}, c1{bd[0][1], bk[0][1], bs[0][1]};
+    Cand c2{bd[1][0], bk[1][0], bs[1][0]}, c3{bd[1][1], bk[1][1], bs[1][1]};
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        cc_top2_push(c0, c1, s_m_at(w, 0));
+        cc_top2_push(c0, c1, s_m_at(w, 1));
+        cc_top2_push(c2, c3, s_m_at(w, 2));
+        cc_top2_push(c2, c3, s_m_at(w, 3));
+    }
+    Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
+// The PRUNED snapshot scan: k_seed -> k_seed_merge -> k_scan_p.  Same contract as k_scan_u (per point and kind the
+// best candidates by (projected distance, list order)), for a fraction of its arithmetic.
+//
+// A distance is a sum of non-negative terms taken left to right (mc_functions.py:37-41), so its partial sums never
+// decrease: a row whose partial sum already exceeds a threshold T cannot have a distance <= T.  With T well above the
+// distance of the point's nearest microcluster, almost every row drops out after four or eight dimensions - for all 64
+// points of a wave at once, because the other microclusters are far from every one of them (the test is wave-uniform:
+// a row is abandoned when ALL lanes are over their thresholds; otherwise its distance is completed for all lanes).
+//   k_seed        per point and kind the row with the smallest UNSCALED squared distance over the first eight
+//                 dimensions, in single precision (a heuristic: nothing downstream relies on it being the nearest), per
+//                 wave sub-range.  It has to be the point's nearest microcluster almost always, though: one lane with a
+//                 far seed keeps its whole wave evaluating every row in full - hence eight dimensions, not four (in
+//                 four, 1 % of the C2 points have another of the 5 000 microclusters closer than their own)
+//   k_seed_merge  per point and kind: the three best of those, their exact distances, T = F x the smallest, and the
+//                 single-precision threshold T32 that goes with it (see there)
+//   k_scan_p      per tile of 16 rows: phase A abandons rows on an eight-dimension single-precision prefix sum, phase B
+//                 completes the others in double precision with the abandon test every eight dimensions; per kind it keeps
+//                 the two best EVALUATED rows and a lower bound (> = T) for every abandoned row's distance.  What leaves
+//                 the kernel per kind is a pair (best, second) in which `second` may be a BOUND (CC_SLOT_BOUND): the
+//                 best is exact whenever it is <= T (the seed row always is evaluated), the second is exact when it is
+//                 smaller than every abandoned partial sum, else all that is known of the other rows is that none is
+//                 closer than the bound.  Pairs merge like candidate pairs (cc_top2_push), in any order.
+// k_decide treats a bound in second place like a second-best candidate that is dirty: the decision is exact iff a live
+// version beats the bound, otherwise the point is undecidable in this window (CC_T_UNKNOWN) - with F = 16 that takes a
+// microcluster whose live version is four times as far (in distance units) as the seed was.
+// ---------------------------------------------------------------------------------
+
+struct __attribute__((aligned(8))) SeedCand {
+    float part;   // unscaled squared distance over the first eight dimensions (single precision)
+    int row;      // -1: none
+};
+
+// the window a snapshot scan works on: mode 0 = the current window (in place), 1 = the lookahead window of parity round & 1
+struct ScanWin {
+    int B, rows, q;
+    long long cursor;
+};
+__device__ __forceinline__ ScanWin cc_scan_window(const Ctl* __restrict__ ctl, int round, int mode)
+{
+    ScanWin w;
+    if (mode == 1) {
+        w.q = round & 1;
+        w.B = ctl->la_b[w.q];
+        w.rows = ctl->la_rows[w.q];
+        w.cursor = ctl->la_cursor[w.q];
+    } else {
+        w.B = (ctl->mode != 0) ? 0 : ctl->win_b;  // (mode != 0: this window's snapshot scan ran ahead)
+        w.rows = ctl->m_rows;
+        w.cursor = ctl->cursor;
+        w.q = (int)(ctl->window_seq & 1ull);
+    }
+    return w;
+}
+
+// single-precision pairs: the prefix arithmetic of k_seed and of k_scan_p's phase A runs on packed FP32 instructions
+typedef float cc_f2 __attribute__((ext_vector_type(2)));
+typedef float cc_f4 __attribute__((ext_vector_type(4)));
+#define CC_PRE 8  // dimensions of the prefix (k_seed's score, phase A's bound): 8 floats = two 16-byte LDS reads per row
+
+// the wave's tile of 16 row prefixes, converted to single precision and staged in LDS: tile[m * 8 + i]
+// (lane + 64 q = 8 m + i); returns the largest |coordinate| this lane saw
+template <int DP>
+__device__ __forceinline__ void cc_load_prefix(const double* __restrict__ g_cen, const int* __restrict__ g_kind, int rt,
+                                               int tm, int lane, double (&tc)[2], int& kd)
+{
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = lane + q * 64, m = e >> 3, i = e & 7;
+        tc[q] = (m < tm) ? g_cen[(size_t)(rt + m) * DP + i] : 0.0;
+    }
+    kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+}
+
+// sum over the prefix of (p - c)^2 in single precision, two dimensions per instruction
+__device__ __forceinline__ float cc_prefix_score(const cc_f2 (&p2)[CC_PRE / 2], const cc_f4* __restrict__ row)
+{
+    const cc_f4 c01 = row[0], c23 = row[1];
+    cc_f2 x0 = p2[0] - cc_f2{c01.x, c01.y};
+    cc_f2 x1 = p2[1] - cc_f2{c01.z, c01.w};
+    cc_f2 x2 = p2[2] - cc_f2{c23.x, c23.y};
+    cc_f2 x3 = p2[3] - cc_f2{c23.z, c23.w};
+    cc_f2 acc = x0 * x0;
+    acc = __builtin_elementwise_fma(x1, x1, acc);
+    acc = __builtin_elementwise_fma(x2, x2, acc);
+    acc = __builtin_elementwise_fma(x3, x3, acc);
+    return acc.x + acc.y;
+}
+
+// k_seed: per point, kind and sub-range of rows the row with the smallest squared distance over the first eight
+// dimensions, in single precision.  Two points per lane (a workgroup covers 128 window points: a row's prefix is read
+// from LDS once for both), and the score in its expanded form: with p' = p - o, c' = c - o (o = the prefix of table
+// row 0: keeps the magnitudes at the size of the data's spread whatever its offset)
+//     |p' - c'|^2 = |p'|^2 - 2 (p' . c' - |c'|^2 / 2),
+// so the nearest row is the one with the LARGEST g = p' . c' - h, h = |c'|^2 / 2 staged with the tile: four packed
+// multiply-adds, an add, a compare and two selects per row and point (the round-3 kernel's difference form - four
+// packed subtractions more, one point per lane - took 61 us where this one takes 54, `profiles/r03_tool_seed.txt`).
+// The cancellation costs a few units of 2^-24 |c'|^2: immaterial for a heuristic.
+// cmax[q] (bits of a double): the largest |centroid coordinate| among the prefixes of the scanned rows, left by the
+// workgroups of the window's first point tile (every row is in exactly one of their waves' sub-ranges)
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                   const double* __restrict__ g_cen, const int* __restrict__ g_kind,
+                                                   SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride,
+                                                   unsigned long long* __restrict__ cmax)
+{
+    static_assert(CC_PRE == 8 && CC_PRE <= DP, "prefix dimensions");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 128;
+    if (j0 >= B) return;
+    spart += (size_t)win.q * spart_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    const int per = (win.rows + nsub - 1) / nsub;
+    const int r0 = sub * per;
+    const int r1 = min(win.rows, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    double org[CC_PRE];
+#pragma unroll
+    for (int i = 0; i < CC_PRE; ++i) org[i] = g_cen[i];  // (wave-uniform: scalar loads)
+    int jj[2];
+    bool valid[2];
+    cc_f2 p2[2][CC_PRE / 2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        jj[u] = j0 + u * 64 + lane;
+        valid[u] = jj[u] < B;
+        const double* xp = Xt + win.cursor + (valid[u] ? jj[u] : 0);
+#pragma unroll
+        for (int i = 0; i < CC_PRE / 2; ++i)
+            p2[u][i] = cc_f2{valid[u] ? (float)(xp[(size_t)(2 * i) * n_pts] - org[2 * i]) : 0.f,
+                             valid[u] ? (float)(xp[(size_t)(2 * i + 1) * n_pts] - org[2 * i + 1]) : 0.f};
+    }
+    // per wave: the centred prefixes of a tile of 16 rows and their h in LDS, read back as wave-uniform broadcasts
+    __shared__ __attribute__((aligned(16))) float s_pre[NW * CC_SCAN_TM * CC_PRE];
+    __shared__ float s_h[NW * CC_SCAN_TM];
+    float* const tile = s_pre + (size_t)wv * CC_SCAN_TM * CC_PRE;
+    float* const th = s_h + (size_t)wv * CC_SCAN_TM;
+    float best[2][2];
+    int idx[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) { best[u][K] = -__builtin_inff(); idx[u][K] = -1; }
+    double tc[2];
+    int kdl = CC_KIND_DEAD;
+    double cm = 0.0;
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            cm = __builtin_fmax(cm, __builtin_fabs(tc[q]));
+            const float v = (float)(tc[q] - org[lane & 7]);
+            tile[lane + q * 64] = v;
+            // h of the row: the eight lanes that hold it add their squares (every lane ends up with the sum)
+            float hsum = v * v;
+            hsum += __shfl_xor(hsum, 1);
+            hsum += __shfl_xor(hsum, 2);
+            hsum += __shfl_xor(hsum, 4);
+            if ((lane & 7) == 0) th[(lane >> 3) + q * 8] = 0.5f * hsum;
+        }
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
+        auto score2 = [&](int m, float (&g)[2]) {
+            const cc_f4 c01 = t4[m * 2], c23 = t4[m * 2 + 1];
+            const float h = th[m];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                cc_f2 acc = p2[u][0] * cc_f2{c01.x, c01.y};
+                acc = __builtin_elementwise_fma(p2[u][1], cc_f2{c01.z, c01.w}, acc);
+                acc = __builtin_elementwise_fma(p2[u][2], cc_f2{c23.x, c23.y}, acc);
+                acc = __builtin_elementwise_fma(p2[u][3], cc_f2{c23.z, c23.w}, acc);
+                g[u] = (acc.x + acc.y) - h;
+            }
+        };
+        auto update = [&](auto KC, const float (&g)[2], int rowg) {
+            constexpr int K = decltype(KC)::value;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool gt = g[u] > best[u][K];  // strict: the first row in scan order keeps a tie (deterministic)
+                best[u][K] = gt ? g[u] : best[u][K];
+                idx[u][K] = gt ? rowg : idx[u][K];
+            }
+        };
+        auto rows_of_kind = [&](auto KC) {
+            int m = 0;
+            for (; m + 2 <= tm; m += 2) {
+                float a[2][2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) score2(m + v, a[v]);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) update(KC, a[v], rt + m + v);
+            }
+            for (; m < tm; ++m) {
+                float a[2];
+                score2(m, a);
+                update(KC, a, rt + m);
+            }
+        };
+        const unsigned full = (1u << tm) - 1u;
+        if (pmask == full) rows_of_kind(std::integral_constant<int, 0>{});
+        else if (omask == full) rows_of_kind(std::integral_constant<int, 1>{});
+        else
+            for (int m = 0; m < tm; ++m) {
+                float a[2];
+                score2(m, a);
+                if ((pmask >> m) & 1u) update(std::integral_constant<int, 0>{}, a, rt + m);
+                else if ((omask >> m) & 1u) update(std::integral_constant<int, 1>{}, a, rt + m);
+            }
+    }
+    if (blockIdx.x == 0) {
+        for (int off = 32; off >= 1; off >>= 1) cm = __builtin_fmax(cm, __shfl_xor(cm, off));
+        if (lane == 0) atomicMax(cmax + win.q, (unsigned long long)__double_as_longlong(cm));  // (>= 0: bits order like values)
+    }
+    // back to squared prefix distances (what k_seed_merge ranks the sub-ranges' winners by): |p'|^2 - 2 g, never below 0
+    float pp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        cc_f2 acc = p2[u][0] * p2[u][0];
+#pragma unroll
+        for (int i = 1; i < CC_PRE / 2; ++i) acc = __builtin_elementwise_fma(p2[u][i], p2[u][i], acc);
+        pp[u] = acc.x + acc.y;
+#pragma unroll
+        for (int K = 0; K < 2; ++K) best[u][K] = idx[u][K] >= 0 ? __builtin_fmaxf(0.f, pp[u] - 2.f * best[u][K]) : __builtin_inff();
+    }
+    __shared__ float s_b[(NW > 1 ? NW - 1 : 1) * 4 * 64];
+    __shared__ int s_i[(NW > 1 ? NW - 1 : 1) * 4 * 64];
+    if (wv > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                s_b[((wv - 1) * 4 + u * 2 + K) * 64 + lane] = best[u][K];
+                s_i[((wv - 1) * 4 + u * 2 + K) * 64 + lane] = idx[u][K];
+            }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!valid[u]) continue;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                const float b = s_b[(w * 4 + u * 2 + K) * 64 + lane];
+                const int ix = s_i[(w * 4 + u * 2 + K) * 64 + lane];
+                const bool lt = ix >= 0 && (idx[u][K] < 0 || b < best[u][K]);
+                best[u][K] = lt ? b : best[u][K];
+                idx[u][K] = lt ? ix : idx[u][K];
+            }
+        SeedCand* o = spart + ((size_t)jj[u] * S + blockIdx.y) * 2;
+        o[0] = SeedCand{best[u][0], idx[u][0]};
+        o[1] = SeedCand{best[u][1], idx[u][1]};
+    }
+}
+
+// per point and kind (one thread each): the three best prefix scores of the sub-ranges -> their exact distances (the
+// scans' own operations, in their order; the three sums advance together) -> T = F x the smallest; +inf when the kind
+// has no row.  And T32, the threshold phase A's SINGLE-PRECISION prefix sum is compared with.  Phase A abandons a row when
+//     Qf = smin * sum_{i < 8} fl32(fl32(p_i) - fl32(c_i))^2     exceeds T32,
+// and that must imply that the row's exact partial sum P = sum_i s_i (p_i - c_i)^2 (s_i = 1 or 1/k) exceeds T.  With
+// e = 2^-21 max(|p|, |c|) (twice the bound 2^-24 (|p_i| + |c_i| + |x_i|) on the error of a difference x_i),
+//     P >= sum s_i (|x_i| - e)^2 >= Q - 2 e sum s_i |x_i| >= Q - a sqrt(Q),   a = 2 e sqrt(8 smax),  Q = sum s_i x_i^2 >= smin sum x_i^2
+// (Cauchy-Schwarz), g(Q) = Q - a sqrt(Q) grows for sqrt(Q) > a / 2, so P > T follows from sqrt(Q) > u = (a + sqrt(a^2 + 4 T)) / 2.
+// The nine roundings of Qf (relative 2^-24 each, all terms >= 0) are covered by the factor 1 + 2^-19; T32 is rounded up.
+template <int DP>
+__global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, const double* __restrict__ X,
+                                                   const double* __restrict__ g_cen, const double* __restrict__ g_scl,
+                                                   const SeedCand* __restrict__ spart, size_t spart_stride, int S,
+                                                   double* __restrict__ thr, float* __restrict__ thr32, size_t thr_stride,
+                                                   double F, int round, int mode, const unsigned long long* __restrict__ cmax)
+{
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t >> 1, K = t & 1;
+    if (j >= win.B) return;
+    constexpr int d = DP;  // (the pruned scan runs for d == DP only: every loop below unrolls, its loads go out together)
+    spart += (size_t)win.q * spart_stride;
+    thr += (size_t)win.q * thr_stride;
+    thr32 += (size_t)win.q * thr_stride;
+    const double* p = X + (size_t)(win.cursor + j) * d;
+    float b0 = __builtin_inff(), b1 = __builtin_inff(), b2 = __builtin_inff();
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int s = 0; s < S; ++s) {
+        const SeedCand c = spart[((size_t)j * S + s) * 2 + K];
+        if (c.row < 0) continue;
+        if (i0 < 0 || c.part < b0) { b2 = b1; i2 = i1; b1 = b0; i1 = i0; b0 = c.part; i0 = c.row; }
+        else if (i1 < 0 || c.part < b1) { b2 = b1; i2 = i1; b1 = c.part; i1 = c.row; }
+        else if (i2 < 0 || c.part < b2) { b2 = c.part; i2 = c.row; }
+    }
+    double out = CC_INF;
+    if (i0 >= 0) {
+        const bool h1 = i1 >= 0, h2 = i2 >= 0;
+        const size_t o0 = (size_t)i0 * d, o1 = (size_t)(h1 ? i1 : i0) * d, o2 = (size_t)(h2 ? i2 : i0) * d;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        // eight dimensions of the three rows per pass: 56 loads in flight, the sums left to right
+        for (int i0 = 0; i0 < d; i0 += 8) {
+            double pv[8], c0[8], c1[8], c2[8], s0[8], s1[8], s2[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = (i0 + u < d) ? i0 + u : d - 1;
+                pv[u] = p[i];
+                c0[u] = g_cen[o0 + i]; c1[u] = g_cen[o1 + i]; c2[u] = g_cen[o2 + i];
+                s0[u] = g_scl[o0 + i]; s1[u] = g_scl[o1 + i]; s2[u] = g_scl[o2 + i];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u < d) {
+                    double x0 = pv[u] - c0[u], x1 = pv[u] - c1[u], x2 = pv[u] - c2[u];
+                    x0 = x0 * x0; x1 = x1 * x1; x2 = x2 * x2;
+                    x0 = x0 * s0[u]; x1 = x1 * s1[u]; x2 = x2 * s2[u];
+                    a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2;
+                }
+            }
+        }
+        double dmin = a0;
+        dmin = a1 < dmin ? a1 : dmin;
+        dmin = a2 < dmin ? a2 : dmin;
+        out = F * dmin;
+    }
+    thr[(size_t)j * 2 + K] = out;
+    float t32 = __builtin_inff();
+    if (out < CC_INF) {
+        double pm = 0.0;
+        for (int i = 0; i < CC_PRE; ++i) pm = __builtin_fmax(pm, __builtin_fabs(p[i]));
+        const double cmx = __longlong_as_double((long long)cmax[win.q]);
+        const double e = 0x1p-21 * __builtin_fmax(pm, cmx);
+        const double inv_k = ctl->inv_k;
+        const double smax = inv_k > 1.0 ? inv_k : 1.0, smin = inv_k < 1.0 ? inv_k : 1.0;
+        const double a = 2.0 * e * sqrt(8.0 * smax);
+        const double u = 0.5 * (a + sqrt(a * a + 4.0 * out)) * (1.0 + 0x1p-40);
+        // the kernel compares sum x^2 (without smin) with T32 = u^2 (1 + 2^-19) / smin
+        const double t64 = u * u * (1.0 + 0x1p-19) / smin * (1.0 + 0x1p-40);
+        t32 = (float)t64;
+        if ((double)t32 < t64) t32 = __uint_as_float(__float_as_uint(t32) + 1u);  // (t32 >= 0 and finite here: the next float up)
+    }
+    thr32[(size_t)j * 2 + K] = t32;
+}
+
+// Per wave and tile of 16 rows two phases:
+//   A  every row, straight-line, in SINGLE precision: the sum over the first eight dimensions of (p - c)^2 (packed FP32
+//      instructions: 4 subtractions, 4 multiply-adds and an add per row) against the lane's threshold T32 (k_seed_merge:
+//      exceeding it implies that the row's exact partial sum exceeds T, whatever the row's preferred dimensions are),
+//      the wave-uniform test "some lane within its threshold", one bit per row; a row that no lane keeps leaves T in the
+//      kind's bound.  Only the first eight dimensions of the tile's rows are fetched (16 x 8 doubles, coalesced,
+//      converted and staged in the wave's LDS tile, read back as wave-uniform broadcasts; the next tile's loads are in
+//      flight during the row loop of the current one) - whole rows, as k_scan stages them, would be five times the bytes
+//      at d = 20 for 2 % of the rows, and the same lines are wanted by every point tile's workgroup at the same moment.
+//   B  the rows phase A kept (few): the whole distance from its first dimension with the reference's four operations
+//      per term in double precision (sub, square, scale, add - no fusion, so no CC_TINY condition to check), centroid
+//      and operand as scalar loads of eight dimensions at a time, the abandon test (now exact: partial sum against T)
+//      every eight dimensions, then the best-two update of k_scan_u.
+#ifndef CC_SCANP_WGS20
+#define CC_SCANP_WGS20 4  // workgroups per CU k_scan_p is compiled for at d <= 20
+#endif
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3 : 2))) void k_scan_p(
+    Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
+    const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
+    const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride)
+{
+    static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 64;
+    if (j0 >= B) return;
+    part += (size_t)win.q * part_stride;
+    thr += (size_t)win.q * thr_stride;
+    thr32 += (size_t)win.q * thr_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    const int per = (win.rows + nsub - 1) / nsub;
+    const int r0 = sub * per;
+    const int r1 = min(win.rows, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const int jj = j0 + lane;
+    const bool valid = jj < B;
+
+    constexpr int TILE_BYTES = NW * CC_SCAN_TM * CC_PRE * 4;
+    constexpr int MERGE_BYTES = (NW - 1) * 4 * 64 * (int)sizeof(Cand);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TILE_BYTES > MERGE_BYTES ? TILE_BYTES : MERGE_BYTES];
+    float* const tile = reinterpret_cast<float*>(smem) + (size_t)wv * CC_SCAN_TM * CC_PRE;
+
+    double p[DP];
+    {
+        const double* xp = Xt + win.cursor + (valid ? jj : 0);
+#pragma unroll
+        for (int i = 0; i < DP; ++i) p[i] = valid ? xp[(size_t)i * n_pts] : 0.0;
+    }
+    cc_f2 p2[CC_PRE / 2];
+#pragma unroll
+    for (int i = 0; i < CC_PRE / 2; ++i) p2[i] = cc_f2{(float)p[2 * i], (float)p[2 * i + 1]};
+    // thresholds (exact: th, single-precision prefix: th32) and the bound of what was abandoned, per kind; lanes without
+    // a point keep no row alive
+    double th[2], lb[2] = {CC_INF, CC_INF};
+    float th32[2];
+#pragma unroll
+    for (int K = 0; K < 2; ++K) {
+        th[K] = valid ? thr[(size_t)jj * 2 + K] : -CC_INF;
+        th32[K] = valid ? thr32[(size_t)jj * 2 + K] : -__builtin_inff();
+    }
+    bool dropped[2] = {false, false};  // (wave-uniform) phase A abandoned a row of the kind: every lane's bound is its T
+    double bd[2][2];
+    int bs[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            bd[kd][r] = valid ? CC_INF : -CC_INF;
+            bs[kd][r] = -1;
+        }
+    int n_rows = 0, n_full = 0;  // statistics (wave-uniform)
+
+    double tc[2];
+    int kdl = CC_KIND_DEAD;
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) tile[lane + q * 64] = (float)tc[q];
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
+        n_rows += tm;
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
+        const unsigned full = (1u << tm) - 1u;
+
+        // ---- phase A ----
+        unsigned surv = 0u;
+        // straight-line: one compare per row, the wave's verdict as one bit (which kinds lost rows follows from the
+        // bits at the end of the tile)
+        auto verdict = [&](auto KSELC, int m, float q) {
+            constexpr int KSEL = decltype(KSELC)::value;
+            float t;
+            if constexpr (KSEL == 0) t = th32[0];
+            else if constexpr (KSEL == 1) t = th32[1];
+            else t = ((pmask >> m) & 1u) ? th32[0] : th32[1];
+            surv |= (__builtin_amdgcn_ballot_w64(q <= t) != 0ull) ? (1u << m) : 0u;
+        };
+        auto phase_a = [&](auto KSELC) {
+            int m = 0;
+            for (; m + 4 <= tm; m += 4) {
+                float a[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = cc_prefix_score(p2, t4 + (m + u) * 2);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) verdict(KSELC, m + u, a[u]);
+            }
+            for (; m < tm; ++m) verdict(KSELC, m, cc_prefix_score(p2, t4 + m * 2));
+        };
+        if (pmask == full) phase_a(std::integral_constant<int, 0>{});
+        else if (omask == full) phase_a(std::integral_constant<int, 1>{});
+        else phase_a(std::integral_constant<int, -1>{});
+        if ((~surv & pmask & full) != 0u) dropped[0] = true;
+        if ((~surv & omask & full) != 0u) dropped[1] = true;
+
+        // ---- phase B: the rows that stayed ----
+        while (surv != 0u) {
+            const int m = __builtin_ctz(surv);
+            surv &= surv - 1u;
+            const int rowg = rt + m;
+            const bool is_p = ((pmask >> m) & 1u) != 0u;
+            if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
+            const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
+            const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
+            double acc = 0.0;
+            bool gone = false;
+            cc_static_for<(DP + 7) / 8>([&](auto CC) {
+                constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
+                if (gone) return;
+                double c[hi - lo], sc[hi - lo];
+#pragma unroll
+                for (int i = 0; i < hi - lo; ++i) {
+                    c[i] = rc[lo + i];
+                    sc[i] = rs[lo + i];
+                }
+#pragma unroll
+                for (int i = 0; i < hi - lo; ++i) {
+                    double x = p[lo + i] - c[i];          // mc_functions.py:37
+                    x = x * x;                             // :38
+                    x = x * sc[i];                         // :39 (the divisor is a power of two)
+                    acc = (lo + i == 0) ? x : acc + x;     // :41
+                }
+                if constexpr (hi < DP) {
+                    // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
+                    if (is_p) {
+                        if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
+                    } else {
+                        if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
+                    }
+                }
+            });
+            if (gone) continue;
+            ++n_full;
+            auto update = [&](auto KC) {
+                constexpr int K = decltype(KC)::value;
+                const double a = acc;
+                double& d0 = bd[K][0];
+                double& d1 = bd[K][1];
+                int& s0 = bs[K][0];
+                int& s1 = bs[K][1];
+                bool ins = a < d1;
+                bool first = a < d0;
+                // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+                const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                if ((e1 | e0) != 0ull) {
+                    if (a == d1 || a == d0) {
+                        const int key = g_key[rowg];
+                        if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                        if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                    }
+                }
+                d1 = cc_vmin(d1, cc_vmax(d0, a));
+                d0 = cc_vmin(d0, a);
+                s1 = first ? s0 : (ins ? rowg : s1);
+                s0 = first ? rowg : s0;
+            };
+            if (is_p) update(std::integral_constant<int, 0>{});
+            else update(std::integral_constant<int, 1>{});
+        }
+    }
+    // rows abandoned in phase A: their exact partial sums exceed every lane's T (k_seed_merge), which is all that is
+    // recorded of them
+    if (dropped[0]) lb[0] = cc_vmin(lb[0], th[0]);
+    if (dropped[1]) lb[1] = cc_vmin(lb[1], th[1]);
+    // statistics for the host's policy: a sample - the waves of the window's first point tile (atomics of every wave on
+    // one address serialise: 30 000 of them cost more than the scan)
+    if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
+        atomicAdd(&ctl->stat_prune_rows, (unsigned long long)n_rows);
+        atomicAdd(&ctl->stat_prune_full, (unsigned long long)n_full);
+    }
+
+    // the survivors' list-order keys; every kind's pair then takes in the bound of what the wave abandoned; the waves'
+    // pairs are merged through LDS as in k_scan_u
+    int bk[2][2];
+#pragma unroll
+    for (int kd = 0; kd < 2; ++kd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) bk[kd][r] = bs[kd][r] >= 0 ? g_key[bs[kd][r]] : CC_IDX_INF;
+    Cand c0{bd[0][0], bk[0][0], bs[0][0]}, c1{bd[0][1], bk[0][1], bs[0][1]};
+    Cand c2{bd[1][0], bk[1][0], bs[1][0]}, c3{bd[1][1], bk[1][1], bs[1][1]};
+    cc_top2_push(c0, c1, Cand{lb[0], -1, (valid && lb[0] < CC_INF) ? CC_SLOT_BOUND : -1});
+    cc_top2_push(c2, c3, Cand{lb[1], -1, (valid && lb[1] < CC_INF) ? CC_SLOT_BOUND : -1});
+    Cand* s_m = reinterpret_cast<Cand*>(smem);
+    auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 4 + c) * 64 + lane]; };
+    __syncthreads();  // every wave is done with its tile: the same bytes now carry the candidate exchange
+    if (wv > 0) {
+        s_m_at(wv - 1, 0) = c0;
+        s_m_at(wv - 1, 1) = c1;
+        s_m_at(wv - 1, 2) = c2;
+        s_m_at(wv - 1, 3) = c3;
+    }
+    __syncthreads();
+    if (wv != 0 || !valid) return;
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) {
+        cc_top2_push(c0, c1, s_m_at(w, 0));
+        cc_top2_push(c0, c1, s_m_at(w, 1));
+        cc_top2_push(c2, c3, s_m_at(w, 2));
+        cc_top2_push(c2, c3, s_m_at(w, 3));
+    }
+    Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
+// k_merge_partials (exact multi-GPU path): the S partials a rank's snapshot scan left per window point -> ONE record
+// of four candidates per point, the unit the ranks all-gather (64 B per point instead of S x 64 B).  Candidates are
+// totally ordered by (distance, list-order key), so the best two of a union do not depend on the merge order and
+// every rank derives the same lists from the gathered records.  One thread per point; `round` / `mode` select the
+// window exactly as in k_scan.  Always recomputed from the scan's partials (idempotent), also when the in-place scan
+// it follows found that the window had been scanned ahead.
+// ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ ctl, const Cand* __restrict__ part,
+                                                        size_t part_stride, int S, Cand* __restrict__ out,
+                                                        size_t out_stride, int round, int mode)
+{
+    int B, q;
+    if (mode == 1) {
+        q = round & 1;
+        B = ctl->la_b[q];
+    } else {
+        q = (int)(ctl->window_seq & 1ull);
+        B = ctl->win_b;
+    }
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= B) return;
+    part += (size_t)q * part_stride;
+    out += (size_t)q * out_stride;
+    const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
+    Cand p1 = none, p2 = none, o1 = none, o2 = none;
+    for (int s = 0; s < S; ++s) {
+        const Cand* c = part + ((size_t)j * S + s) * 4;
+        cc_top2_push(p1, p2, c[0]);
+        cc_top2_push(p1, p2, c[1]);
+        cc_top2_push(o1, o2, c[2]);
+        cc_top2_push(o1, o2, c[3]);
+    }
+    Cand* o = out + (size_t)j * 4;
+    o[0] = p1; o[1] = p2; o[2] = o1; o[3] = o2;
+}
