@@ -176,6 +176,26 @@ def test_host_group_peer_gone_raises_instead_of_hanging(tmp_path):
         rendezvous.HostGroup(1, 2, rdzv_file=str(tmp_path / "nobody"), timeout=0.5)
 
 
+def test_default_rendezvous_file_is_the_same_for_every_rank_of_a_job(monkeypatch):
+    """The file rank 0 publishes its port in must have the same name in every rank, whatever started them: with a
+    MASTER_PORT (every launcher of the contract sets one) the name does not involve the parent's pid - ranks behind a
+    wrapper script have different parents -, two jobs of one user differ in the port, CHRONOCLUST_RDZV_FILE overrides."""
+    from chronoclust_amd import rendezvous
+    monkeypatch.delenv("CHRONOCLUST_RDZV_FILE", raising=False)
+    monkeypatch.setenv("MASTER_PORT", "29517")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job7")
+    a = rendezvous.default_rdzv_file()
+    assert str(os.getppid()) not in os.path.basename(a).split("_") and "29517" in a and "job7" in a
+    monkeypatch.setattr(os, "getppid", lambda: 424242)
+    assert rendezvous.default_rdzv_file() == a
+    monkeypatch.setenv("MASTER_PORT", "29518")
+    assert rendezvous.default_rdzv_file() != a
+    monkeypatch.delenv("MASTER_PORT")
+    assert "424242" in rendezvous.default_rdzv_file()  # no port: the launcher's pid tells jobs apart
+    monkeypatch.setenv("CHRONOCLUST_RDZV_FILE", "/tmp/explicit_rdzv")
+    assert rendezvous.default_rdzv_file() == "/tmp/explicit_rdzv"
+
+
 def test_bench_imports_no_torch():
     """north_star: no PyTorch on the path - bench.py and the package import neither torch nor the oracle at import time."""
     import subprocess
