@@ -656,8 +656,21 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             bcf1 = ver.cf1 + (size_t)wrow * d; bcf2 = ver.cf2 + (size_t)wrow * d; bw = ver.w[wrow];
             target = ver.tgt[wrow];
         }
-        const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, par);  // hddstream.py:334-337
-        if (g.r2 <= par.eps_sq) {
+        // hddstream.py:334-337.  In a validation round the very same add has usually been made already: k_chain (or
+        // k_chain_long) of this round replayed the claims of the previous one, and if j claimed `target` there and
+        // the state it is added to now is the one its step started from - the version row of its predecessor in the
+        // chain, or the row itself when nobody before j claims the MC (j heads the chain) - the radius test's verdict
+        // is in ver.acc[j]: the same operands in the same order, so the same bits.
+        bool known = false, fits = false;
+        if (round > 0 && Told[j] == target && ver.tgt[j] == target) {
+            known = (wkind == 2 && wrow < CC_CAR_BASE) ? (ver.next[wrow] == j) : true;
+            fits = ver.acc[j] != 0;
+        }
+        if (!known) {
+            const GroupAdd g = cc_group_add(bcf1, bcf2, bw, p, d, par);
+            fits = g.r2 <= par.eps_sq;
+        }
+        if (fits) {
             T = target;
             path = stage;
         }
