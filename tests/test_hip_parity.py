@@ -341,6 +341,38 @@ def test_long_chains_on_a_large_table(window, lookahead, heavy):
     assert s["long_chains"] > 0 and s["long_chain_launches"] > 0, s
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_skewed_streams_fuzz(seed):
+    """Random skewed streams on tables of 1 100 - 2 600 microclusters: a few heavy populations (chains of hundreds to
+    thousands of members, listed and replayed by k_chain_long from the second batch on) among many light ones, any
+    window size up to the largest, lookahead off / default / forced, two timepoints with drift and decay."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(8800 + seed)
+    d = int(rng.choice([3, 6, 14, 20]))
+    g = int(rng.integers(1100, 2600))
+    n = int(rng.choice([40_000, 60_000]))
+    heavy_blobs = int(rng.integers(1, 6))
+    heavy = float(rng.choice([0.03, 0.1, 0.3, 0.6]))
+    sigma = float(rng.choice([0.002, 0.004]))
+    window = int(rng.choice([4096, 12288, 32768, 49152]))
+    lookahead = int(rng.choice([0, 2, 3]))
+    cfg = scenarios.params_to_config(scenarios.blob_params(
+        n, param_epsilon=float(rng.choice([0.03, 0.08])), param_k=float(rng.choice([1.0, 2.0, 4.0])),
+        param_lambda=float(rng.choice([0.0, 0.5])), promote_after=int(rng.choice([3, 10]))))
+    h, o = _hdd(cfg, window=window, lookahead=lookahead), O.OracleHDDStream(cfg)
+    centres = rng.uniform(0.05, 0.95, (g, d))
+    for t in range(2):
+        lab = rng.integers(heavy_blobs, g, n)
+        big = rng.random(n) < heavy
+        lab[big] = rng.integers(0, heavy_blobs, int(big.sum()))
+        X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, sigma, (n, d)), 0.0, 1.0))
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+        centres = np.clip(centres + rng.normal(0.0, 0.001, centres.shape), 0.0, 1.0)
+    assert h.stats()["long_chains"] > 0
+
+
 def test_windows_with_more_than_32767_creations():
     """k_commit_a ranks a window's creations and promotions in two 16-bit counts packed into one word: a window at
     the largest size (49 152 points) in which EVERY point creates a microcluster (uniform points, a radius threshold
