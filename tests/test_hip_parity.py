@@ -370,7 +370,6 @@ def test_skewed_streams_fuzz(seed):
         o.online_microcluster_maintenance(X, t)
         _check_against_oracle(h, o)
         centres = np.clip(centres + rng.normal(0.0, 0.001, centres.shape), 0.0, 1.0)
-    assert h.stats()["long_chains"] > 0
 
 
 def test_windows_with_more_than_32767_creations():
