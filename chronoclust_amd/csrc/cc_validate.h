@@ -1060,12 +1060,12 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
     const long long cursor = ctl->cursor;
     const int pk_base = ctl->n_pkeys;
     // steps per batch: the CF1 / CF2 prefixes of a batch have to fit the staging area
-    const int K = (d <= 24) ? 128 : ((d <= 48) ? 64 : 32);
+    const int K = min(256, (CC_LONG_XY_DOUBLES / (2 * d)) & ~7);  // (256 at d <= 12, 216 at 14, 152 at 20, 72 at 40, 48 at 64)
 
     __shared__ __attribute__((aligned(16))) double s_xy[CC_LONG_XY_DOUBLES];
-    __shared__ double s_w[128], s_dq[128];
-    __shared__ unsigned long long s_mask[128];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
-    __shared__ int s_flag[128];                 // bit 0: radius test passed, bit 1: promotion condition holds
+    __shared__ double s_w[256], s_dq[256];
+    __shared__ unsigned long long s_mask[256];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
+    __shared__ int s_flag[256];                 // bit 0: radius test passed, bit 1: promotion condition holds
     __shared__ int s_queue[CC_LONG_QUEUE];
     __shared__ double s_b1[64], s_b2[64], s_bcen[64], s_bpref[64], s_c0[64], s_w0[64];  // running state / snapshot metric
     __shared__ double s_bw, s_bdq;
