@@ -1,6 +1,6 @@
-"""Skewed populations: G blobs of which three take the share HEAVY of the events (N points per timepoint, two timepoints
+"""Skewed populations: G blobs of which HB (default three) take the share HEAVY of the events (N points per timepoint, two timepoints
 of the same populations; the second one runs on the settled table).  Online-phase time and rate per timepoint, chains
-longer than the member list, launches of k_chain_long.  Environment: N, D, G, HEAVY, WIN, LA."""
+longer than the member list, launches of k_chain_long.  Environment: N, D, G, HEAVY, HB, WIN, LA."""
 import os
 import sys
 import time
@@ -15,6 +15,7 @@ from chronoclust_amd import _lib  # noqa: E402
 if __name__ == "__main__":
     n, d, g = int(os.environ.get("N", 2_000_000)), int(os.environ.get("D", 14)), int(os.environ.get("G", 2000))
     heavy = float(os.environ.get("HEAVY", 0.3))
+    hb = int(os.environ.get("HB", 3))
     rng = np.random.default_rng(7)
     centres = rng.uniform(0.1, 0.9, (g, d))
     cfg = bench.blob_config(n)
@@ -22,9 +23,9 @@ if __name__ == "__main__":
     h.set_tuning(window=int(os.environ.get("WIN", "0")), lookahead=int(os.environ.get("LA", "0")), time_kernels=1)
     bench.set_params(h, cfg, n, d)
     for t in range(3):
-        lab = rng.integers(3, g, n)
+        lab = rng.integers(hb, g, n)
         big = rng.random(n) < heavy
-        lab[big] = rng.integers(0, 3, int(big.sum()))
+        lab[big] = rng.integers(0, hb, int(big.sum()))
         X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 0.01, (n, d)), 0.0, 1.0))
         h.points_upload(X)
         h.online_run()
