@@ -1170,23 +1170,32 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
         for (int e = tid; e < n * d; e += 256) {
             const int k = e / d, i = e - k * d;
             const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
-            xs[e] = X[(cursor + m) * d + i];
+            const double x = X[(cursor + m) * d + i];
+            xs[e] = x;
+            ys[e] = x * x;  // (the square every step adds to CF2: formed here, by all threads, instead of inside the chain)
         }
         if (tid == 0) { s_first_fail = n; s_first_up = n; }
         __syncthreads();
+        // The three running sums are chains of dependent additions, a dozen instructions per step for ONE wave that has
+        // its SIMD to itself: CF1 in the first wave, CF2 in the second, W in the third, side by side
+        // (mc_functions.py:24-29 / microcluster.py:147: the additions k_chain makes, in its order).
         if (tid < d) {
-            double c1 = s_b1[tid], c2 = s_b2[tid];
+            double c1 = s_b1[tid];
             for (int k = 0; k < n; ++k) {
-                const double x = xs[k * d + tid];
-                c1 = c1 + x;          // mc_functions.py:24-29, the additions k_chain makes, in its order
-                c2 = c2 + x * x;
+                c1 = c1 + xs[k * d + tid];
                 xs[k * d + tid] = c1;
-                ys[k * d + tid] = c2;
             }
-        } else if (tid == 64) {
+        } else if (tid >= 64 && tid < 64 + d) {
+            const int i = tid - 64;
+            double c2 = s_b2[i];
+            for (int k = 0; k < n; ++k) {
+                c2 = c2 + ys[k * d + i];
+                ys[k * d + i] = c2;
+            }
+        } else if (tid == 128) {
             double w = s_bw;
             for (int k = 0; k < n; ++k) {
-                w = w + 1.0;  // microcluster.py:147
+                w = w + 1.0;
                 s_w[k] = w;
             }
         }
