@@ -1367,6 +1367,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         long long cursor_prev = range_a;
         long long long_prev = 0;   // Ctl::stat_long at the end of the previous batch
         bool long_seen = false;    // ... and whether that batch added to it
+        bool long_few = true;      // ... by no more than 64 chains per validation round
+        long long rounds_prev = 0, long_avg = 1;
         long long long_launches = 0;
         unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
         while (done < N) {
@@ -1456,6 +1458,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // that follow one in which such chains were seen (a function of device counters: every rank decides alike)
             const bool long_listed = h->allow_long && scan_rows == 0 && long_seen;
             int* const long_list = long_listed ? h->long_list.p : nullptr;
+            // workgroups of its launches = entries k_decide may list per round: a few more than the previous batch's
+            // average when that was small (a launch of hundreds of workgroups that return at once is not free)
+            const int long_cap = long_few ? (int)std::min<long long>(CC_LONG_CAP, 2 * long_avg + 8) : CC_LONG_CAP;
             // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
             // a batch, then kept up commit by commit
             ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
@@ -1530,7 +1535,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                    dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                    h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list);
+                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 for (int r = 1; r <= Rcur; ++r) {
@@ -1538,12 +1543,23 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     int* tnew = (r & 1) ? h->T1.p : h->T0.p;
                     hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(chain_threads), 0, sA,
                                        h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
-                    if (long_rows > 0)
-                        hipLaunchKernelGGL(k_chain_long, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                    // k_chain_long: one workgroup per table row while k_claims serves the table, else per entry of the
+                    // round's list.  The large workgroups (SPLIT) while they are few - rows <= 256, or a short list, judged by
+                    // the previous batch's count -, the small ones (two per CU) when hundreds of chains are long
+                    if (long_rows > 0 && long_rows <= 256)
+                        hipLaunchKernelGGL(k_chain_long<true>, dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
+                                           ver, car, told, r, long_rows, (const int*)nullptr);
+                    else if (long_rows > 0)
+                        hipLaunchKernelGGL(k_chain_long<false>, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                            told, r, long_rows, (const int*)nullptr);
-                    else if (long_listed && ++long_launches > 0)
-                        hipLaunchKernelGGL(k_chain_long, dim3(CC_LONG_CAP), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                           told, r, 0, (const int*)long_list);
+                    else if (long_listed && ++long_launches > 0) {
+                        if (long_few)
+                            hipLaunchKernelGGL(k_chain_long<true>, dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
+                                               tab, ver, car, told, r, 0, (const int*)long_list);
+                        else
+                            hipLaunchKernelGGL(k_chain_long<false>, dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
+                                               car, told, r, 0, (const int*)long_list);
+                    }
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                        h->clean.p, h->dseed.p, told, r);
                     if (!nodirty) {
@@ -1552,7 +1568,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
-                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list);
+                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
@@ -1578,7 +1594,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
                 cursor_prev = h->hc.cursor;
                 long_seen = h->hc.stat_long > long_prev;
+                // (long chains per window and validation round of the batch: up to 64 count as few)
+                long_avg = (h->hc.stat_long - long_prev) / std::max<long long>(1, h->hc.stat_rounds - rounds_prev) + 1;
+                long_few = long_avg <= 64;
                 long_prev = h->hc.stat_long;
+                rounds_prev = h->hc.stat_rounds;
             }
             {
                 // what the device counted, and the policy's decision for the next batch

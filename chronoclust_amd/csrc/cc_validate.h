@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
-                                                int* __restrict__ long_list)
+                                                int* __restrict__ long_list, int long_cap)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -723,7 +723,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                 atomicAdd((unsigned long long*)&ctl->stat_long, 1ull);
                 if (long_list != nullptr) {
                     const int idx = atomicAdd(&ctl->n_long[round + 1], 1);
-                    if (idx < CC_LONG_CAP) {
+                    if (idx < long_cap) {  // (= the workgroups of the k_chain_long launch that follows)
                         long_list[(size_t)((round + 1) & 1) * CC_LONG_CAP + idx] = T;
                         atomicOr(cw, CC_LONG_LISTED);
                     }
@@ -1023,8 +1023,14 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 
 #define CC_LONG_XY_DOUBLES 6144  // staged CF1 / CF2 prefixes of a batch: 2 * K * d doubles (48 KB)
 #define CC_LONG_QUEUE 2048       // pending chain members (ring buffer)
+#define CC_LONG_THREADS 1024      // threads of a k_chain_long workgroup
 
-__global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+// SPLIT: workgroups of CC_LONG_THREADS threads (four waves per SIMD) with the per-(step, dimension) work of the radius
+// tests spread over all of them - twice the LDS, so one workgroup per CU: for the few long chains of few-microcluster
+// streams and skewed populations.  !SPLIT: 256 threads, two workgroups per CU: tables of hundreds of rows, where every
+// row's chain is long-ish and the workgroups are many.
+template <bool SPLIT>
+__global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                     Versions ver, Carry car, const int* __restrict__ T, int round,
                                                     int scan_rows, const int* __restrict__ long_list)
 {
@@ -1039,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
         t = blockIdx.x;
         if (t >= scan_rows) return;
     } else {
-        const int n_listed = min(ctl->n_long[round], CC_LONG_CAP);
+        const int n_listed = min(ctl->n_long[round], (int)gridDim.x);  // (k_decide listed at most as many as this launch has workgroups)
         if ((int)blockIdx.x >= n_listed) return;
         t = long_list[(size_t)(round & 1) * CC_LONG_CAP + blockIdx.x];
     }
@@ -1072,6 +1078,10 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
     __shared__ unsigned long long s_m0, s_bmask;  // preferred dimensions in the snapshot / of the running state (bit i)
     __shared__ int s_wsum[4];
     __shared__ int s_first_fail, s_first_up;
+    // per (step, dimension) of a batch: the term of the radius sum, the displacement term, "preferred after the step"
+    __shared__ double s_term[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1], s_dqt[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
+    __shared__ unsigned char s_pf[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
+    const int NT = (int)blockDim.x;  // CC_LONG_THREADS: four waves per SIMD - these phases are instruction chains, not bandwidth
     double* const xs = s_xy;
     double* const ys = s_xy + (size_t)K * d;
 
@@ -1128,15 +1138,17 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
     for (;;) {
         // ---- 1. members in order: ordered compaction of the next claims into the queue ----
         while (!scan_done && qcount < K + 1 && qcount + 1024 <= CC_LONG_QUEUE) {
-            const int i0 = scan_pos + tid * 4;
+            // (the first 256 threads scan 1 024 claims per pass; the others only keep the barriers company)
+            const bool scanner = tid < 256;
+            const int i0 = scan_pos + (scanner ? tid : 0) * 4;
             int4 v = make_int4(-1, -1, -1, -1);
-            if (i0 <= last_j) v = T4[i0 >> 2];
+            if (scanner && i0 <= last_j) v = T4[i0 >> 2];
             const int e[4] = {v.x, v.y, v.z, v.w};
             int f[4], cnt = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int j = i0 + c;
-                f[c] = (j >= head && j <= last_j && j < B && e[c] == t) ? 1 : 0;
+                f[c] = (scanner && j >= head && j <= last_j && j < B && e[c] == t) ? 1 : 0;
                 cnt += f[c];
             }
             int incl = cnt;
@@ -1146,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
                 if (lane >= off) incl += o;
             }
             __syncthreads();  // (s_wsum of the previous pass has been read)
-            if (lane == 63) s_wsum[wv] = incl;
+            if (lane == 63 && wv < 4) s_wsum[wv] = incl;
             __syncthreads();
             int base = 0, total = 0;
 #pragma unroll
@@ -1167,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
         const int n = qcount < K ? qcount : K;  // steps of this batch (the member after it is known, or the chain ends)
 
         // ---- 2. stage the points, then the sequential additions per dimension ----
-        for (int e = tid; e < n * d; e += 256) {
+        for (int e = tid; e < n * d; e += NT) {
             const int k = e / d, i = e - k * d;
             const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
             const double x = X[(cursor + m) * d + i];
@@ -1202,6 +1214,25 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
         __syncthreads();
 
         // ---- 3. every step evaluated on its own prefix ----
+        // (a) per (step, dimension), all threads: the two quotients, the variance, the term of the radius sum - the
+        // divisions are most of a step's instructions and independent of one another
+        if constexpr (SPLIT) {
+        for (int e = tid; e < n * d; e += NT) {
+            const int k = e / d, i = e - k * d;
+            const double w1 = s_w[k];
+            const double qa = ys[e] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
+            const double qb = xs[e] / w1;
+            const double var = qa - qb * qb;
+            const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
+            const double pr = prefd ? par.k : 1.0;
+            s_term[e] = cc_div_pref(var, pr, par);
+            s_pf[e] = prefd ? (unsigned char)1 : (unsigned char)0;
+            const double df = qb - s_c0[i];
+            s_dqt[e] = df * df * s_w0[i];
+        }
+        __syncthreads();
+        }
+        // (b) per step, one thread: the ordered sums over the dimensions (!SPLIT: the terms themselves as well)
         if (tid < n) {
             const int k = tid;
             const double w1 = s_w[k];
@@ -1209,16 +1240,24 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
             int gt1 = 0;
             unsigned long long mask = 0ull;
             for (int i = 0; i < d; ++i) {
-                const double qa = ys[k * d + i] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
-                const double qb = xs[k * d + i] / w1;
-                const double var = qa - qb * qb;
-                const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
-                const double pr = prefd ? par.k : 1.0;
-                r2 = r2 + cc_div_pref(var, pr, par);     // mc_functions.py:54, left to right
-                gt1 += (pr > 1.0) ? 1 : 0;
-                mask |= prefd ? (1ull << i) : 0ull;
-                const double df = qb - s_c0[i];
-                dq += df * df * s_w0[i];
+                if constexpr (SPLIT) {
+                    r2 = r2 + s_term[k * d + i];             // mc_functions.py:54, left to right
+                    dq += s_dqt[k * d + i];
+                    const bool prefd = s_pf[k * d + i] != 0;
+                    gt1 += (prefd && par.k > 1.0) ? 1 : 0;    // count(pref' > 1): pref' = k where preferred
+                    mask |= prefd ? (1ull << i) : 0ull;
+                } else {
+                    const double qa = ys[k * d + i] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
+                    const double qb = xs[k * d + i] / w1;
+                    const double var = qa - qb * qb;
+                    const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
+                    const double pr = prefd ? par.k : 1.0;
+                    r2 = r2 + cc_div_pref(var, pr, par);     // mc_functions.py:54, left to right
+                    gt1 += (pr > 1.0) ? 1 : 0;
+                    mask |= prefd ? (1ull << i) : 0ull;
+                    const double df = qb - s_c0[i];
+                    dq += df * df * s_w0[i];
+                }
             }
             const bool ok = r2 <= par.eps_sq;                          // hddstream.py:334-337
             const bool up = w1 >= par.beta_mu && gt1 <= par.pi;        // hddstream.py:416-417
@@ -1238,7 +1277,7 @@ __global__ __launch_bounds__(256) void k_chain_long(Ctl* __restrict__ ctl, const
         const int up_point = (u >= 0) ? s_queue[(qhead + u) & (CC_LONG_QUEUE - 1)] : -1;
 
         // ---- 4. version rows: vectors by (row, dimension), the rest by row ----
-        for (int e = tid; e < n_rows * d; e += 256) {
+        for (int e = tid; e < n_rows * d; e += NT) {
             const int k = e / d, i = e - k * d;
             const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
             const int src = (k < n_ok) ? k : k - 1;  // a rejected step leaves the state of the step before it
