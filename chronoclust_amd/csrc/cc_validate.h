@@ -863,6 +863,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     // its versions: the table row, unless (lookahead) the previous window changed it after that scan
     double c0[2] = {bce[0], bce[1]};
     double w0[2] = {1.0 / bpr[0], 1.0 / bpr[1]};
+    double binv[2] = {w0[0], w0[1]};  // 1 / bpr of the running state: divided anew only when a preferred dimension changes
     int kind0 = bkind;
     if (!isnew && ctl->mode != 0) {
         const unsigned long long co = tab.carry_of[t];
@@ -960,6 +961,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                     for (int h = 0; h < 2; ++h) {
                         bc1[h] = g.c1[h]; bc2[h] = g.c2[h];
                         bce[h] = g.cen[h];  // mc_functions.py:31-33: CF1 / W, the quotient the variance was formed from
+                        if (g.pr[h] != bpr[h]) binv[h] = 1.0 / g.pr[h];
                         bpr[h] = g.pr[h];
                     }
                     bw = w1;
@@ -987,7 +989,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 // threshold assumes the window-start metric)
                 bool mv = false;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) mv = mv || ((1.0 / bpr[h]) != w0[h]);
+                for (int h = 0; h < 2; ++h) mv = mv || (binv[h] != w0[h]);
                 if (isnew || bkind != kind0 || !(dq >= 0.0) || cc_group_ballot(mv) != 0u) dq = CC_INF;
                 if (gl == 0) {
                     ver.w[cur] = bw;
