@@ -21,3 +21,25 @@ for _name in _ALIASES:
     if "." not in _name:
         globals()[_name] = _mod
 del _name, _mod
+
+
+class _NoCounterpart(object):
+    """Import hook: the reference modules that have no counterpart here fail with a message that says why (instead of a
+    bare ModuleNotFoundError).  SURVEY.md section 8b, seam B4: not a viable GPU boundary - one microcluster x one point
+    per call."""
+    _NAMES = ("clustering.predecon", "objects.predecon_mc", "utilities", "utilities.mc_functions",
+              "utilities.predeconmc_functions")
+
+    def find_spec(self, fullname, path=None, target=None):
+        for pkg in (__name__, "chronoclust_amd"):
+            if fullname.startswith(pkg + ".") and fullname[len(pkg) + 1:] in self._NAMES:
+                raise ImportError(
+                    "%s has no counterpart in the MI355X build of chronoclust: the per-vector numba helpers and the "
+                    "PreDeCon classes of the reference (chronoclust/utilities/*.py, clustering/predecon.py, "
+                    "objects/predecon_mc.py) are HIP kernels behind the C-ABI of include/chronoclust_hip.h here.  Use "
+                    "chronoclust.app.run, chronoclust.clustering.hddstream.HDDStream (offline_clustering / final_clusters) "
+                    "or the chronoclust.tracking.cluster_tracker classes; see INTEGRATION.md." % fullname, name=fullname)
+        return None
+
+
+sys.meta_path.insert(0, _NoCounterpart())

@@ -186,8 +186,14 @@ def format_points_csv(values, first_id, label_idx, labels, threads=8, chunk=6553
     from concurrent.futures import ThreadPoolExecutor
     lib = load()
     values = _f64(values)
+    if values.ndim != 2:
+        raise ValueError("values must be a [n, d] array, got shape %r" % (values.shape,))
     n, d = values.shape
     label_idx = np.ascontiguousarray(label_idx, dtype=np.int32)
+    if label_idx.shape != (n,):  # (the C side reads n entries: a short array would be read past its end)
+        raise ValueError("label_idx must hold one entry per row: shape %r for %d rows" % (label_idx.shape, n))
+    if len(labels) < 1:
+        raise ValueError("labels must not be empty")
     enc = [s.encode() for s in labels]
     offs = np.zeros(len(enc) + 1, np.int32)
     offs[1:] = np.cumsum([len(e) for e in enc])

@@ -1049,8 +1049,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
 void comm_all_reduce_sum(cc_handle* h, double* buf, size_t count, hipStream_t st)
 {
     cc::Comm& cm = h->comm;
+    // (fail_group() drops the communicators, so a broken group no longer looks like an RCCL one: ask first)
+    if (cm.broken) throw cc::CommErr{"the group has failed earlier"};
     if (cm.rccl()) {
-        if (cm.broken) throw cc::CommErr{"the group has failed earlier"};
         cm.check(cc::RcclApi::get().AllReduce(buf, buf, count, ncclDouble, ncclSum, cm.lane(0), st), "ncclAllReduce");
         return;
     }
@@ -2268,9 +2269,14 @@ int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world)
         h->comm.broken = false;
         const char* to = getenv("CHRONOCLUST_HIP_COMM_TIMEOUT_S");
         if (to && atof(to) > 0.0) h->comm.timeout_s = atof(to);
-        // the second communicator (lookahead stream): its id is made by rank 0 and travels through the first one
-        const char* one = getenv("CHRONOCLUST_HIP_ONE_COMM");
-        if (!(one && one[0] == '1')) {
+        // ONE communicator serves both streams by default: RCCL then orders the lookahead scans' all-gathers (second
+        // stream) with those of the validation stream, which costs some overlap but is the mode every RCCL user runs.
+        // CHRONOCLUST_HIP_TWO_COMMS=1: a second communicator for the lookahead stream (its id is made by rank 0 and
+        // travels through the first one), so that the two streams' collectives are independent - concurrent
+        // communicators need both collective kernels co-resident on every rank and have never run on more than one
+        // GPU in a build session: opt-in until a multi-GPU run has confirmed them
+        const char* two = getenv("CHRONOCLUST_HIP_TWO_COMMS");
+        if (two && two[0] == '1') {
             DevBuf<char> ids;
             ids.ensure((size_t)world * sizeof(ncclUniqueId) + sizeof(ncclUniqueId));
             ncclUniqueId id2;
@@ -2427,7 +2433,7 @@ int64_t cc_format_points_csv(const double* values, int64_t n, int32_t d, int64_t
         const double* v = values + r * d;
         for (int i = 0; i < d; ++i) {
             *o++ = ',';
-            o += cc::format_repr(v[i], o);
+            if (v[i] == v[i]) o += cc::format_repr(v[i], o);  // (NaN: an empty field, DataFrame.to_csv's na_rep)
         }
         *o++ = '\n';
     }

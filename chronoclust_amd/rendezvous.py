@@ -15,10 +15,11 @@ and the handful of `torch.distributed`-style methods chronoclust_amd.multi calls
 is_initialized, all_gather_object, broadcast_object_list), so the same helpers serve either kind of group.
 Every wait has a deadline (default 300 s): a rank that is gone raises TimeoutError / ConnectionError in the others
 instead of hanging them."""
+import json
 import os
-import pickle
 import socket
 import struct
+import tempfile
 import time
 
 _MAGIC = b"CCRDZV1\n"
@@ -44,10 +45,20 @@ class HostGroup(object):
         ls.settimeout(self.timeout)
         self._listener = ls
         self._token = os.urandom(8).hex()
-        tmp = "%s.%d.tmp" % (self._file, os.getpid())
-        with open(tmp, "w") as f:
-            f.write("%d %s\n" % (ls.getsockname()[1], self._token))
-        os.replace(tmp, self._file)  # (a stale file of an earlier job with the same name is overwritten)
+        # the port and the token that admits a rank: readable by this user only, written to a name nobody can predict
+        # (mkstemp: O_CREAT | O_EXCL, mode 0600, so no symlink can be planted under it) and moved into place
+        fd, tmp = tempfile.mkstemp(prefix=os.path.basename(self._file) + ".", suffix=".tmp",
+                                   dir=os.path.dirname(self._file) or ".")
+        try:
+            with os.fdopen(fd, "w") as f:
+                f.write("%d %s\n" % (ls.getsockname()[1], self._token))
+            os.replace(tmp, self._file)  # (a stale file of an earlier job with the same name is overwritten)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
         deadline = time.monotonic() + self.timeout
         while len(self._peers) < self.world - 1:
             if time.monotonic() > deadline:
@@ -103,12 +114,12 @@ class HostGroup(object):
             parts = [payload] + [None] * (self.world - 1)
             for r, c in self._peers.items():
                 parts[r] = _recv_msg(c)
-            blob = pickle.dumps(parts)
+            blob = _pack_parts(parts)
             for c in self._peers.values():
                 _send_msg(c, blob)
             return parts
         _send_msg(self._sock, payload)
-        return pickle.loads(_recv_msg(self._sock))
+        return _unpack_parts(_recv_msg(self._sock), self.world)
 
     def barrier(self):
         self.all_gather_bytes(b"")
@@ -134,13 +145,16 @@ class HostGroup(object):
     def is_initialized(self):
         return True
 
+    # (payloads are bytes or JSON-able values - what multi.py sends: the RCCL id, digests, small lists; nothing a peer
+    # sends is ever unpickled or evaluated)
     def all_gather_object(self, box, obj):
-        for i, p in enumerate(self.all_gather_bytes(pickle.dumps(obj))):
-            box[i] = pickle.loads(p)
+        for i, p in enumerate(self.all_gather_bytes(_encode_obj(obj))):
+            box[i] = _decode_obj(p)
 
     def broadcast_object_list(self, box, src=0):
-        got = pickle.loads(self.broadcast_bytes(pickle.dumps(list(box)) if self.rank == src else b"", src))
-        box[:] = got
+        blob = _pack_parts([_encode_obj(x) for x in box]) if self.rank == src else b""
+        got = self.broadcast_bytes(blob, src)
+        box[:] = [_decode_obj(p) for p in _unpack_parts(got, len(box))]
 
     def close(self):
         for c in list(self._peers.values()) + [self._sock, self._listener]:
@@ -190,3 +204,39 @@ def _send_msg(c, payload):
 
 def _recv_msg(c):
     return _recv_exact(c, struct.unpack("<q", _recv_exact(c, 8))[0])
+
+
+def _pack_parts(parts):
+    """[bytes, ...] -> one frame: count, then length-prefixed items."""
+    return struct.pack("<i", len(parts)) + b"".join(struct.pack("<q", len(p)) + p for p in parts)
+
+
+def _unpack_parts(blob, expect):
+    n = struct.unpack_from("<i", blob, 0)[0]
+    if n != expect:
+        raise ConnectionError("rendezvous: malformed frame (%d parts, %d expected)" % (n, expect))
+    out, off = [], 4
+    for _ in range(n):
+        ln = struct.unpack_from("<q", blob, off)[0]
+        off += 8
+        if ln < 0 or off + ln > len(blob):
+            raise ConnectionError("rendezvous: malformed frame")
+        out.append(bytes(blob[off:off + ln]))
+        off += ln
+    return out
+
+
+def _encode_obj(obj):
+    """bytes as they are; anything else as JSON (numbers, strings, lists, dicts, None): data, never code."""
+    if isinstance(obj, (bytes, bytearray)):
+        return b"B" + bytes(obj)
+    return b"J" + json.dumps(obj).encode("utf-8")
+
+
+def _decode_obj(p):
+    tag, body = p[:1], p[1:]
+    if tag == b"B":
+        return body
+    if tag == b"J":
+        return json.loads(body.decode("utf-8"))
+    raise ConnectionError("rendezvous: malformed object frame")

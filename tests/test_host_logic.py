@@ -170,6 +170,18 @@ def test_points_csv_formatter_writes_repr_bytes():
         assert _lib.format_points_csv(Y, 0, idx, quoted, threads=threads, chunk=chunk, out=sink) == len(got)
         assert sink.getvalue() == got
     assert _lib.format_points_csv(np.empty((0, 3)), 0, np.empty(0, np.int32), ["None"], out=io.BytesIO()) == 0
+    # NaN is an empty field, +-inf is spelled out: pandas' defaults
+    Z = np.array([[1.5, np.nan, -np.inf], [np.nan, np.inf, 2.0]])
+    f = io.StringIO()
+    pd.DataFrame({"id": [0, 1], "cluster_id": ["C", "C"], "a": Z[:, 0], "b": Z[:, 1], "c": Z[:, 2]}).to_csv(f, index=False, header=False)
+    assert _lib.format_points_csv(Z, 0, np.array([2, 2], np.int32), quoted) == f.getvalue().encode()
+    # a label array that does not cover the rows is refused before the C side could read past it
+    with pytest.raises(ValueError):
+        _lib.format_points_csv(Y, 0, idx[:10], quoted)
+    with pytest.raises(ValueError):
+        _lib.format_points_csv(Y, 0, np.empty(0, np.int32), quoted)
+    with pytest.raises(ValueError):
+        _lib.format_points_csv(Y[0], 0, idx[:1], quoted)
 
 
 def test_rounded_weights_equal_the_reference_expression():
@@ -214,3 +226,17 @@ def test_point_cluster_index_maps_points_through_microclusters_to_clusters():
     assert got.tolist() == [0, 1, 0, -1, 1, -1]
     assert multi.point_cluster_index(np.array([3, 4]), np.array([], int), np.array([], int), np.array([], int),
                                      np.array([0])).tolist() == [-1, -1]
+
+
+@pytest.mark.parametrize("stmt", ["import chronoclust.clustering.predecon", "from chronoclust.clustering import predecon",
+                                  "from chronoclust.utilities import mc_functions", "import chronoclust.objects.predecon_mc",
+                                  "import chronoclust.utilities.predeconmc_functions"])
+def test_reference_modules_without_counterpart_say_why(stmt):
+    """chronoclust/clustering/predecon.py:22 & co. are kernels here (seam B4): importing them fails with a
+    message that names the replacement, not with a bare ModuleNotFoundError."""
+    import chronoclust  # noqa: F401
+    with pytest.raises(ImportError, match="no counterpart in the MI355X build") as e:
+        exec(stmt, {})
+    assert not isinstance(e.value, ModuleNotFoundError)
+    with pytest.raises(ModuleNotFoundError):
+        exec("import chronoclust.no_such_module", {})

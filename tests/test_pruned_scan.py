@@ -95,6 +95,42 @@ def test_forced_pruning_matches_the_oracle(seed, n, d, g, sigma, over, tuning, s
     print("seed %d d %d: %d pruned launches, %.1f %% of the sampled (wave, row) pairs completed" % (seed, d, launches, 100.0 * full / rows))
 
 
+# Coordinates outside single precision's range (|x| >= 2^128: float(p) and float(c) are both +inf, their difference NaN)
+# and far below it (squares underflow to 0): phase A must keep what it cannot judge.  `normalise_data=False` makes such
+# float64 input legal (app.py:172-176), and the reference handles it like any other.
+EXTREME = [
+    # (name, factor applied to every coordinate, (dimension, factor) applied to one column or None)
+    ("2^70", 2.0 ** 70, None),        # squares overflow single precision (2^140), coordinates do not
+    ("2^130", 2.0 ** 130, None),      # coordinates themselves overflow single precision: inf - inf in the prefix
+    ("2^-80", 2.0 ** -80, None),      # squares underflow single precision
+    ("one huge prefix column", 1.0, (3, 2.0 ** 130)),
+    ("one huge late column", 1.0, (13, 2.0 ** 130)),
+]
+
+
+@pytest.mark.parametrize("name,scale,column", EXTREME, ids=[e[0] for e in EXTREME])
+@pytest.mark.parametrize("prune", [2, 1])
+def test_coordinates_outside_single_precision_range(name, scale, column, prune):
+    from oracle import oracle as O
+    n, d, g = 5000, 20, 80
+    eps = 0.05 * scale * (column[1] if column else 1.0)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=eps))
+    h = _hdd(cfg, prune, window=1024)
+    o = O.OracleHDDStream(cfg)
+    launches = 0
+    for t in range(2):
+        X = scenarios.make_blobs(900 + t, n, d, g) * scale  # (a power of two: exact)
+        if column:
+            X[:, column[0]] *= column[1]
+        assert np.isfinite(X).all()
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _against_oracle(h, o)
+        launches += h.stats()["scan_p_launches"]
+    if prune == 2:
+        assert launches > 0
+
+
 @pytest.mark.parametrize("F", [1, 2, 64, 4096])
 def test_threshold_factor_never_changes_a_result(F):
     """F = 1 (thresholds equal to the seed's distance: bounds everywhere, the second-best almost never exact) up to
