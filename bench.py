@@ -21,11 +21,16 @@ also carries, as side legs (strong scaling: ONE stream, all N GPUs):
 Every leg carries `n_gpus`, `collective`, `rccl_ranks_seen` and a `roofline` object of its own scan kernel.
 
 No torch anywhere: the timing bracket is cc_sync (HIP stream synchronise through the C-ABI), barrier / max over
-ranks / the 128-byte RCCL id travel over chronoclust_amd.rendezvous (TCP on 127.0.0.1).  Any launcher that sets
-RANK / WORLD_SIZE / LOCAL_RANK will do:
+ranks / the 128-byte RCCL id travel over chronoclust_amd.rendezvous (TCP on 127.0.0.1).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+        N > 1 and no launcher's RANK / WORLD_SIZE in the environment: THIS process starts the N ranks itself - fresh
+        child processes, one per GPU (LOCAL_RANK = device), before anything here has touched HIP or RCCL -, relays
+        rank 0's line and exits with the worst child's status (launch_ranks below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK will do as well (only the launcher of torch is used)
+    python bench.py --gpus N --dry-launch
+        the ranks only meet (rendezvous, barrier) and rank 0 prints who came: the launch path without a GPU
 
 Prints ONE JSON line on rank 0.  Exit status: 0 when every leg ran; 3 when a leg was abandoned (a collective that
 never completed) or failed - the line is still printed, with the error in that leg's object.
@@ -121,6 +126,65 @@ class LineGuard:
             os.close(self._w)
             self._w = None
             os.waitpid(self._pid, 0)
+
+
+def launch_ranks(n_ranks, argv):
+    """`bench.py --gpus N` started without a launcher: N ranks as fresh child processes of this one, which has not
+    loaded the HIP library and never will (a process that has touched the GPU must not be re-executed, and does not
+    have to be).  Every child gets RANK / LOCAL_RANK / WORLD_SIZE, a rendezvous file in a private directory and the
+    same command line; all devices stay visible to every rank (RCCL wants to see its peers) and a rank picks device
+    LOCAL_RANK.  Rank 0 inherits stdout - its ONE line is this job's line -, the other ranks' stdout goes to stderr.
+    Returns the exit status: 0 when every rank left with 0, else the worst one (a signal counts as 128 + number).
+    A rank that fails takes the job down: the others get 60 s to notice through their own bounded waits, then SIGTERM."""
+    import shutil
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="chronoclust_bench_")
+    env = dict(os.environ)
+    env["WORLD_SIZE"] = str(n_ranks)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env["CHRONOCLUST_RDZV_FILE"] = os.path.join(tmp, "rendezvous")
+    env["CHRONOCLUST_BENCH_LAUNCHER"] = "bench.py"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs between processes on this host driver)
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    try:
+        for r in range(n_ranks):
+            procs.append(subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                          stdout=None if r == 0 else sys.stderr))
+
+        def forward(sig, _frame):
+            for p in procs:
+                if p.poll() is None:
+                    p.send_signal(sig)
+
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            signal.signal(sig, forward)
+        first_failure = None
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.05)
+            if first_failure is None and any(p.poll() not in (None, 0) for p in procs):
+                first_failure = time.monotonic()
+            if first_failure is not None and time.monotonic() - first_failure > 60.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                grace = time.monotonic() + 10.0
+                while any(p.poll() is None for p in procs) and time.monotonic() < grace:
+                    time.sleep(0.05)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+        codes = [p.wait() for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("[bench] ranks that did not exit cleanly: %s\n" % ", ".join("rank %d -> %d" % rc for rc in bad))
+    return max((c if c >= 0 else 128 - c) for c in codes)
 
 
 def make_blobs(seed, n, d, g, sigma=0.01):
@@ -246,6 +310,20 @@ def join_group(h, rank, world, group):
     return [int(x) for x in seen]
 
 
+def split_note(s, info, world, d, min_row_dims):
+    """What the leg's line says about the row split - from what the library did (cc_stats, cc_comm_info), not assumed."""
+    rows = int(s["rows"])
+    if s["sharded_windows"]:
+        return ", each of %d rank(s) scans 1/%d of the table rows per window (%d windows split)" % (
+            info["world"], info["world"], int(s["sharded_windows"]))
+    if info["transport"] == "none":
+        return "; one rank without a group: nothing to split"
+    if rows * d < min_row_dims:
+        return "; the final table (%d rows x %d dims = %d) is below this leg's split threshold of %d (row, dim) entries: " \
+               "every rank scans all rows" % (rows, d, rows * d, min_row_dims)
+    return "; no window was split although the final table (%d x %d) is above the threshold of %d" % (rows, d, min_row_dims)
+
+
 def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, force_split=False):
     """ONE stream on all ranks (exact multi-GPU path).  Every rank generates the same input."""
     from chronoclust_amd import multi
@@ -254,9 +332,12 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     cfg = blob_config(n)
     h = _lib.Handle(local_rank)
     h.set_tuning(time_kernels=1)
-    seen = join_group(h, rank, world, group) if (world > 1 or force_split) else [1]
-    if force_split:
-        h.set_shard_thresholds(0, 0)
+    if world > 1 or force_split:
+        seen = join_group(h, rank, world, group)
+    else:  # one rank, no group: what every rank's library says about itself (cc_comm_info), gathered like the others
+        seen = [int(x) for x in group.all_gather_bytes(b"%d" % h.comm_info()["world"])]
+    # the split threshold of this leg (the library's own default is the same figure): stated in the line below
+    h.set_shard_thresholds(0 if force_split else args.shard_min_row_dims, 0 if force_split else -1)
     set_params(h, cfg, n, d)
     h.points_upload(X)
     del X
@@ -273,11 +354,12 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     sync(h)
     t0 = time.perf_counter()
     acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0,
-               scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0)
+               scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0, sharded_windows=0)
     for _ in range(args.stream_steps):
         s, n_clusters = step()
         for k in acc:
             acc[k] += s[k]
+    s = dict(s, sharded_windows=acc["sharded_windows"])
     sync(h)
     elapsed = time.perf_counter() - t0
     elapsed = multi.max_over_ranks(elapsed, group)
@@ -290,17 +372,17 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     return {
         "workload": "%s: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters, exact sequential "
                     "semantics; online + offline phases per step; every rank holds the table and the points%s" % (
-                        label, n, d, g, ", scans 1/%d of the table rows per window" % world if s["sharded_windows"] else
-                        "; the table is below the split threshold (rows x d < 400 000): every rank scans all rows"),
+                        label, n, d, g, split_note(s, info, world, d, 0 if force_split else args.shard_min_row_dims)),
         "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
         "n_gpus": world, "rccl_ranks_seen": seen, "steps": args.stream_steps, "warmup": args.stream_warmup,
         "ms_per_step": 1e3 * elapsed / args.stream_steps,
         "collective": "none (one rank, no group)" if info["transport"] == "none" else (
-            "%s all-gather of 64 B per window point on the scan's stream (two communicators, one per stream), %d per "
-            "step; offline: all-gather of preference vectors + reachability bitmask" % (
-                info["transport"], int(acc["comm_launches"] / args.stream_steps))),
+            "%s all-gather of 64 B per window point on the scan's stream, %d per step; offline: all-gather of preference "
+            "vectors + reachability bitmask" % (info["transport"], int(acc["comm_launches"] / args.stream_steps))),
+        "transport": info["transport"],
         "microclusters": int(s["rows"]), "clusters": n_clusters, "windows_per_step": int(s["windows"]),
-        "sharded_windows_per_step": int(s["sharded_windows"]),
+        "sharded_windows_per_step": int(s["sharded_windows"] / args.stream_steps),
+        "pruned_scan_launches_per_step": int(acc["scan_p_launches"] / args.stream_steps),
         "rank0_online_ms_per_step": acc["run_ms"] / args.stream_steps,
         "rank0_scan_ms_per_step": acc["scan_ms"] / args.stream_steps,
         "rank0_exchange_ms_per_step": acc["comm_ms"] / args.stream_steps,
@@ -368,6 +450,7 @@ def relaxed_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label
     pc = h.export(_lib.PCORE)
     pci = multi.point_cluster_index(uid, pc["id"], pc["uid"], arrays[0], arrays[1])
     n_clusters = len(arrays[2])
+    transport = h.comm_info()["transport"]
     h.comm_destroy()
     h.close()
     out = {
@@ -383,6 +466,7 @@ def relaxed_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label
                       "indices per super-step, %d super-steps per step" % (int(s["rows"]), d, rs["super_steps"]),
         "microclusters": int(s["rows"]), "clusters": n_clusters,
         "set_aside_points_per_step": rs["deferred_points"], "all_ranks_bit_identical": bool(agree_ranks),
+        "transport": transport,
         "roofline": scan_roofline(acc, d, scan_kernel_name(s, d)),
     }
     if rank == 0:
@@ -446,7 +530,14 @@ def main():
     ap.add_argument("--relaxed-minibatch", type=int, default=65536, help="points per rank and super-step")
     ap.add_argument("--no-c2-legs", action="store_true", help="skip the two C2-shaped strong-scaling legs")
     ap.add_argument("--only-leg", default=None, help="profiling: only this leg, after a token headline (20 000 points, 100 microclusters, no CPU baseline)")
+    ap.add_argument("--dry-launch", action="store_true", help="the ranks only rendezvous and rank 0 prints who came (no GPU is touched)")
+    ap.add_argument("--shard-min-row-dims", type=int, default=400_000,
+                    help="one-stream legs: a snapshot scan is split over the ranks from this many (row, dim) entries on")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # no launcher: start the N ranks from here (nothing in this process has loaded the HIP library)
+        sys.stdout.flush()
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     # stdout carries exactly ONE line, the JSON: native libraries (RCCL prints its path when a communicator is
     # created) and anything else that writes to file descriptor 1 during the run go to stderr instead
@@ -455,6 +546,19 @@ def main():
     os.dup2(2, 1)
     from chronoclust_amd import multi, rendezvous
     rank, world, local_rank = multi.rank_info()
+    if world != args.gpus:
+        sys.stderr.write("[bench rank %d] --gpus %d, but the launcher started %d rank(s): the launcher's count is what "
+                         "runs and what the line reports\n" % (rank, args.gpus, world))
+    if args.dry_launch:
+        group = rendezvous.from_env(timeout=60.0)
+        came = group.all_gather_bytes(json.dumps({"rank": rank, "local_rank": local_rank, "pid": os.getpid()}).encode())
+        group.barrier()
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"dry_launch": True, "n_gpus": world, "gpus_requested": args.gpus,
+                                           "launcher": os.environ.get("CHRONOCLUST_BENCH_LAUNCHER", "external"),
+                                           "ranks": [json.loads(x) for x in came]}) + "\n").encode())
+        group.close()
+        sys.exit(0)
     guard = LineGuard(json_fd) if rank == 0 else None  # (before HIP or RCCL exist in this process)
 
     def emit(obj):
@@ -588,6 +692,12 @@ def main():
     h.close()
     del X
     if rank == 0:
+        out["strong_scaling"] = {
+            "note": "`value` above is N independent streams (one per GPU, no data-path collective); the entries here are ONE "
+                    "stream clustered by all %d rank(s): points of that one stream per second.  The 20-dim metric's own "
+                    "shape: one_stream_exact_c2 (exact) and events_sharded_relaxed_c2 (relaxed, not the reference's "
+                    "semantics).  Full objects: the keys of the same names" % world,
+            "n_gpus": world, "rccl_ranks_seen": None}
         guard.provisional(out)  # from here on the headline is safe whatever happens to the legs below
 
     legs = []
@@ -631,6 +741,14 @@ def main():
         timer.cancel()
         if rank == 0:
             out[name] = leg
+            if "error" not in leg:
+                # the strong-scaling figures - ONE stream on all ranks - at the top level, beside the replicas headline
+                out["strong_scaling"]["rccl_ranks_seen"] = leg.get("rccl_ranks_seen")
+                out["strong_scaling"][name] = {
+                    k: leg.get(k) for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks_seen", "transport",
+                                            "sharded_windows_per_step", "pruned_scan_launches_per_step",
+                                            "all_ranks_bit_identical", "agreement_with_exact_by_cluster") if k in leg}
+                out["strong_scaling"][name]["semantics"] = "relaxed" if "relaxed" in name else "exact"
         # the ranks must agree on whether to go on: one that failed may have left the others' group
         failed = not group.all_equal(b"ok" if "error" not in leg else b"failed:" + str(rank).encode()) or "error" in leg
         if failed:

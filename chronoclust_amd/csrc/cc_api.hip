@@ -136,6 +136,7 @@ struct cc_handle {
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
+    DevBuf<unsigned long long> pstat; // [2][2]     a split pruned scan's sample {rows visited, rows completed} per window parity
     size_t spart_stride = 0, thr_stride = 0;
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
@@ -433,6 +434,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->thr.ensure(2 * h->thr_stride);
     h->thr32.ensure(2 * h->thr_stride);
     h->cmax.ensure(2);
+    h->pstat.ensure(4);
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
@@ -507,7 +509,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
         if (scan_u_applies(h, DP)) {
             ++h->stats.scan_u_launches;
             if constexpr (DP > 8) {
-                if (h->prune_now && shard_world == 1) {
+                if (h->prune_now) {
                     // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them
                     ++h->stats.scan_p_launches;
                     // (k_seed holds two points per lane: point tiles of 128)
@@ -515,10 +517,12 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                        rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p);
                     hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
                                        rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
-                                       h->prune_F, round, mode, h->cmax.p);
+                                       h->prune_F, round, mode, h->cmax.p, h->pstat.p);
+                    // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
+                    // that every rank abandons against the same T -, phases A / B over the rank's own rows)
                     hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                        rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                       h->part_stride);
+                                       h->part_stride, shard_rank, shard_world, h->pstat.p);
                     return;
                 }
             }
@@ -1241,8 +1245,11 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         // (a communicator of one rank takes the same path: that is how the RCCL calls are exercised on one GPU)
         const bool grouped = h->comm.active();
         if (grouped) {
-            h->gsend_stride = (size_t)h->win_alloc * 4;
-            h->gpart_stride = (size_t)world * h->win_alloc * 4;
+            // (+ 4: the record behind the last point's carries the rank's pruned-scan sample, see k_merge_partials)
+            // (grids cover at least 64 points, see gw below: the blocks are sized for that even when the window is smaller)
+            const size_t gmax = (size_t)std::max(64, h->win_alloc);
+            h->gsend_stride = gmax * 4 + 4;
+            h->gpart_stride = (size_t)world * (gmax * 4 + 4);
             h->gsend.ensure(2 * h->gsend_stride);
             h->gpart.ensure(2 * h->gpart_stride);
         }
@@ -1321,6 +1328,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         // no carry set yet: the commit record of an earlier call describes rows that may have moved since
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
+        HIPCHK(hipMemsetAsync(h->pstat.p, 0, 4 * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
@@ -1495,9 +1503,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         const int q = (mode == 1) ? (round & 1) : (int)(seq_host & 1ull);
                         if (timing) HIPCHK(hipEventRecord(get_event(h, ev_used), st));
                         hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
-                                           h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode);
+                                           h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode,
+                                           (const unsigned long long*)(h->prune_now && sworld > 1 ? h->pstat.p : nullptr), gw * 4);
                         h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
-                                           (size_t)gw * 4 * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
+                                           ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
                         if (timing) {
                             HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
                             timed_comm.push_back(ev_used);
@@ -1509,7 +1518,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 const Cand* const dec_part = shard_on ? h->gpart.p : h->part.p;
                 const size_t dec_stride = shard_on ? h->gpart_stride : h->part_stride;
                 const int dec_S = shard_on ? world : S, dec_inner = shard_on ? 1 : S;
-                const size_t dec_outer = shard_on ? (size_t)gw * 4 : 0;
+                const size_t dec_outer = shard_on ? (size_t)gw * 4 + 4 : 0;
+                const int dec_tail = shard_on ? gw * 4 : -1;  // where each rank's pruned-scan sample sits in its block
                 if (la_on) {
                     // first stream: this window's snapshot scan (enqueued one iteration ago on the second stream)
                     if (evScan) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));
@@ -1536,7 +1546,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                    dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                    h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap);
+                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 for (int r = 1; r <= Rcur; ++r) {
@@ -1569,7 +1579,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
-                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap);
+                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }

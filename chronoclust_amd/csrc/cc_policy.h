@@ -46,7 +46,7 @@ public:
         la_on_ = c_.lookahead == 3;
         nodirty_ = false;
         shard_on_ = policy_want_shard(c_, m_rows);
-        prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_;
+        prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0;  // (independent of the split: k_scan_p takes a row range)
         prune_resume_at_ = 0;
         prune_backoff_ = 65536;
         stalled_ = 0;
@@ -158,7 +158,7 @@ public:
         const bool shard_next = policy_want_shard(c_, o.m_rows);
         const bool shard_flip = shard_next != shard_on_;
         shard_on_ = shard_next;
-        const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 && !shard_on_ &&
+        const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 &&
                                 ((c_.prune_mode == 2 && prune_resume_at_ != std::numeric_limits<long long>::max()) ||
                                  o.cursor >= prune_resume_at_ ||
                                  // a settled stream (no tile needed its dirty scan: nothing created, promoted or moved far)

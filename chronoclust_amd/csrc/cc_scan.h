@@ -1120,12 +1120,15 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
                                                    const double* __restrict__ g_cen, const double* __restrict__ g_scl,
                                                    const SeedCand* __restrict__ spart, size_t spart_stride, int S,
                                                    double* __restrict__ thr, float* __restrict__ thr32, size_t thr_stride,
-                                                   double F, int round, int mode, const unsigned long long* __restrict__ cmax)
+                                                   double F, int round, int mode, const unsigned long long* __restrict__ cmax,
+                                                   unsigned long long* __restrict__ pstat)
 {
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = t >> 1, K = t & 1;
     if (j >= win.B) return;
+    // the sample counters of this window's k_scan_p (split scans only: see there) start at zero
+    if (t < 2) pstat[win.q * 2 + t] = 0ull;
     constexpr int d = DP;  // (the pruned scan runs for d == DP only: every loop below unrolls, its loads go out together)
     spart += (size_t)win.q * spart_stride;
     thr += (size_t)win.q * thr_stride;
@@ -1209,7 +1212,8 @@ template <int DP, int NW>
 __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3 : 2))) void k_scan_p(
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
-    const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride)
+    const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride,
+    int shard_rank, int shard_world, unsigned long long* __restrict__ pstat)
 {
     static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
     const ScanWin win = cc_scan_window(ctl, round, mode);
@@ -1225,9 +1229,13 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     const int S = gridDim.y;
     const int nsub = S * NW;
     const int sub = blockIdx.y * NW + wv;
-    const int per = (win.rows + nsub - 1) / nsub;
-    const int r0 = sub * per;
-    const int r1 = min(win.rows, r0 + per);
+    // exact multi-GPU path: this rank's block of the table rows (the thresholds come from seeds over ALL rows, computed
+    // by every rank alike, so every rank abandons against the same T)
+    int row_lo = 0, row_hi = win.rows;
+    if (shard_world > 1) cc_shard_range(win.rows, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int per = (row_hi - row_lo + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
     const size_t n_pts = (size_t)ctl->xt_stride;
     const int jj = j0 + lane;
     const bool valid = jj < B;
@@ -1387,9 +1395,14 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     if (dropped[1]) lb[1] = cc_vmin(lb[1], th[1]);
     // statistics for the host's policy: a sample - the waves of the window's first point tile (atomics of every wave on
     // one address serialise: 30 000 of them cost more than the scan)
+    // A split scan's sample describes this rank's rows only, and the host policy that reads the counters has to decide
+    // alike on every rank: the sample then goes to the window's own pair of counters, travels with the rank's candidate
+    // records (k_merge_partials) and k_decide adds up what all ranks sent - the same sum everywhere.
     if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
-        atomicAdd(&ctl->stat_prune_rows, (unsigned long long)n_rows);
-        atomicAdd(&ctl->stat_prune_full, (unsigned long long)n_full);
+        unsigned long long* const rows_to = shard_world > 1 ? pstat + win.q * 2 : &ctl->stat_prune_rows;
+        unsigned long long* const full_to = shard_world > 1 ? pstat + win.q * 2 + 1 : &ctl->stat_prune_full;
+        atomicAdd(rows_to, (unsigned long long)n_rows);
+        atomicAdd(full_to, (unsigned long long)n_full);
     }
 
     // the survivors' list-order keys; every kind's pair then takes in the bound of what the wave abandoned; the waves'
@@ -1436,7 +1449,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
 
 __global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ ctl, const Cand* __restrict__ part,
                                                         size_t part_stride, int S, Cand* __restrict__ out,
-                                                        size_t out_stride, int round, int mode)
+                                                        size_t out_stride, int round, int mode,
+                                                        const unsigned long long* __restrict__ pstat, int tail_at)
 {
     int B, q;
     if (mode == 1) {
@@ -1447,6 +1461,13 @@ __global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ 
         B = ctl->win_b;
     }
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    // the record behind the last point's: this rank's sample of its pruned scan (k_scan_p), {rows visited, rows completed},
+    // zeros after a plain scan - gathered with the candidates, summed over the ranks by k_decide
+    if (j == 0) {
+        Cand tail = Cand{0.0, 0, 0};
+        if (pstat != nullptr) { tail.key = (int)pstat[q * 2]; tail.slot = (int)pstat[q * 2 + 1]; }
+        out[(size_t)q * out_stride + (size_t)tail_at] = tail;
+    }
     if (j >= B) return;
     part += (size_t)q * part_stride;
     out += (size_t)q * out_stride;

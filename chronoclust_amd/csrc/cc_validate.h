@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
-                                                int* __restrict__ long_list, int long_cap)
+                                                int* __restrict__ long_list, int long_cap, int stat_tail)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -523,6 +523,20 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     }
     const int B = ctl->win_b;
     if (B == 0) return;
+    // exact multi-GPU path: the ranks' samples of their split pruned scans (the record behind each rank's candidates,
+    // k_merge_partials) add up to the counters the host policy reads - the same sum on every rank
+    if (round == 0 && stat_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        const Cand* g = part + (size_t)(ctl->window_seq & 1ull) * part_stride + (size_t)stat_tail;
+        unsigned long long rows = 0ull, full = 0ull;
+        for (int r = 0; r < S; ++r) {
+            rows += (unsigned long long)(unsigned)g[(size_t)r * part_outer].key;
+            full += (unsigned long long)(unsigned)g[(size_t)r * part_outer].slot;
+        }
+        if (rows > 0ull) {
+            atomicAdd(&ctl->stat_prune_rows, rows);
+            atomicAdd(&ctl->stat_prune_full, full);
+        }
+    }
     if (round > 0 && ctl->fc[round - 1] >= B) return;
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);

@@ -171,7 +171,8 @@ def test_c4_full_size_association_argmin_matches_oracle(c4):
 
 def test_eight_ranks_exact_at_the_c5_shape():
     """2 M x 40, 50 000 microclusters, EIGHT ranks with the default thresholds (scan split once rows x d >= 400 000,
-    offline pair matrices once there are 8 192 pcores): every rank bit-equal to one GPU."""
+    offline pair matrices once there are 8 192 pcores): every rank bit-equal to one GPU - with pruned scans among the
+    split ones (round 4: a group no longer trades the pruned scan for the row split)."""
     from test_sharded_local import run_group
     n, d, g = 2_000_000, 40, 50_000
     X = scenarios.make_blobs(42, n, d, g)
@@ -182,6 +183,10 @@ def test_eight_ranks_exact_at_the_c5_shape():
         P.same_results(r, single)
         st = r[0]["stats"]
         assert 0 < st["sharded_windows"] <= st["windows"]
+        assert st["scan_p_launches"] > 0
+    print("C5-shaped, 8 ranks: %d windows, %d split, %d pruned launches of %d, %.2f %% of the sampled rows completed" % (
+        st["windows"], st["sharded_windows"], st["scan_p_launches"], st["scan_u_launches"],
+        100.0 * st["pruned_scan_full_rows"] / max(1, st["pruned_scan_rows"])))
     assert len(single[0]["pcore"]["id"]) + len(single[0]["outlier"]["id"]) == g
 
 

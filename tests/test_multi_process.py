@@ -256,3 +256,43 @@ def test_bench_line_survives_the_death_of_the_process():
         assert obj["value"] == 1.0
         assert ("incomplete" in obj) == (mode != "final")
         assert ("one_stream_exact" in obj) == (mode == "final")
+
+
+def _bench(*argv, env=None, timeout=120):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "CHRONOCLUST_RDZV_FILE")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True,
+                          timeout=timeout, env=e)
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_starts_its_own_ranks(n):
+    """`python bench.py --gpus N` without a launcher (the form the driver uses at N = 1): the process itself starts N fresh
+    ranks - before anything touched the GPU - and relays rank 0's ONE line.  --dry-launch: the ranks only meet."""
+    import json
+    out = _bench("--gpus", str(n), "--dry-launch")
+    assert out.returncode == 0, out.stderr
+    lines = [x for x in out.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, out.stdout
+    obj = json.loads(lines[0])
+    assert obj["dry_launch"] is True and obj["n_gpus"] == n and obj["launcher"] == "bench.py"
+    assert [r["rank"] for r in obj["ranks"]] == list(range(n)) == [r["local_rank"] for r in obj["ranks"]]
+    assert len({r["pid"] for r in obj["ranks"]}) == n  # n processes, none of them this one's child re-executed in place
+
+
+def test_bench_under_an_external_launcher_does_not_spawn():
+    """With RANK / WORLD_SIZE in the environment (torch.distributed.run, srun, ...) bench.py is one rank of that job."""
+    import json
+    out = _bench("--gpus", "1", "--dry-launch", env=dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert out.returncode == 0, out.stderr
+    obj = json.loads(out.stdout.strip())
+    assert obj["n_gpus"] == 1 and obj["launcher"] == "external" and len(obj["ranks"]) == 1
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """A rank that dies takes the job's exit status with it (here: every rank fails at once on an unknown flag)."""
+    out = _bench("--gpus", "2", "--dry-launch", "--no-such-flag")
+    assert out.returncode != 0

@@ -16,12 +16,22 @@ import scenarios
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0):
+def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0, env=None):
     """The pipeline of app.run on `world` replicas of one stream, one thread per rank.  Returns the per-timepoint
-    results of every rank."""
+    results of every rank.  env: knobs the library reads when a handle is created (CHRONOCLUST_HIP_PRUNE ...)."""
+    import os
     from chronoclust_amd import _lib
     from chronoclust_amd.clustering.hddstream import HDDStream
-    streams = [HDDStream(cfg, tuning=tuning) for _ in range(world)]
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update({k: str(v) for k, v in (env or {}).items()})
+    try:
+        streams = [HDDStream(cfg, tuning=tuning) for _ in range(world)]
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     _lib.comm_init_local([s._h for s in streams])
     for r, s in enumerate(streams):
         s._h.set_shard_thresholds(min_row_dims, offline_min_rows)
@@ -157,3 +167,52 @@ def test_sharded_group_with_tiny_timepoints():
     single = P.run_pipeline(Xs, cfg)
     for res in run_group(3, Xs, cfg):
         P.same_results(res, single)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# pruned snapshot scans split over the ranks (round 4): seeds and thresholds over all rows on every rank, phases A / B
+# over the rank's rows, the rank's sample of completed rows gathered with its candidate records
+# ---------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("seed", range(0, 96, 4))
+def test_forced_pruning_fuzz_in_a_group(seed, world):
+    """The forced-pruning fuzz of tests/test_pruned_scan.py with every scan split over 2 / 3 ranks: the oracle's
+    results on every rank, and the pruned kernels really ran split."""
+    from oracle import oracle as O
+    from test_pruned_scan import _fuzz_case
+    cfg, window, lookahead, F, Xs = _fuzz_case(seed)
+    res = run_group(world, Xs, cfg, tuning=dict(window=window, lookahead=lookahead),
+                    env=dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_PRUNE_F=F))
+    o = O.OracleHDDStream(cfg)
+    for t, X in enumerate(Xs):
+        o.online_microcluster_maintenance(X, t)
+        for rank in range(world):
+            r = res[rank][t]
+            assert np.array_equal(r["labels_uid"], o.labels_uid)
+            assert r["counters"] == o.counters
+            for kind, name in ((0, "pcore"), (1, "outlier")):
+                b = o.table(kind)
+                for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+                    assert np.array_equal(r[name][key], b[key]), (t, rank, kind, key)
+            assert r["members"] == [[int(x) for x in c["members"]] for c in o.clusters]
+    st = [r["stats"] for r in res[0]]
+    assert sum(s["scan_p_launches"] for s in st) > 0 and sum(s["sharded_windows"] for s in st) > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pruned_and_split_in_the_steady_state(world):
+    """The default policy inside a group whose table is above the split threshold: start-up with plain split scans, then
+    pruned split scans - the counters the policy reads are the gathered ones, so the ranks keep deciding alike - and
+    the single-GPU results."""
+    n, d, g = 400_000, 20, 2000
+    X = scenarios.make_blobs(5, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    single = P.run_pipeline([X], cfg)
+    res = run_group(world, [X], cfg, min_row_dims=20_000, offline_min_rows=-1)
+    for r in res:
+        P.same_results(r, single)
+        st = r[0]["stats"]
+        assert st["sharded_windows"] > 0 and 0 < st["scan_p_launches"] < st["scan_u_launches"]
+        assert 0 < st["pruned_scan_full_rows"] < 0.2 * st["pruned_scan_rows"]
+    assert len({(r[0]["stats"]["pruned_scan_rows"], r[0]["stats"]["pruned_scan_full_rows"], r[0]["stats"]["windows"]) for r in res}) == 1
