@@ -118,6 +118,12 @@ struct cc_handle {
     Ctl hc{};  // host mirror of the device control block
     DevBuf<Ctl> ctl;
     bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
+    // what the rounding-error guard of Ctl::s0_on needs to know about the table's history since the last reset: the
+    // largest |coordinate| uploaded, the number of points uploaded, and whether rows came in from elsewhere (cc_inject_*)
+    double coord_max = 0.0;
+    long long points_total = 0;
+    bool hist_unknown = false;
+    bool allow_s0 = true;       // CHRONOCLUST_HIP_S0=0: never skip stage 0 on the radius bound
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
@@ -217,7 +223,7 @@ struct cc_handle {
         hipStream_t stream = nullptr;
         void* pin[2] = {nullptr, nullptr};
         size_t pin_bytes = 0;
-        int bad_host = 0;
+        int bad_host[4] = {0, 0, 0, 0};  // k_check_finite's words: [0] non-finite flag, [2..3] bits of the largest |value|
         int rc = 0;                     // hipError_t of the worker (0: fine)
         const char* what = "";
     } pf;
@@ -424,7 +430,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     const size_t w = (size_t)win, d = (size_t)std::max(h->d, h->d_alloc);
     h->v_cf1.ensure(w * d); h->v_cf2.ensure(w * d); h->v_cen.ensure(w * d); h->v_pref.ensure(w * d); h->v_scl.ensure(w * d); h->v_w.ensure(w);
     h->v_kind.ensure(w); h->v_key.ensure(w); h->v_next.ensure(w); h->v_upg.ensure(w); h->v_acc.ensure(w);
-    h->v_dsq.ensure(w); h->v_tau.ensure(2 * w); h->v_tile_dsq.ensure(2 * (w / 16 + 2));
+    h->v_dsq.ensure(w); h->v_tau.ensure(CC_TAU_STRIDE * w); h->v_tile_dsq.ensure(CC_DSQ_STRIDE * (w / 16 + 2));
     h->v_tgt.ensure(w);
     h->v_skip.ensure(w / 64 + 2); h->v_skip_car.ensure(w / 64 + 2); h->v_unsafe.ensure(w);
     h->part_stride = w * seg * 4;
@@ -439,7 +445,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
     h->c_sclv.ensure(w * d); h->c_wv.ensure(w); h->c_c0.ensure(w * d); h->c_w0.ensure(w * d);
-    h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(2 * (w / 16 + 2));
+    h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(CC_DSQ_STRIDE * (w / 16 + 2));
     h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
     h->long_list.ensure(2 * CC_LONG_CAP);
     h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
@@ -698,7 +704,7 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
-        h->badflag.ensure(1);
+        h->badflag.ensure(4);
         memset(&h->hc, 0, sizeof(Ctl));
         h->tun.window = 32768;
         h->tun.rounds = 3;
@@ -729,6 +735,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* s0 = getenv("CHRONOCLUST_HIP_S0");
+        h->allow_s0 = !(s0 && s0[0] == '0');
         push_ctl(h);
         sync_stream(h, h->stream);
         return CC_OK;
@@ -801,6 +809,9 @@ int cc_reset(cc_handle* h)
         c.pcore_last_id = c.outlier_last_id = 0;
         c.cursor = 0;
         h->tainted = false;
+        h->coord_max = 0.0;
+        h->points_total = 0;
+        h->hist_unknown = false;
         h->adapt_win = 0;  // an empty table starts with small windows again
         h->seq_sticky = false;
         h->clean_batches = 0;
@@ -896,6 +907,17 @@ static void prefetch_discard(cc_handle* h)
     h->pf.active = false;
 }
 
+// bookkeeping of an upload: the largest |coordinate| (k_check_finite leaves its bits in words 2..3) and the point count
+static void note_points(cc_handle* h, int64_t n, const int* flag_words)
+{
+    unsigned long long bits;
+    memcpy(&bits, flag_words + 2, 8);
+    double m;
+    memcpy(&m, &bits, 8);
+    if (m > h->coord_max) h->coord_max = m;
+    h->points_total += n;
+}
+
 static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn)
 {
     int rc = set_dim(h, d);
@@ -913,10 +935,11 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
             h->lab_uid.ensure((size_t)n);
             h->lab_path.ensure((size_t)n);
             h->n_points = n;
-            if (pf.bad_host) {
+            if (pf.bad_host[0]) {
                 h->n_points = 0;
                 return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
             }
+            note_points(h, n, pf.bad_host);
             return (int)CC_OK;
         }
     }
@@ -927,7 +950,7 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     h->n_points = n;
     if (n == 0) return (int)CC_OK;
     HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 16, h->stream));
     const long long tot = (long long)n * d;
     if (scale) {
         h->scr2.ensure((size_t)2 * d);
@@ -940,13 +963,14 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
     hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
                        h->Xt.p, (long long)n, (int)d);
-    int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
+    int bad[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(bad, h->badflag.p, 16, hipMemcpyDeviceToHost, h->stream));
     sync_stream(h, h->stream);
-    if (bad) {
+    if (bad[0]) {
         h->n_points = 0;
         return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
     }
+    note_points(h, n, bad);
     return (int)CC_OK;
 }
 
@@ -959,7 +983,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
         pf.x = x; pf.n = n; pf.d = d; pf.scaled = scale != nullptr;
         pf.scale.assign(scale ? scale : x, scale ? scale + d : x);
         pf.mn.assign(min_ ? min_ : x, min_ ? min_ + d : x);
-        pf.rc = 0; pf.what = ""; pf.bad_host = 0;
+        pf.rc = 0; pf.what = ""; pf.bad_host[0] = pf.bad_host[1] = pf.bad_host[2] = pf.bad_host[3] = 0;
         if (!pf.stream) HIPCHK(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
         const size_t chunk = (size_t)16 << 20;
         if (pf.pin_bytes < chunk) {
@@ -970,7 +994,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             pf.pin_bytes = chunk;
         }
-        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(1);
+        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(4);
         pf.active = true;
         const int device = h->device;
         pf.worker = std::thread([&pf, device, chunk]() {
@@ -993,7 +1017,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             const long long tot = pf.n * (long long)pf.d;
             if (pf.rc == 0) {
-                chk(hipMemsetAsync(pf.bad.p, 0, 4, pf.stream), "hipMemsetAsync");
+                chk(hipMemsetAsync(pf.bad.p, 0, 16, pf.stream), "hipMemsetAsync");
                 if (pf.scaled) {
                     chk(hipMemcpyAsync(pf.sm.p, pf.scale.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
                     chk(hipMemcpyAsync(pf.sm.p + pf.d, pf.mn.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
@@ -1004,7 +1028,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
                 hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, pf.stream, pf.X.p, tot, pf.bad.p);
                 hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, pf.stream, pf.X.p, pf.Xt.p,
                                    pf.n, pf.d);
-                chk(hipMemcpyAsync(&pf.bad_host, pf.bad.p, 4, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
+                chk(hipMemcpyAsync(pf.bad_host, pf.bad.p, 16, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
                 chk(hipGetLastError(), "kernel launch");
             }
             chk(hipStreamSynchronize(pf.stream), "hipStreamSynchronize");
@@ -1301,6 +1325,23 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_seq_points = 0;
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
+        c.stat_s0fail = 0;
+        // "stage 0 provably fails" (k_dseed, CC_FLAG_S0FAIL): available when the bound's premises hold for this call -
+        // no pdim filter (the snapshot's pcore list is then the nearest of ALL pcore rows), every preferred-dimension
+        // entry 1 or k, a table whose whole history this handle has seen - and its quarter of margin covers the rounding
+        // errors of the variances: 64 d (n + 1024) 2^-53 M^2 max(1, 1 / k) <= eps^2 / 16 for n points of magnitude <= M
+        // since the last reset (sums of n squares carry a relative error of n 2^-53; coordinates far from the origin
+        // make the variances cancel and switch the proof off).  h_all: taken from the table by k_rebuild_scl below.
+        c.h_all = 0ull;
+        {
+            const double k = c.k, eps2 = c.eps_sq, M = h->coord_max;
+            const double kappa = (k > 1.0 ? k : 1.0) / (k < 1.0 ? k : 1.0);
+            const double slack = 64.0 * (double)h->d * ((double)h->points_total + 1024.0) * 0x1p-53 * M * M * (k < 1.0 ? 1.0 / k : 1.0);
+            const bool ok = h->allow_s0 && c.filter == 0 && !h->tainted && !h->hist_unknown && k > 0.0 && std::isfinite(kappa) &&
+                            eps2 > 0.0 && std::isfinite(eps2) && std::isfinite(slack) && slack <= eps2 / 16.0;
+            c.s0_on = ok ? 1 : 0;
+            c.s0_coef = ok ? 1.25 * eps2 * kappa : 0.0;
+        }
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         bool la_on = false;
         auto set_lookahead = [&](bool on) {
@@ -1329,8 +1370,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
         HIPCHK(hipMemsetAsync(h->pstat.p, 0, 4 * sizeof(unsigned long long), h->stream));
+        // (the displacement maxima are reset by the kernels as they go; the h maxima beside them only ever grow)
+        HIPCHK(hipMemsetAsync(h->v_tile_dsq.p, 0, h->v_tile_dsq.n * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
-            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
+            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
@@ -1418,6 +1461,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     bad_batches = 0;
                     HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
                     h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
+                    h->hc.s0_on = 0;  // (k_seq changed rows without writing version rows: h_all no longer covers the table)
                     dec = policy.after_sequential(h->hc.cursor, h->hc.m_rows);
                     ptrace.sequential(h->hc.cursor, h->hc.m_rows, dec);
                     nodirty = dec.nodirty != 0;
@@ -1572,7 +1616,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                                                car, told, r, 0, (const int*)long_list);
                     }
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                       h->clean.p, h->dseed.p, told, r);
+                                       h->clean.p, h->dseed.p, told, r, (const int8_t*)h->dpath.p);
                     if (!nodirty) {
                         launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
@@ -1700,6 +1744,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.pruned_scan_full_rows += (int64_t)h->hc.stat_prune_full;
         h->stats.long_chains += (int64_t)h->hc.stat_long;
         h->stats.long_chain_launches += long_launches;
+        h->stats.tiles += h->hc.stat_tiles;
+        h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
+        h->stats.stage0_skipped += h->hc.stat_s0fail;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {
@@ -1820,6 +1867,7 @@ int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const dou
         if (rc != CC_OK) return rc;
         ensure_table(h, (size_t)h->hc.m_rows + 1);
         const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d;
+        h->hist_unknown = true;  // (sums formed elsewhere: how many points, of what magnitude, is not known here)
         for (int i = 0; i < d; ++i)
             if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) h->tainted = true;
         HIPCHK(hipMemcpyAsync(h->tab.cf1.p + r * dd, cf1, dd * 8, hipMemcpyHostToDevice, h->stream));
@@ -1856,6 +1904,7 @@ int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* c
         if (rc != CC_OK) return rc;
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)n);
         const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d, nn = (size_t)n;
+        h->hist_unknown = true;  // (see cc_inject_mc)
         for (size_t i = 0; i < nn * dd; ++i)
             if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) { h->tainted = true; break; }
         const int knd = kind == CC_PCORE ? CC_KIND_PCORE : CC_KIND_OUTLIER;

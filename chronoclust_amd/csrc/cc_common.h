@@ -90,7 +90,7 @@ struct Carry {
     double* w0;    // [B, d] 1 / pref of the row before the commit
     int* kind0;    // kind before the commit; CC_KIND_DEAD: the row did not exist
     double* dsq;   // [B] squared displacement of the committed centroid from c0 in the w0 metric (see Versions::dsq)
-    unsigned long long* tile_dsq;  // [B / 16, 2] per 16 rows and kind: max of dsq (cc_dsq_code: 0 = no such row)
+    unsigned long long* tile_dsq;  // [B / 16, CC_DSQ_STRIDE] per 16 rows and class: max of dsq (cc_dsq_code: 0 = no such row)
 };
 
 // Version rows of the current window: row j = state of point j's target microcluster right after point j
@@ -109,18 +109,19 @@ struct Versions {
     int* acc;   // 1 if point j was absorbed (radius test passed or new microcluster)
     int* tgt;   // target id of the chain this row belongs to
     // squared displacement of the version's centroid from its MC's window-start centroid, in the window-start
-    // metric; +inf for MCs created or promoted inside the window or whose preferred dimensions changed (k_chain).
-    // tile_dsq[(i / 16) * 2 + kind] = max over the rows of that (current) kind among 16 (cc_dsq_code: 0 = none).
+    // metric; +inf for MCs created inside the window or whose preferred dimensions changed (k_chain); negated for
+    // MCs promoted since the snapshot (class 2, see CC_DSQ_STRIDE).
+    // tile_dsq[(i / 16) * CC_DSQ_STRIDE + class] = max over the rows of that class among 16 (cc_dsq_code: 0 = none).
     double* dsq;
     unsigned long long* tile_dsq;
-    double* tau;  // [B, 2] per window point and kind: a version of the kind with sqrt(dsq) below this cannot matter to it (k_dseed)
+    double* tau;  // [B, CC_TAU_STRIDE] per window point and class: a version of the class with sqrt(dsq) below this cannot matter to it (k_dseed)
     // per 64-point tile: 1 if no version row (skip) / no carried row (skip_car) can matter to any of its points,
     // so the dirty scan of the tile is not run and k_decide takes the seeds (k_dseed)
     int* skip;
     int* skip_car;
-    // per window point: 1 if some version row or carried row could matter to it beyond the seeds (k_dseed).  While no
-    // point is, the host stops launching the dirty scans; k_decide then refuses to decide such a point
-    // (CC_T_UNKNOWN: the window commits up to it and the host brings the dirty scans back)
+    // per window point: CC_FLAG_* (k_dseed).  Which kinds of version / carried rows could matter to it beyond the seeds:
+    // k_decide refuses to decide a point (CC_T_UNKNOWN: the window commits up to it) when a stage it has to evaluate
+    // needs rows no dirty scan covered - the tile's scan was skipped, or the host has stopped launching them
     int* unsafe;
 };
 
@@ -199,7 +200,35 @@ struct Ctl {
     // pruned snapshot scans (k_scan_p): (wave, row) pairs visited / of those, pairs whose distance was evaluated in full
     // (a sample: the waves of every window's first point tile)
     unsigned long long stat_prune_rows, stat_prune_full;
+    // "stage 0 provably fails" (k_dseed, see CC_FLAG_S0FAIL): h_all = bits of the largest h(W) = (W + 1)^2 / W over every
+    // table row at the start of the call and every version row written since (k_rebuild_scl / k_commit_a keep it up);
+    // s0_coef = 1.25 * eps^2 * max(1, k) / min(1, k); s0_on = 0: the proof is not available for this call (host: pdim
+    // filter, mixed k, unknown history of the table, magnitudes whose rounding errors the margin does not cover)
+    unsigned long long h_all;
+    double s0_coef;
+    int s0_on;
+    int pad2;
+    long long stat_s0fail;  // (point, validation round) pairs whose stage 0 was ruled out by that proof
 };
+
+// Displacement classes of a version row / carried row relative to the snapshot its window was scanned against
+// (Versions::tile_dsq, Carry::tile_dsq: CC_DSQ_STRIDE words per 16 rows):
+//   0  pcore now and in the snapshot       competes in a point's pcore list, bounded through that list's second-best
+//   1  outlier now and in the snapshot     ... outlier list ...
+//   2  pcore now, OUTLIER in the snapshot  (promoted since: hddstream.py:416-430) competes in the pcore list, but its
+//      snapshot distance is bounded through the point's OUTLIER list - its dsq is stored negated (see cc_dsq_class)
+//   3  (version rows only) not a displacement: the largest h(W) of the tile's rows, never reset within a call
+// Rows without a bound (new microclusters, changed preferred dimensions) carry dsq = +inf in class 0 / 1.
+#define CC_DSQ_STRIDE 4
+#define CC_TAU_STRIDE 4   // Versions::tau: thresholds of classes 0, 1, 2 per window point (+ 1 pad)
+// Versions::unsafe, per window point (k_dseed -> k_decide):
+#define CC_FLAG_U0 1       // some version row of class 0 / 2 could matter to the point beyond the seeds
+#define CC_FLAG_U1 2       // ... of class 1
+#define CC_FLAG_C0 4       // the same for the carried rows
+#define CC_FLAG_C1 8
+#define CC_FLAG_S0FAIL 16  // no pcore microcluster live at this point can pass the radius test with it: stage 0 is skipped
+#define CC_FLAG_N1SKIP 32  // the outlier-kind threshold was withheld (the point is expected to join a pcore MC): a dirty
+                           // scan that ran does not cover the outlier kind for this point
 
 // Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole
 // units of `unit` rows (1: table rows of a snapshot scan, current pcores of the association argmin; 64: p rows of

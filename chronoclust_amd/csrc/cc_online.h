@@ -191,6 +191,31 @@ __device__ __forceinline__ bool cc_dsq_below(unsigned long long code, double tau
     return dq < CC_INF && sqrt(dq) * (1.0 + 1e-9) < tau;
 }
 
+// class of a version / carried row (CC_DSQ_STRIDE) from its current kind and its stored dsq (negated: promoted since the
+// snapshot), and the stored form of a displacement for a row whose snapshot kind was kind0
+__device__ __forceinline__ int cc_dsq_class(int kind, double dsq_stored)
+{
+    return (kind == CC_KIND_PCORE) ? (__builtin_signbit(dsq_stored) ? 2 : 0) : 1;
+}
+// dq >= 0 or +inf (no bound) -> what Versions::dsq / Carry::dsq hold and the class whose maximum it enters.
+// A row without a bound stays in the class of its kind (+inf is never below a threshold).
+__device__ __forceinline__ double cc_dsq_store(double dq, int kind, int kind0, int* cls)
+{
+    const bool promoted = kind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER && dq < CC_INF;
+    *cls = (kind == CC_KIND_PCORE) ? (promoted ? 2 : 0) : 1;
+    return promoted ? -dq : dq;
+}
+// h(W) = (W + 1)^2 / W = W + 2 + 1 / W as an ordered code (bits of a positive double; NaN / inf / W <= 0: all ones)
+__device__ __forceinline__ unsigned long long cc_h_code(double w)
+{
+    const double h = w + 2.0 + 1.0 / w;
+    return (w > 0.0 && h < CC_INF) ? (unsigned long long)__double_as_longlong(h) : ~0ull;
+}
+__device__ __forceinline__ double cc_h_value(unsigned long long code)
+{
+    return (code == ~0ull) ? CC_INF : __longlong_as_double((long long)code);
+}
+
 // wave-uniform operand of a dimension from bit BIT of its row mask: two scalar instructions (the compiler's own
 // selection takes three, and the scalar unit issues one instruction per wave turn like the vector unit)
 template <int BIT>

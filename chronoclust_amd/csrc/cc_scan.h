@@ -131,15 +131,20 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
     // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave; when that
     // rules out every tile of the sub-range the wave only hands its seeds on and never loads its points
     // (per kind: a version competes in the list of its kind, against that list's threshold)
-    double wave_tau[2] = {-CC_INF, -CC_INF};
+    // (per class of row, see CC_DSQ_STRIDE: 0 pcore, 1 outlier, 2 promoted since the snapshot)
+    double wave_tau[3] = {-CC_INF, -CC_INF, -CC_INF};
     bool any_tile = true;
+    auto tile_below = [&](int rt) -> bool {
+        const unsigned long long* w = rows.tile_dsq + (size_t)(rt >> 4) * CC_DSQ_STRIDE;
+        return cc_dsq_below(w[0], wave_tau[0]) && cc_dsq_below(w[1], wave_tau[1]) && cc_dsq_below(w[2], wave_tau[2]);
+    };
     if (DIRTY) {
 #pragma unroll
-        for (int K = 0; K < 2; ++K) {
+        for (int K = 0; K < 3; ++K) {
             double wt = CC_INF;
 #pragma unroll
             for (int t = 0; t < PT; ++t) {
-                const double tj = valid[t] ? rows.tau[(size_t)jj[t] * 2 + K] : CC_INF;
+                const double tj = valid[t] ? rows.tau[(size_t)jj[t] * CC_TAU_STRIDE + K] : CC_INF;
                 wt = tj < wt ? tj : wt;
             }
             for (int off = 32; off >= 1; off >>= 1) {
@@ -150,9 +155,7 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
         }
         any_tile = false;
         for (int rt = r0; rt < r1; rt += CC_SCAN_TM)
-            if (!(cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
-                  cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1])))
-                any_tile = true;
+            if (!tile_below(rt)) any_tile = true;
     }
 #pragma unroll
     for (int t = 0; t < PT; ++t) {
@@ -210,9 +213,7 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
         const int tm = __builtin_amdgcn_readfirstlane(max(0, min(CC_SCAN_TM, r1 - rt)));
         if (tm == 0) break;
         if (DIRTY) {
-            if (cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 0], wave_tau[0]) &&
-                cc_dsq_below(rows.tile_dsq[(size_t)(rt >> 4) * 2 + 1], wave_tau[1]))
-                continue;  // nothing in this tile can matter
+            if (tile_below(rt)) continue;  // nothing in this tile can matter
         }
         CC_WAVE_SYNC();
         bool fuse_tile = false;
@@ -283,9 +284,11 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
         // while MCs are being created or promoted almost every tile holds a row without a bound, but few rows do)
         unsigned rowmask = 0xFFFFu;
         if (DIRTY) {
-            const double rq = (lane < tm) ? rows.dsq[rt + lane] : 0.0;
+            const double rqs = (lane < tm) ? rows.dsq[rt + lane] : 0.0;  // (negated: class 2)
             const int rk = (lane < tm) ? rows.kind[rt + lane] : CC_KIND_DEAD;
-            const double wt = (rk == CC_KIND_PCORE) ? wave_tau[0] : wave_tau[1];
+            const int cls = cc_dsq_class(rk, rqs);
+            const double rq = __builtin_fabs(rqs);
+            const double wt = (cls == 0) ? wave_tau[0] : (cls == 1 ? wave_tau[1] : wave_tau[2]);
             rowmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < tm && rk != CC_KIND_DEAD && !(rq < CC_INF && sqrt(rq) * (1.0 + 1e-9) < wt));
         }
         CC_WAVE_SYNC();

@@ -144,7 +144,8 @@ __device__ __forceinline__ void cc_row16_exchanges(F&& f)
 
 __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
-                                              Cand* __restrict__ seed, const int* __restrict__ T, int round)
+                                              Cand* __restrict__ seed, const int* __restrict__ T, int round,
+                                              const int8_t* __restrict__ dpath)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -155,29 +156,40 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     const bool la_mode = ctl->mode != 0;
     // largest displacement of any version row / carried row (the workgroup is one wave)
     // (per kind, in cc_dsq_code form: 0 = the window / the carry set holds no row of the kind)
-    unsigned long long maxd[2] = {0ull, 0ull}, maxd_car[2] = {0ull, 0ull};
+    // (per class, see CC_DSQ_STRIDE; word 3 of the version rows' tiles: the largest h(W), for CC_FLAG_S0FAIL)
+    unsigned long long maxd[3] = {0ull, 0ull, 0ull}, maxd_car[3] = {0ull, 0ull, 0ull};
+    unsigned long long hmax = ctl->h_all;
     {
-        for (int i = threadIdx.x; i < 2 * ((B + 15) / 16); i += 64) {
-            const unsigned long long v = ver.tile_dsq[i];
-            if (i & 1) maxd[1] = v > maxd[1] ? v : maxd[1];
-            else maxd[0] = v > maxd[0] ? v : maxd[0];
+        for (int i = threadIdx.x; i < (B + 15) / 16; i += 64) {
+            const unsigned long long* w = ver.tile_dsq + (size_t)i * CC_DSQ_STRIDE;
+            const unsigned long long v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+            maxd[0] = v0 > maxd[0] ? v0 : maxd[0];
+            maxd[1] = v1 > maxd[1] ? v1 : maxd[1];
+            maxd[2] = v2 > maxd[2] ? v2 : maxd[2];
+            hmax = v3 > hmax ? v3 : hmax;
         }
         if (la_mode)
-            for (int i = threadIdx.x; i < 2 * ((ctl->car_n + 15) / 16); i += 64) {
-                const unsigned long long v = car.tile_dsq[i];
-                if (i & 1) maxd_car[1] = v > maxd_car[1] ? v : maxd_car[1];
-                else maxd_car[0] = v > maxd_car[0] ? v : maxd_car[0];
+            for (int i = threadIdx.x; i < (ctl->car_n + 15) / 16; i += 64) {
+                const unsigned long long* w = car.tile_dsq + (size_t)i * CC_DSQ_STRIDE;
+                const unsigned long long v0 = w[0], v1 = w[1], v2 = w[2];
+                maxd_car[0] = v0 > maxd_car[0] ? v0 : maxd_car[0];
+                maxd_car[1] = v1 > maxd_car[1] ? v1 : maxd_car[1];
+                maxd_car[2] = v2 > maxd_car[2] ? v2 : maxd_car[2];
             }
 #pragma unroll
-        for (int K = 0; K < 2; ++K)
+        for (int K = 0; K < 3; ++K)
             for (int off = 32; off >= 1; off >>= 1) {
                 const unsigned long long o = __shfl_xor(maxd[K], off), oc = __shfl_xor(maxd_car[K], off);
                 maxd[K] = o > maxd[K] ? o : maxd[K];
                 maxd_car[K] = oc > maxd_car[K] ? oc : maxd_car[K];
             }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(hmax, off);
+            hmax = o > hmax ? o : hmax;
+        }
     }
-    double tau_out[2] = {CC_INF, CC_INF};  // lanes past the window do not constrain the tile
-    bool flag_unprov = false, flag_unsafe = false;
+    bool flag_unprov = false, flag_unsafe = false, flag_s0 = false;
+    bool need_ver = false, need_car = false;  // this point's stages need rows only a dirty scan of the versions / the carry set covers
     if (j < B) {
     const Par par = cc_load_par(ctl);
     const int d = par.d;
@@ -398,47 +410,93 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     // list may be closer than d2 (they were filtered out), so nothing is pruned for that kind.
     // One threshold per kind: a version competes in the list of its (current) kind.  A kind without any version row in
     // the window constrains nothing - stale outlier MCs that no point touches must not cost anything.
-    bool ok_v = true, ok_c = true;
-    for (int kd = 0; kd < 2; ++kd) {
+    // Class 2 - a MC promoted since the snapshot (hddstream.py:416-430): it competes in the pcore list, but the snapshot
+    // scanned it as an OUTLIER MC, so its snapshot distance is >= the second-best of the point's outlier list unless
+    // it is one of that list's two entries (whose live versions are seeded above whatever their kind has become):
+    //     sqrt(dsq_v) < sqrt(d2_outlier) - sqrt(K * ce_pcore)    rules it out.
+    double tau[3];
+    for (int kd = 0; kd < 3; ++kd) {
         double t;
-        if (kd == 0 && filter) t = -CC_INF;
-        else if (!have1[kd]) t = CC_INF;  // no MC of this kind at window start: its versions have dsq = +inf
+        const int list = (kd == 1) ? 1 : 0;        // the list the row competes in
+        const int from = (kd == 0) ? 0 : 1;        // the list its snapshot distance is bounded by
+        if (list == 0 && filter) t = -CC_INF;
+        else if (kd != 2 && !have1[kd]) t = CC_INF;  // no MC of this kind at window start: its versions have dsq = +inf
         else {
-            const double fb = (kd == 0) ? first0.dist : first1.dist;
-            const double ce = fb < cap[kd] ? fb : cap[kd];
-            t = (d2v[kd] == CC_INF) ? CC_INF : (sqrt(d2v[kd]) - sqrt(K * ce));
+            const double fb = (list == 0) ? first0.dist : first1.dist;
+            const double ce = fb < cap[list] ? fb : cap[list];
+            // (d2 = +inf: the snapshot held no other MC of that kind; cap = +inf: nothing to beat yet - every row matters)
+            t = (d2v[from] == CC_INF) ? CC_INF : (sqrt(d2v[from]) - sqrt(K * ce));
         }
         if (!provable) t = -CC_INF;
         t = (t == CC_INF) ? CC_INF : t * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
-        tau_out[kd] = t;
-        ver.tau[(size_t)j * 2 + kd] = t;
-        // the same test as for the tile below, for this point alone
-        ok_v = ok_v && cc_dsq_below(maxd[kd], t);
-        ok_c = ok_c && (!la_mode || cc_dsq_below(maxd_car[kd], t));
+        tau[kd] = t;
     }
-    ver.unsafe[j] = (ok_v && ok_c) ? 0 : 1;
+    // Stage 0 (hddstream.py:288-343) can be ruled out as a whole.  Adding x to a MC (CF1, CF2, W) gives, per dimension,
+    //     var' = W / (W + 1) var + W / (W + 1)^2 (x - CF1 / W)^2  >=  (x - c)^2 / h(W),      h(W) = (W + 1)^2 / W,
+    // so the radius test's sum (mc_functions.py:45-56) is at least D / (kappa h(W)) for the MC's projected distance D
+    // from x (kappa = max(1, k) / min(1, k): the preferred-dimension weights of the two sums differ by at most that).
+    // If EVERY pcore MC that is live when j arrives has D > s0_coef * h_max (s0_coef = 1.25 kappa eps^2; the quarter
+    // covers the rounding of either side, the host checks that it does: Ctl::s0_on), whichever of them is nearest fails
+    // the test and j goes on to the outlier list - no pcore version can matter to it.  Lower bound of those D: the
+    // snapshot's best pcore distance (every untouched row), the seeded live versions of the list entries, and for the
+    // other touched rows their snapshot bound less the largest displacement of their class.
+    bool s0fail = false;
+    if (ctl->s0_on != 0 && provable && !filter) {
+        auto moved = [&](double base, unsigned long long code) -> double {
+            if (code == 0ull) return CC_INF;
+            const double dq = __longlong_as_double((long long)(code - 1ull));
+            if (!(dq < CC_INF) || base == CC_INF) return (base == CC_INF && dq < CC_INF) ? CC_INF : 0.0;
+            const double r = sqrt(base) * (1.0 - 1e-9) - sqrt(dq) * (1.0 + 1e-9);
+            return r > 0.0 ? r * r : 0.0;
+        };
+        const double base0 = have1[0] ? cq[0].dist : CC_INF;   // every pcore row of the snapshot is at least this far
+        const double base2 = d2v[1];                            // ... every outlier row outside the point's list
+        double lb = base0 < first0.dist ? base0 : first0.dist;
+        double m;
+        m = moved(base0, maxd[0]); lb = m < lb ? m : lb;
+        m = moved(base2, maxd[2]); lb = m < lb ? m : lb;
+        if (la_mode) {
+            m = moved(base0, maxd_car[0]); lb = m < lb ? m : lb;
+            m = moved(base2, maxd_car[2]); lb = m < lb ? m : lb;
+        }
+        s0fail = lb > ctl->s0_coef * cc_h_value(hmax);
+    }
+    // Stage 1 (hddstream.py:345-395) is only reached when stage 0 fails.  A point whose previous decision was to join a
+    // pcore MC is expected to do so again: the outlier-kind rows are not held against its tile, and k_decide refuses
+    // the point (CC_T_UNKNOWN) if stage 0 fails after all and those rows were not covered.
+    const bool need0 = !s0fail;
+    const bool need1 = !(T[j] >= 0 && dpath[j] == 0);
+    if (s0fail) { tau[0] = CC_INF; tau[2] = CC_INF; }
+    int flags = s0fail ? CC_FLAG_S0FAIL : 0;
+    if (!(cc_dsq_below(maxd[0], tau[0]) && cc_dsq_below(maxd[2], tau[2]))) flags |= CC_FLAG_U0;
+    if (!cc_dsq_below(maxd[1], tau[1])) flags |= CC_FLAG_U1;
+    if (la_mode && !(cc_dsq_below(maxd_car[0], tau[0]) && cc_dsq_below(maxd_car[2], tau[2]))) flags |= CC_FLAG_C0;
+    if (la_mode && !cc_dsq_below(maxd_car[1], tau[1])) flags |= CC_FLAG_C1;
+    if (!need1) { tau[1] = CC_INF; flags |= CC_FLAG_N1SKIP; }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) ver.tau[(size_t)j * CC_TAU_STRIDE + kd] = tau[kd];
+    ver.unsafe[j] = flags;
+    need_ver = (need0 && (flags & CC_FLAG_U0)) || (need1 && (flags & CC_FLAG_U1));
+    need_car = (need0 && (flags & CC_FLAG_C0)) || (need1 && (flags & CC_FLAG_C1));
     flag_unprov = !provable;
-    flag_unsafe = !(ok_v && ok_c);
+    flag_unsafe = need_ver || need_car;
+    flag_s0 = s0fail;
     }
     {
         // statistics for the host's trace line (one atomic per wave and only when something is flagged)
         const unsigned long long b1 = __builtin_amdgcn_ballot_w64(flag_unprov), b2 = __builtin_amdgcn_ballot_w64(flag_unsafe);
         if (threadIdx.x == 0 && b1) atomicAdd((unsigned long long*)&ctl->stat_unprovable, (unsigned long long)__builtin_popcountll(b1));
         if (threadIdx.x == 0 && b2) atomicAdd((unsigned long long*)&ctl->stat_unsafe, (unsigned long long)__builtin_popcountll(b2));
+        const unsigned long long b3 = __builtin_amdgcn_ballot_w64(flag_s0);
+        if (threadIdx.x == 0 && b3) atomicAdd((unsigned long long*)&ctl->stat_s0fail, (unsigned long long)__builtin_popcountll(b3));
     }
-    // the tile as a whole: when even the largest displacement stays below every point's threshold, no row can matter
-    // to any point of the tile and its dirty scan is not run at all (the same test k_scan makes per 16 rows)
-    double tile_tau[2] = {tau_out[0], tau_out[1]};
-#pragma unroll
-    for (int K = 0; K < 2; ++K)
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double o = __shfl_xor(tile_tau[K], off);
-            tile_tau[K] = o < tile_tau[K] ? o : tile_tau[K];
-        }
+    // the tile as a whole: when no point of it needs a row that only a dirty scan covers - even the largest displacement
+    // of every class stays below the point's threshold, for the stages the point is expected to evaluate -, the tile's
+    // dirty scan is not run at all
+    const unsigned long long any_v = __builtin_amdgcn_ballot_w64(need_ver), any_c = __builtin_amdgcn_ballot_w64(need_car);
     if (threadIdx.x == 0) {
-        const int sk = (cc_dsq_below(maxd[0], tile_tau[0]) && cc_dsq_below(maxd[1], tile_tau[1])) ? 1 : 0;
-        ver.skip[blockIdx.x] = sk;  // (k_commit_a counts the tiles of the last round for the host's window policy)
-        ver.skip_car[blockIdx.x] = (!la_mode || (cc_dsq_below(maxd_car[0], tile_tau[0]) && cc_dsq_below(maxd_car[1], tile_tau[1]))) ? 1 : 0;
+        ver.skip[blockIdx.x] = any_v == 0ull ? 1 : 0;  // (k_commit_a counts the tiles of the last round for the host's window policy)
+        ver.skip_car[blockIdx.x] = (!la_mode || any_c == 0ull) ? 1 : 0;
     }
 }
 
@@ -581,12 +639,14 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         p1 = in[0]; p2 = in[1]; o1 = in[2]; o2 = in[3];
     }
     Cand dvp = none, dvo = none;  // best live version per kind
+    // what k_dseed found out about this point (CC_FLAG_*), and which dirty scans covered its tile
+    const int flags = (round > 0) ? ver.unsafe[j] : 0;
+    // a dirty scan that k_dseed ruled out for this point's tile was not run: the seeds are its whole result
+    // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
+    const bool ran = round > 0 && nodirty == 0 && ver.skip[j >> 6] == 0;
+    const bool ran_car = round > 0 && nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
     if (round > 0) {
         Cand dummy = none;
-        // a dirty scan that k_dseed ruled out for this point's tile was not run: the seeds are its whole result
-        // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
-        const bool ran = nodirty == 0 && ver.skip[j >> 6] == 0;
-        const bool ran_car = nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
         if (!ran && !ran_car) {
             // no dirty scan ran for this point's tile (the steady state): the seeds are the whole result, every lane
             // reads them itself and nothing has to be merged
@@ -689,8 +749,21 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             path = stage;
         }
     };
-    run_stage(p1, p2, dvp, 0);
-    if (T == -1) run_stage(o1, o2, dvo, 1);
+    // A stage is evaluated only when the rows it needs were covered: by the seeds alone (no flag), or by the dirty scans
+    // of the point's tile.  Stage 0 is skipped when k_dseed proved that no live pcore MC can pass the radius test with
+    // this point (CC_FLAG_S0FAIL): whichever of them is nearest, the reference goes on to the outlier list.
+    if ((flags & CC_FLAG_S0FAIL) == 0) {
+        const bool missing = ((flags & CC_FLAG_U0) != 0 && !ran) || ((flags & CC_FLAG_C0) != 0 && la_mode && !ran_car);
+        if (missing) T = CC_T_UNKNOWN;
+        else run_stage(p1, p2, dvp, 0);
+    }
+    if (T == -1) {
+        const bool covers1 = (flags & CC_FLAG_N1SKIP) == 0;  // (the outlier-kind threshold was not withheld from the scans)
+        const bool missing = ((flags & CC_FLAG_U1) != 0 && !(ran && covers1)) ||
+                             ((flags & CC_FLAG_C1) != 0 && la_mode && !(ran_car && covers1));
+        if (missing) T = CC_T_UNKNOWN;
+        else run_stage(o1, o2, dvo, 1);
+    }
     if (T == -1) {
         if (ctl->no_create != 0) {
             T = CC_T_NONE;  // relaxed multi-GPU mode: set aside for the replicated second half of the super-step
@@ -701,14 +774,14 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             if (gl == 0) ctl->any_new[round] = 1;
         }
     }
-    if (round > 0 && nodirty != 0 && ver.unsafe[j] != 0) T = CC_T_UNKNOWN;  // the seeds are not this point's whole story
     if (gl == 0) {
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
-        if ((j & 15) == 0) {  // the next k_chain takes maxima into them
-            ver.tile_dsq[(size_t)(j >> 4) * 2] = 0ull;
-            ver.tile_dsq[(size_t)(j >> 4) * 2 + 1] = 0ull;
+        if ((j & 15) == 0) {  // the next k_chain takes maxima into them (word 3, the h maximum, is never reset)
+            ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE] = 0ull;
+            ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 1] = 0ull;
+            ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 2] = 0ull;
         }
         // (claims on the first scan_rows table rows are gathered by k_claims instead, without atomics)
         if (T >= 0 && !(T < M0 && T < scan_rows)) {
@@ -1004,13 +1077,18 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                 bool mv = false;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) mv = mv || (binv[h] != w0[h]);
-                if (isnew || bkind != kind0 || !(dq >= 0.0) || cc_group_ballot(mv) != 0u) dq = CC_INF;
+                // (a MC promoted since the snapshot keeps its bound: it was scanned as an outlier MC, and k_dseed bounds it
+                // through the point's outlier list - class 2)
+                const bool promoted = bkind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER;
+                if (isnew || (bkind != kind0 && !promoted) || !(dq >= 0.0) || cc_group_ballot(mv) != 0u) dq = CC_INF;
                 if (gl == 0) {
                     ver.w[cur] = bw;
                     ver.tgt[cur] = t; ver.kind[cur] = bkind; ver.key[cur] = bkey; ver.upg[cur] = bupg;
                     ver.acc[cur] = ok ? 1 : 0; ver.next[cur] = nx;
-                    ver.dsq[cur] = dq;
-                    atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * 2 + (bkind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
+                    int cls;
+                    ver.dsq[cur] = cc_dsq_store(dq, bkind, isnew ? CC_KIND_DEAD : kind0, &cls);
+                    atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
+                    atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * CC_DSQ_STRIDE + 3], cc_h_code(bw));
                 }
             }
         }
@@ -1318,7 +1396,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             double dq = (src >= 0) ? s_dq[src] : s_bdq;
             // (no bound either when the preferred dimensions differ from the snapshot's, see k_chain)
             const unsigned long long vmask = (src >= 0) ? s_mask[src] : s_bmask;
-            if (kind != kind0 || !(dq >= 0.0) || vmask != s_m0) dq = CC_INF;
+            const bool was_outlier = kind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER;  // promoted since the snapshot: class 2
+            if ((kind != kind0 && !was_outlier) || !(dq >= 0.0) || vmask != s_m0) dq = CC_INF;
             const int nx = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (CC_LONG_QUEUE - 1)] : CC_IDX_INF;
             ver.w[m] = (src >= 0) ? s_w[src] : s_bw;
             ver.tgt[m] = t;
@@ -1327,8 +1406,10 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             ver.upg[m] = promoted ? up_point : bupg;
             ver.acc[m] = (k < n_ok) ? 1 : 0;
             ver.next[m] = nx;
-            ver.dsq[m] = dq;
-            atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * 2 + (kind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
+            int cls;
+            ver.dsq[m] = cc_dsq_store(dq, kind, kind0, &cls);
+            atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
+            atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * CC_DSQ_STRIDE + 3], cc_h_code((src >= 0) ? s_w[src] : s_bw));
         }
         __syncthreads();  // every read of the running state and of the queue slots is done
 
@@ -1451,8 +1532,27 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     const bool la_ok = ctl->la_on != 0 && n == B && next_b > 0 && ctl->la_b[qn] == next_b &&
                        ctl->la_cursor[qn] == next_cursor;
     if (la_ok)
-        for (int i = tid; i < 2 * ((B + 15) / 16 + 1); i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into them
+        for (int i = tid; i < CC_DSQ_STRIDE * ((B + 15) / 16 + 1); i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into them
+    // the largest h(W) of this window's version rows (every round's: the words are never reset) joins the call's
+    // maximum, which therefore covers every state a table row has been committed in (CC_FLAG_S0FAIL)
+    __shared__ unsigned long long s_hmax;
+    if (tid == 0) s_hmax = ctl->h_all;
+    __syncthreads();
+    if (r >= 1) {
+        unsigned long long hm = 0ull;
+        for (int i = tid; i < (B + 15) / 16; i += 1024) {
+            const unsigned long long v = ver.tile_dsq[(size_t)i * CC_DSQ_STRIDE + 3];
+            hm = v > hm ? v : hm;
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(hm, off);
+            hm = o > hm ? o : hm;
+        }
+        if ((tid & 63) == 0 && hm != 0ull) atomicMax(&s_hmax, hm);
+    }
+    __syncthreads();
     if (tid == 0) {
+        ctl->h_all = s_hmax;
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         rec->carry = la_ok ? 1 : 0;
         rec->cursor = cursor;
@@ -1565,7 +1665,8 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
         }
         if (carry) {
             for (int off = 16; off >= 1; off >>= 1) dq += __shfl_xor(dq, off, 32);
-            if (kind0 == CC_KIND_DEAD || kind != kind0 || !(dq >= 0.0) || cc_group_ballot(metric_moved) != 0u) dq = CC_INF;
+            const bool promoted = kind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER;  // class 2, see k_chain
+            if (kind0 == CC_KIND_DEAD || (kind != kind0 && !promoted) || !(dq >= 0.0) || cc_group_ballot(metric_moved) != 0u) dq = CC_INF;
         }
         if (gl == 0) {
             tab.w[row] = ver.w[j];
@@ -1589,8 +1690,9 @@ __global__ __launch_bounds__(256) void k_commit_b(const CommitRec* __restrict__ 
                 car.key[j] = key;
                 car.slot[j] = (int)row;
                 car.kind0[j] = kind0;
-                car.dsq[j] = dq;
-                atomicMax(&car.tile_dsq[(size_t)(j >> 4) * 2 + (kind == CC_KIND_PCORE ? 0 : 1)], cc_dsq_code(dq));
+                int cls;
+                car.dsq[j] = cc_dsq_store(dq, kind, kind0, &cls);
+                atomicMax(&car.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
                 tab.carry_of[row] = (rec->next_seq << 20) | (unsigned long long)j;
             }
         }

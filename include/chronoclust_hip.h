@@ -116,6 +116,11 @@ typedef struct cc_stats {
                               * (per validation round) ...                                      */
     int64_t long_chain_launches; /* ... and launches of k_chain_long over the list of such chains (tables
                               * of more than 1 024 rows; smaller ones always run it)             */
+    int64_t tiles;           /* 64-point tiles validated ...                                               */
+    int64_t dirty_tiles;     /* ... and of those, tiles whose dirty scan had to run (last round of a window) */
+    int64_t stage0_skipped;  /* (point, validation round) pairs for which the pcore stage (hddstream.py:288-343)
+                              * was ruled out as a whole: no live pcore microcluster could pass the radius
+                              * test with the point                                 */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

@@ -69,6 +69,32 @@ if __name__ == "__main__":
     assert a == b, "the ranks of a group took different decisions"
     os.rename(os.path.join(out, "group_crossing_split_threshold.jsonl.rank0"), os.path.join(out, "group_crossing_split_threshold.jsonl"))
     os.remove(os.path.join(out, "group_crossing_split_threshold.jsonl.rank1"))
+    # (e) a group of two ranks at the stress config's table shape (40 dims, 50 000 microclusters: rows x d far above the
+    # split threshold): split scans from early on, and pruned ones once the table has settled - the group keeps pruning
+    def group_run(name, n, d, g, seed, thresholds):
+        trace_to(os.path.join(out, name))
+        X = scenarios.make_blobs(seed, n, d, g)
+        cfg = scenarios.params_to_config(scenarios.blob_params(n))
+        streams = [HDDStream(cfg) for _ in range(2)]
+        _lib.comm_init_local([s._h for s in streams])
+        for s in streams:
+            s._h.set_shard_thresholds(*thresholds)
+        ths = [threading.Thread(target=s.online_microcluster_maintenance, args=(X, 0)) for s in streams]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        st = streams[0].stats()
+        print(name, "sharded", st["sharded_windows"], "of", st["windows"], "pruned launches", st["scan_p_launches"])
+        a = open(os.path.join(out, name + ".rank0")).read()
+        b = open(os.path.join(out, name + ".rank1")).read()
+        assert a == b, "the ranks of a group took different decisions"
+        os.rename(os.path.join(out, name + ".rank0"), os.path.join(out, name))
+        os.remove(os.path.join(out, name + ".rank1"))
+        for s in streams:
+            s._h.close()
+
+    group_run("group_c5_shape_keeps_pruning.jsonl", 1_200_000, 40, 50_000, 42, (-1, -1))
     os.environ.pop("CHRONOCLUST_HIP_POLICY_TRACE")
     for f in sorted(os.listdir(out)):
         print(f, sum(1 for _ in open(os.path.join(out, f))), "lines")
