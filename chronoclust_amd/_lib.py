@@ -38,7 +38,7 @@ class CcStats(C.Structure):
                 ("comm_ms", C.c_double), ("seq_points", C.c_int64), ("scan_u_launches", C.c_int64),
                 ("scan_p_launches", C.c_int64), ("pruned_scan_rows", C.c_int64), ("pruned_scan_full_rows", C.c_int64),
                 ("window", C.c_int64), ("long_chains", C.c_int64), ("long_chain_launches", C.c_int64),
-                ("tiles", C.c_int64), ("dirty_tiles", C.c_int64), ("stage0_skipped", C.c_int64)]
+                ("tiles", C.c_int64), ("dirty_tiles", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -47,7 +47,7 @@ POLICY_MAX_ROUNDS = 8
 class CcPolicyConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
-                                         "pad")] + [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
+                                         "allow_sparse")] + [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
 
 
 class CcPolicyCarry(C.Structure):
@@ -57,14 +57,14 @@ class CcPolicyCarry(C.Structure):
 class CcPolicyObs(C.Structure):
     _fields_ = [("cursor", C.c_int64), ("m_rows", C.c_int32), ("stall_b", C.c_int32)] + \
                [(k, C.c_int64) for k in ("stat_windows", "stat_truncated", "stat_trunc_unknown", "stat_tiles",
-                                         "stat_dirty_tiles")] + \
+                                         "stat_dirty_tiles", "stat_unsafe")] + \
                [("round_hist", C.c_int64 * (POLICY_MAX_ROUNDS + 2)), ("prune_rows", C.c_uint64), ("prune_full", C.c_uint64),
                 ("after_sequential", C.c_int32), ("pad", C.c_int32)]
 
 
 class CcPolicyDecision(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune",
-                                         "shard", "restart", "bad", "stalled", "pad")] + \
+                                         "shard", "restart", "bad", "stalled", "sparse")] + \
                [(k, C.c_int64) for k in ("wins", "pts", "trunc", "unk", "tiles", "dtiles", "grew", "prune_rows", "prune_full")]
 
 

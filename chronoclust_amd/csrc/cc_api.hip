@@ -118,12 +118,6 @@ struct cc_handle {
     Ctl hc{};  // host mirror of the device control block
     DevBuf<Ctl> ctl;
     bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
-    // what the rounding-error guard of Ctl::s0_on needs to know about the table's history since the last reset: the
-    // largest |coordinate| uploaded, the number of points uploaded, and whether rows came in from elsewhere (cc_inject_*)
-    double coord_max = 0.0;
-    long long points_total = 0;
-    bool hist_unknown = false;
-    bool allow_s0 = true;       // CHRONOCLUST_HIP_S0=0: never skip stage 0 on the radius bound
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
     int clean_batches = 0;  // consecutive batches without a truncated window
     int since_shrink = 1000;  // batches since the window was last shrunk
@@ -148,6 +142,8 @@ struct cc_handle {
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
+    int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
+    DevBuf<int> sp_list;        // [window] the round's list of points for the sparse dirty scans
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
     int n_cus = 256;            // compute units of the device (hipDeviceProp_t::multiProcessorCount)
 
@@ -223,7 +219,7 @@ struct cc_handle {
         hipStream_t stream = nullptr;
         void* pin[2] = {nullptr, nullptr};
         size_t pin_bytes = 0;
-        int bad_host[4] = {0, 0, 0, 0};  // k_check_finite's words: [0] non-finite flag, [2..3] bits of the largest |value|
+        int bad_host = 0;
         int rc = 0;                     // hipError_t of the worker (0: fine)
         const char* what = "";
     } pf;
@@ -248,9 +244,9 @@ struct PolicyTrace {
     static void obs_json(FILE* f, const cc_policy_obs& o)
     {
         fprintf(f, "{\"cursor\": %lld, \"m_rows\": %d, \"stall_b\": %d, \"stat_windows\": %lld, \"stat_truncated\": %lld, "
-                   "\"stat_trunc_unknown\": %lld, \"stat_tiles\": %lld, \"stat_dirty_tiles\": %lld, \"round_hist\": [",
+                   "\"stat_trunc_unknown\": %lld, \"stat_tiles\": %lld, \"stat_dirty_tiles\": %lld, \"stat_unsafe\": %lld, \"round_hist\": [",
                 (long long)o.cursor, o.m_rows, o.stall_b, (long long)o.stat_windows, (long long)o.stat_truncated,
-                (long long)o.stat_trunc_unknown, (long long)o.stat_tiles, (long long)o.stat_dirty_tiles);
+                (long long)o.stat_trunc_unknown, (long long)o.stat_tiles, (long long)o.stat_dirty_tiles, (long long)o.stat_unsafe);
         for (int r = 0; r < CC_POLICY_MAX_ROUNDS + 2; ++r) fprintf(f, "%s%lld", r ? ", " : "", (long long)o.round_hist[r]);
         fprintf(f, "], \"prune_rows\": %llu, \"prune_full\": %llu, \"after_sequential\": %d}", (unsigned long long)o.prune_rows,
                 (unsigned long long)o.prune_full, o.after_sequential);
@@ -258,8 +254,8 @@ struct PolicyTrace {
     static void dec_json(FILE* f, const cc_policy_decision& d)
     {
         fprintf(f, "{\"win_cfg\": %d, \"want\": %d, \"rounds\": %d, \"batch_windows\": %d, \"lookahead\": %d, \"nodirty\": %d, "
-                   "\"prune\": %d, \"shard\": %d, \"restart\": %d, \"bad\": %d, \"stalled\": %d}",
-                d.win_cfg, d.want, d.rounds, d.batch_windows, d.lookahead, d.nodirty, d.prune, d.shard, d.restart, d.bad, d.stalled);
+                   "\"prune\": %d, \"shard\": %d, \"restart\": %d, \"bad\": %d, \"stalled\": %d, \"sparse\": %d}",
+                d.win_cfg, d.want, d.rounds, d.batch_windows, d.lookahead, d.nodirty, d.prune, d.shard, d.restart, d.bad, d.stalled, d.sparse);
     }
     // rank >= 0: the handle is rank `rank` of a group and writes <file>.rank<rank>
     PolicyTrace(const cc_policy_config& c, const cc_policy_carry& k, long long cursor, int rows, const cc_policy_decision& d0,
@@ -272,9 +268,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, (long long)c.shard_min_row_dims, (long long)c.n_end,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, (long long)c.shard_min_row_dims, (long long)c.n_end,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -448,7 +444,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(CC_DSQ_STRIDE * (w / 16 + 2));
     h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
     h->long_list.ensure(2 * CC_LONG_CAP);
-    h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1);
+    h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1); h->sp_list.ensure(w);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
 
@@ -704,7 +700,7 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
-        h->badflag.ensure(4);
+        h->badflag.ensure(1);
         memset(&h->hc, 0, sizeof(Ctl));
         h->tun.window = 32768;
         h->tun.rounds = 3;
@@ -735,8 +731,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
-        const char* s0 = getenv("CHRONOCLUST_HIP_S0");
-        h->allow_s0 = !(s0 && s0[0] == '0');
+        const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
+        if (sp && atoi(sp) >= 0) h->allow_sparse = atoi(sp);
         push_ctl(h);
         sync_stream(h, h->stream);
         return CC_OK;
@@ -809,9 +805,6 @@ int cc_reset(cc_handle* h)
         c.pcore_last_id = c.outlier_last_id = 0;
         c.cursor = 0;
         h->tainted = false;
-        h->coord_max = 0.0;
-        h->points_total = 0;
-        h->hist_unknown = false;
         h->adapt_win = 0;  // an empty table starts with small windows again
         h->seq_sticky = false;
         h->clean_batches = 0;
@@ -907,17 +900,6 @@ static void prefetch_discard(cc_handle* h)
     h->pf.active = false;
 }
 
-// bookkeeping of an upload: the largest |coordinate| (k_check_finite leaves its bits in words 2..3) and the point count
-static void note_points(cc_handle* h, int64_t n, const int* flag_words)
-{
-    unsigned long long bits;
-    memcpy(&bits, flag_words + 2, 8);
-    double m;
-    memcpy(&m, &bits, 8);
-    if (m > h->coord_max) h->coord_max = m;
-    h->points_total += n;
-}
-
 static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn)
 {
     int rc = set_dim(h, d);
@@ -935,11 +917,10 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
             h->lab_uid.ensure((size_t)n);
             h->lab_path.ensure((size_t)n);
             h->n_points = n;
-            if (pf.bad_host[0]) {
+            if (pf.bad_host) {
                 h->n_points = 0;
                 return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
             }
-            note_points(h, n, pf.bad_host);
             return (int)CC_OK;
         }
     }
@@ -950,7 +931,7 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     h->n_points = n;
     if (n == 0) return (int)CC_OK;
     HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 16, h->stream));
+    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
     const long long tot = (long long)n * d;
     if (scale) {
         h->scr2.ensure((size_t)2 * d);
@@ -963,14 +944,13 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
     hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
                        h->Xt.p, (long long)n, (int)d);
-    int bad[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(bad, h->badflag.p, 16, hipMemcpyDeviceToHost, h->stream));
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
     sync_stream(h, h->stream);
-    if (bad[0]) {
+    if (bad) {
         h->n_points = 0;
         return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
     }
-    note_points(h, n, bad);
     return (int)CC_OK;
 }
 
@@ -983,7 +963,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
         pf.x = x; pf.n = n; pf.d = d; pf.scaled = scale != nullptr;
         pf.scale.assign(scale ? scale : x, scale ? scale + d : x);
         pf.mn.assign(min_ ? min_ : x, min_ ? min_ + d : x);
-        pf.rc = 0; pf.what = ""; pf.bad_host[0] = pf.bad_host[1] = pf.bad_host[2] = pf.bad_host[3] = 0;
+        pf.rc = 0; pf.what = ""; pf.bad_host = 0;
         if (!pf.stream) HIPCHK(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
         const size_t chunk = (size_t)16 << 20;
         if (pf.pin_bytes < chunk) {
@@ -994,7 +974,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             pf.pin_bytes = chunk;
         }
-        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(4);
+        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(1);
         pf.active = true;
         const int device = h->device;
         pf.worker = std::thread([&pf, device, chunk]() {
@@ -1017,7 +997,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             const long long tot = pf.n * (long long)pf.d;
             if (pf.rc == 0) {
-                chk(hipMemsetAsync(pf.bad.p, 0, 16, pf.stream), "hipMemsetAsync");
+                chk(hipMemsetAsync(pf.bad.p, 0, 4, pf.stream), "hipMemsetAsync");
                 if (pf.scaled) {
                     chk(hipMemcpyAsync(pf.sm.p, pf.scale.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
                     chk(hipMemcpyAsync(pf.sm.p + pf.d, pf.mn.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
@@ -1028,7 +1008,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
                 hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, pf.stream, pf.X.p, tot, pf.bad.p);
                 hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, pf.stream, pf.X.p, pf.Xt.p,
                                    pf.n, pf.d);
-                chk(hipMemcpyAsync(pf.bad_host, pf.bad.p, 16, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
+                chk(hipMemcpyAsync(&pf.bad_host, pf.bad.p, 4, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
                 chk(hipGetLastError(), "kernel launch");
             }
             chk(hipStreamSynchronize(pf.stream), "hipStreamSynchronize");
@@ -1302,6 +1282,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         pcfg.can_shard = (grouped && !h->shard_suspended) ? 1 : 0;
         pcfg.d = h->d;
         pcfg.resume = resume ? 1 : 0;
+        pcfg.allow_sparse = h->allow_sparse;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.n_end = N;
         cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
@@ -1325,23 +1306,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_seq_points = 0;
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
-        c.stat_s0fail = 0;
-        // "stage 0 provably fails" (k_dseed, CC_FLAG_S0FAIL): available when the bound's premises hold for this call -
-        // no pdim filter (the snapshot's pcore list is then the nearest of ALL pcore rows), every preferred-dimension
-        // entry 1 or k, a table whose whole history this handle has seen - and its quarter of margin covers the rounding
-        // errors of the variances: 64 d (n + 1024) 2^-53 M^2 max(1, 1 / k) <= eps^2 / 16 for n points of magnitude <= M
-        // since the last reset (sums of n squares carry a relative error of n 2^-53; coordinates far from the origin
-        // make the variances cancel and switch the proof off).  h_all: taken from the table by k_rebuild_scl below.
-        c.h_all = 0ull;
-        {
-            const double k = c.k, eps2 = c.eps_sq, M = h->coord_max;
-            const double kappa = (k > 1.0 ? k : 1.0) / (k < 1.0 ? k : 1.0);
-            const double slack = 64.0 * (double)h->d * ((double)h->points_total + 1024.0) * 0x1p-53 * M * M * (k < 1.0 ? 1.0 / k : 1.0);
-            const bool ok = h->allow_s0 && c.filter == 0 && !h->tainted && !h->hist_unknown && k > 0.0 && std::isfinite(kappa) &&
-                            eps2 > 0.0 && std::isfinite(eps2) && std::isfinite(slack) && slack <= eps2 / 16.0;
-            c.s0_on = ok ? 1 : 0;
-            c.s0_coef = ok ? 1.25 * eps2 * kappa : 0.0;
-        }
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         bool la_on = false;
         auto set_lookahead = [&](bool on) {
@@ -1370,10 +1334,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
         HIPCHK(hipMemsetAsync(h->pstat.p, 0, 4 * sizeof(unsigned long long), h->stream));
-        // (the displacement maxima are reset by the kernels as they go; the h maxima beside them only ever grow)
-        HIPCHK(hipMemsetAsync(h->v_tile_dsq.p, 0, h->v_tile_dsq.n * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
-            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
+            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
@@ -1416,6 +1378,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         int batch_windows = dec.batch_windows;
         h->prune_now = dec.prune != 0;
         nodirty = dec.nodirty != 0;
+        bool sparse_now = dec.sparse != 0;  // with nodirty: sparse dirty scans for the round's list of points
         long long cursor_prev = range_a;
         long long long_prev = 0;   // Ctl::stat_long at the end of the previous batch
         bool long_seen = false;    // ... and whether that batch added to it
@@ -1461,10 +1424,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     bad_batches = 0;
                     HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
                     h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
-                    h->hc.s0_on = 0;  // (k_seq changed rows without writing version rows: h_all no longer covers the table)
                     dec = policy.after_sequential(h->hc.cursor, h->hc.m_rows);
                     ptrace.sequential(h->hc.cursor, h->hc.m_rows, dec);
                     nodirty = dec.nodirty != 0;
+                    sparse_now = dec.sparse != 0;
                     set_lookahead(dec.lookahead != 0);
                     push_ctl(h);
                 }
@@ -1475,11 +1438,15 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             // (h->prune_now was set for this batch at the end of the previous one, together with the lookahead restart a
             // change of it needs: a pruned scan leaves fewer partials per point than a plain one)
             const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, 0};
+                             nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
-                             ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, 0};
+                             ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, nullptr, 0};
             const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
-                             car.tile_dsq, car.dsq, ver.tau, ver.skip_car, car.slot, tab.touch, tab.cap};
+                             car.tile_dsq, car.dsq, ver.tau, ver.skip_car, nullptr, car.slot, tab.touch, tab.cap};
+            // the sparse dirty scans: the same rows for the round's list of points instead of the window's tiles
+            Rows vrows_sp = vrows, crows_sp = crows;
+            vrows_sp.skip = nullptr; vrows_sp.plist = h->sp_list.p;
+            crows_sp.skip = nullptr; crows_sp.plist = h->sp_list.p;
             ev_sync = ev_base;
             // grids cover the window size of this batch (no window of the batch is larger), not the configured maximum
             const int gw = std::max(64, std::min(win, h->hc.win_cfg));
@@ -1494,6 +1461,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? 16 : 24);
             const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * prune_wgs) / std::max(1, (gw + 63) / 64)))
                                        : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
+            // capacity of the round's list for the sparse dirty scans: a sixteenth of the window (the policy's bound on
+            // the batch's average), in whole tiles
+            const int sparse_cap = std::min(CC_MAX_WINDOW / 16, std::max(64, ((gw / 16 + 63) / 64) * 64));
             const int decide_threads = h->decide_threads;
             const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
             const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
@@ -1521,7 +1491,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             Rows srows[2];
             for (int q = 0; q < 2; ++q)
                 srows[q] = Rows{scopy[q].cen, scopy[q].scl, nullptr, scopy[q].cf1, scopy[q].cf2, scopy[q].w, scopy[q].kind,
-                                scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+                                scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
@@ -1615,14 +1585,20 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                             hipLaunchKernelGGL(k_chain_long<false>, dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
                                                car, told, r, 0, (const int*)long_list);
                     }
+                    const bool sparse_r = nodirty && sparse_now;
                     hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                       h->clean.p, h->dseed.p, told, r, (const int8_t*)h->dpath.p);
+                                       h->clean.p, h->dseed.p, told, r, (const int8_t*)h->dpath.p, h->sp_list.p,
+                                       sparse_r ? sparse_cap : 0);
                     if (!nodirty) {
                         launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
                         if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
+                    } else if (sparse_r) {
+                        // (the grid covers the list's capacity; workgroups beyond the round's count return at once)
+                        launch_scan<true>(h, sA, sparse_cap, vrows_sp, h->dseed.p, h->dpart.p, Sd, r, 0);
+                        if (la_on) launch_scan<true>(h, sA, sparse_cap, crows_sp, h->dseed.p, h->dpart2.p, Sd, r, 1);
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
-                                       dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? 1 : 0, scan_rows,
+                                       dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
                                        dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1);
                     if (scan_rows > 0)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
@@ -1666,6 +1642,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 o.stat_trunc_unknown = h->hc.stat_trunc_unknown;
                 o.stat_tiles = h->hc.stat_tiles;
                 o.stat_dirty_tiles = h->hc.stat_dirty_tiles;
+                o.stat_unsafe = h->hc.stat_unsafe;
                 for (int r = 0; r < CC_MAX_ROUNDS + 2; ++r) o.round_hist[r] = h->hc.round_hist[r];
                 o.prune_rows = h->hc.stat_prune_rows;
                 o.prune_full = h->hc.stat_prune_full;
@@ -1684,6 +1661,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 Rcur = dec.rounds;
                 Sd = Sd_full;
                 nodirty = dec.nodirty != 0;
+                sparse_now = dec.sparse != 0;
                 shard_on = dec.shard != 0;
                 h->prune_now = dec.prune != 0;
                 if (dec.restart) {
@@ -1746,7 +1724,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.long_chain_launches += long_launches;
         h->stats.tiles += h->hc.stat_tiles;
         h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
-        h->stats.stage0_skipped += h->hc.stat_s0fail;
         if (timing) {
             double tot = 0.0;
             for (auto& t : timed) {
@@ -1867,7 +1844,6 @@ int cc_inject_mc(cc_handle* h, int kind, int32_t d, const double* cf1, const dou
         if (rc != CC_OK) return rc;
         ensure_table(h, (size_t)h->hc.m_rows + 1);
         const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d;
-        h->hist_unknown = true;  // (sums formed elsewhere: how many points, of what magnitude, is not known here)
         for (int i = 0; i < d; ++i)
             if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) h->tainted = true;
         HIPCHK(hipMemcpyAsync(h->tab.cf1.p + r * dd, cf1, dd * 8, hipMemcpyHostToDevice, h->stream));
@@ -1904,7 +1880,6 @@ int cc_inject_bulk(cc_handle* h, int kind, int32_t d, int32_t n, const double* c
         if (rc != CC_OK) return rc;
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)n);
         const size_t r = (size_t)h->hc.m_rows, dd = (size_t)d, nn = (size_t)n;
-        h->hist_unknown = true;  // (see cc_inject_mc)
         for (size_t i = 0; i < nn * dd; ++i)
             if (pref[i] != 1.0 && !(h->have_par && pref[i] == h->par.k)) { h->tainted = true; break; }
         const int knd = kind == CC_PCORE ? CC_KIND_PCORE : CC_KIND_OUTLIER;

@@ -140,6 +140,7 @@ struct Rows {
     const double* dsq;                   // only for version / carried rows: per-row squared displacement
     const double* tau;                   // only for version rows
     const int* skip;                     // dirty scans: per 64-point tile, 1 = nothing to do (Versions::skip)
+    const int* plist;                    // sparse dirty scans: the window points to scan, compacted (Ctl::n_sparse of them); else null
     const int* slot;                     // only for carried rows: table row
     const unsigned long long* touch;     // only for carried rows: Table::touch
     size_t cap;                          //                         Table::cap
@@ -200,15 +201,9 @@ struct Ctl {
     // pruned snapshot scans (k_scan_p): (wave, row) pairs visited / of those, pairs whose distance was evaluated in full
     // (a sample: the waves of every window's first point tile)
     unsigned long long stat_prune_rows, stat_prune_full;
-    // "stage 0 provably fails" (k_dseed, see CC_FLAG_S0FAIL): h_all = bits of the largest h(W) = (W + 1)^2 / W over every
-    // table row at the start of the call and every version row written since (k_rebuild_scl / k_commit_a keep it up);
-    // s0_coef = 1.25 * eps^2 * max(1, k) / min(1, k); s0_on = 0: the proof is not available for this call (host: pdim
-    // filter, mixed k, unknown history of the table, magnitudes whose rounding errors the margin does not cover)
-    unsigned long long h_all;
-    double s0_coef;
-    int s0_on;
+    // the round's list of points for the sparse dirty scans (k_dseed fills it, k_chain of the round resets the count)
+    int n_sparse;
     int pad2;
-    long long stat_s0fail;  // (point, validation round) pairs whose stage 0 was ruled out by that proof
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against
@@ -217,7 +212,6 @@ struct Ctl {
 //   1  outlier now and in the snapshot     ... outlier list ...
 //   2  pcore now, OUTLIER in the snapshot  (promoted since: hddstream.py:416-430) competes in the pcore list, but its
 //      snapshot distance is bounded through the point's OUTLIER list - its dsq is stored negated (see cc_dsq_class)
-//   3  (version rows only) not a displacement: the largest h(W) of the tile's rows, never reset within a call
 // Rows without a bound (new microclusters, changed preferred dimensions) carry dsq = +inf in class 0 / 1.
 #define CC_DSQ_STRIDE 4
 #define CC_TAU_STRIDE 4   // Versions::tau: thresholds of classes 0, 1, 2 per window point (+ 1 pad)
@@ -226,9 +220,10 @@ struct Ctl {
 #define CC_FLAG_U1 2       // ... of class 1
 #define CC_FLAG_C0 4       // the same for the carried rows
 #define CC_FLAG_C1 8
-#define CC_FLAG_S0FAIL 16  // no pcore microcluster live at this point can pass the radius test with it: stage 0 is skipped
 #define CC_FLAG_N1SKIP 32  // the outlier-kind threshold was withheld (the point is expected to join a pcore MC): a dirty
                            // scan that ran does not cover the outlier kind for this point
+#define CC_FLAG_SPARSE 64  // the point is on the round's list of points whose dirty scans run point by point (the sparse
+                           // dirty scans: compacted tiles of such points, both kinds covered) although its tile's did not
 
 // Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole
 // units of `unit` rows (1: table rows of a snapshot scan, current pcores of the association argmin; 64: p rows of

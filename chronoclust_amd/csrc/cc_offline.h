@@ -31,21 +31,12 @@ __global__ void k_downgrade_flags(Table tab, int m_rows, int d, double beta_mu, 
 }
 
 // scl column from pref (run before every online phase: covers injected rows and parameter changes)
-// ... and Ctl::h_all, the largest h(W) = (W + 1)^2 / W over the rows as they are now (CC_FLAG_S0FAIL; the host zeroes
-// the word before the launch)
-__global__ __launch_bounds__(256) void k_rebuild_scl(Ctl* __restrict__ ctl, Table tab, int m_rows, int d, int pow2, double inv_k)
+__global__ void k_rebuild_scl(Table tab, int m_rows, int d, int pow2, double inv_k)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < m_rows * d) {
-        const double pr = tab.pref[e];
-        tab.scl[e] = pow2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
-    }
-    unsigned long long hc = (e < m_rows) ? cc_h_code(tab.w[e]) : 0ull;
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned long long o = __shfl_xor(hc, off);
-        hc = o > hc ? o : hc;
-    }
-    if ((threadIdx.x & 63) == 0 && hc != 0ull) atomicMax(&ctl->h_all, hc);
+    if (e >= m_rows * d) return;
+    const double pr = tab.pref[e];
+    tab.scl[e] = pow2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
 }
 
 // dst row i <- src row perm[i]; kind / key / id are rewritten from the host-computed lists

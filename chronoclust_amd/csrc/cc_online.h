@@ -205,17 +205,6 @@ __device__ __forceinline__ double cc_dsq_store(double dq, int kind, int kind0, i
     *cls = (kind == CC_KIND_PCORE) ? (promoted ? 2 : 0) : 1;
     return promoted ? -dq : dq;
 }
-// h(W) = (W + 1)^2 / W = W + 2 + 1 / W as an ordered code (bits of a positive double; NaN / inf / W <= 0: all ones)
-__device__ __forceinline__ unsigned long long cc_h_code(double w)
-{
-    const double h = w + 2.0 + 1.0 / w;
-    return (w > 0.0 && h < CC_INF) ? (unsigned long long)__double_as_longlong(h) : ~0ull;
-}
-__device__ __forceinline__ double cc_h_value(unsigned long long code)
-{
-    return (code == ~0ull) ? CC_INF : __longlong_as_double((long long)code);
-}
-
 // wave-uniform operand of a dimension from bit BIT of its row mask: two scalar instructions (the compiler's own
 // selection takes three, and the scalar unit issues one instruction per wave turn like the vector unit)
 template <int BIT>

@@ -45,6 +45,7 @@ public:
         batch_windows_ = (win_cfg_ < 1024) ? 2 : std::max(2, c_.windows_per_sync / 4);
         la_on_ = c_.lookahead == 3;
         nodirty_ = false;
+        sparse_ = false;
         shard_on_ = policy_want_shard(c_, m_rows);
         prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0;  // (independent of the split: k_scan_p takes a row range)
         prune_resume_at_ = 0;
@@ -64,6 +65,7 @@ public:
         prev_.cursor = cursor;
         prev_.m_rows = m_rows;
         nodirty_ = false;
+        sparse_ = false;
         la_on_ = c_.lookahead == 3;
         return decision(1, 0);
     }
@@ -119,7 +121,16 @@ public:
         //  - The same holds while MCs are being promoted: a promoted MC competes in a list it was not scanned for, so
         //    the dirty scans run unpruned; the device counts the point tiles whose dirty scan ran.
         const long long tiles = o.stat_tiles - prev_.stat_tiles, dtiles = o.stat_dirty_tiles - prev_.stat_dirty_tiles;
-        const bool unpruned = tiles > 0 && dtiles * 2 > tiles;
+        //    What counts is how many POINTS needed rows that only a dirty scan covers, not how many tiles held such a
+        //    point: a few per cent of the points (the first points of a new population; points between two far pcore MCs
+        //    while their own MC is still an outlier MC) put one into most tiles.  While they stay under a sixteenth of
+        //    the batch's points their dirty scans run point by point (the sparse dirty scans: compacted tiles of just
+        //    those points), the tiles' scans are not launched and the windows run at full size with lookahead.
+        //    (c_.allow_sparse is the divisor: one point in allow_sparse.  Every such point costs a pass over the window's
+        //    live version rows, so the share has to be small: the work grows with the square of the window.)
+        const long long flagged = o.stat_unsafe - prev_.stat_unsafe;
+        const bool few_flagged = c_.allow_sparse > 0 && pts > 0 && flagged * c_.allow_sparse <= pts;
+        const bool unpruned = tiles > 0 && dtiles * 2 > tiles && !few_flagged;
         const int target = ((pts > 0 && grew * 50 > pts) || unpruned) ? std::min(win, early_win) : win;
         int want = win_cfg_;
         if (nodirty_ && trunc_batch > 0) {
@@ -143,7 +154,7 @@ public:
             if (trunc_batch == 0 && k_.clean_batches >= need) {
                 // a batch in which no window was cut short and no point tile needed its dirty scan (the table has
                 // settled: nothing created or promoted any more) goes straight to the full size
-                const bool settled = tiles > 0 && dtiles == 0 && grew == 0;
+                const bool settled = tiles > 0 && (dtiles == 0 || few_flagged) && grew == 0;
                 want = settled ? target : std::min(target, std::max(want, 64) * (want < kFastBelow ? 4 : 2));
             }
         }
@@ -152,7 +163,11 @@ public:
         // ---- dirty scans, lookahead, split, scan kind ----
         // lookahead scans pay when windows commit in full; while they are being truncated (start-up, few overlapping
         // MCs) the scan of a window that then starts elsewhere is wasted
-        nodirty_ = c_.allow_nodirty != 0 && tiles > 0 && dtiles == 0 && trunc_batch == 0;
+        // (a batch that ran without the tiles' scans and was cut short at a point that needed them: the sparse scans
+        // take such points from the next batch on - or, should they be many, the tiles' scans come back)
+        sparse_ = c_.allow_nodirty != 0 && few_flagged && flagged > 0 && tiles > 0 &&
+                  (trunc_batch == 0 || (nodirty_ && trunc_batch * 4 < wins));
+        nodirty_ = c_.allow_nodirty != 0 && tiles > 0 && ((dtiles == 0 && trunc_batch == 0) || sparse_);
         const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned);
         // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)
         const bool shard_next = policy_want_shard(c_, o.m_rows);
@@ -201,6 +216,7 @@ private:
         d.batch_windows = batch_windows_;
         d.lookahead = la_on_ ? 1 : 0;
         d.nodirty = nodirty_ ? 1 : 0;
+        d.sparse = sparse_ ? 1 : 0;
         d.prune = prune_on_ ? 1 : 0;
         d.shard = shard_on_ ? 1 : 0;
         d.restart = restart;
@@ -214,7 +230,7 @@ private:
     cc_policy_obs prev_{};
     int win_cfg_ = 0, rcur_ = 0, batch_windows_ = 2, stalled_ = 0;
     long long prune_resume_at_ = 0, prune_backoff_ = 65536;  // pruned scans are tried again from this point on / stretch after the next failed try
-    bool la_on_ = false, nodirty_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
+    bool la_on_ = false, nodirty_ = false, sparse_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
 };
 
 }  // namespace cc

@@ -79,8 +79,12 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
     const int bx = (int)blockIdx.x;
     {
     const int j0 = bx * (64 * PT);
-    if (j0 >= B) return;
-    if (DIRTY && rows.skip[bx] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
+    // Sparse dirty scans: the tile is not 64 consecutive window points but 64 entries of the round's list of points
+    // that need rows only a dirty scan covers (k_dseed compacted them: a few per cent of the window, in any order).
+    const bool sparse = DIRTY && rows.plist != nullptr;
+    const int n_list = sparse ? ctl->n_sparse : 0;
+    if (sparse ? (j0 >= n_list) : (j0 >= B)) return;
+    if (DIRTY && !sparse && rows.skip[bx] != 0) return;  // k_dseed: no row can matter to this tile; k_decide takes the seeds
     const int d = ctl->d;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform, in an SGPR
@@ -92,7 +96,29 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
     // Exact multi-GPU path: the table is replicated, rank r of `shard_world` scans the rows
     // [r * ceil(M / world), (r + 1) * ceil(M / world)) of the snapshot and the ranks exchange their per-point
     // candidates afterwards (k_merge_partials + all-gather); shard_world == 1: the whole table.
-    int row_lo = 0, row_hi = DIRTY ? (carried ? car_n : min(B, j0 + 64 * PT - 1)) : m_rows_scan;
+    int jj[PT];
+    bool valid[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int e = j0 + t * 64 + lane;
+        if (sparse) {
+            valid[t] = e < n_list;
+            jj[t] = valid[t] ? rows.plist[e] : 0;
+        } else {
+            jj[t] = e;
+            valid[t] = e < B;
+        }
+    }
+    // (version rows at or beyond the tile's last point cannot matter to it)
+    int rows_upto = min(B, j0 + 64 * PT - 1);
+    if (sparse) {
+        int mx = 0;
+#pragma unroll
+        for (int t = 0; t < PT; ++t) mx = max(mx, valid[t] ? jj[t] : 0);
+        for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+        rows_upto = min(B, __builtin_amdgcn_readfirstlane(mx));
+    }
+    int row_lo = 0, row_hi = DIRTY ? (carried ? car_n : rows_upto) : m_rows_scan;
     if (!DIRTY && shard_world > 1) cc_shard_range(m_rows_scan, shard_world, shard_rank, 1, &row_lo, &row_hi);
     const int nrows = row_hi - row_lo;
     // dirty scan: sub-ranges are whole 16-row tiles so that the per-tile displacement maxima line up
@@ -121,13 +147,6 @@ __global__ __launch_bounds__(64 * NW, (ScanShape<DP, DIRTY>::WGS)) void k_scan(c
     int* const s_next_w = s_int + 2 * CC_SCAN_TM;
 
     double p[PT][DP];
-    int jj[PT];
-    bool valid[PT];
-#pragma unroll
-    for (int t = 0; t < PT; ++t) {
-        jj[t] = j0 + t * 64 + lane;
-        valid[t] = jj[t] < B;
-    }
     // dirty scan: no version whose displacement is below wave_tau can matter to any point of this wave; when that
     // rules out every tile of the sub-range the wave only hands its seeds on and never loads its points
     // (per kind: a version competes in the list of its kind, against that list's threshold)

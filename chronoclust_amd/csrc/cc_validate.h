@@ -145,7 +145,7 @@ __device__ __forceinline__ void cc_row16_exchanges(F&& f)
 __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                               Versions ver, Carry car, const Cand* __restrict__ clean,
                                               Cand* __restrict__ seed, const int* __restrict__ T, int round,
-                                              const int8_t* __restrict__ dpath)
+                                              const int8_t* __restrict__ dpath, int* __restrict__ sparse_list, int sparse_cap)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -156,17 +156,15 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     const bool la_mode = ctl->mode != 0;
     // largest displacement of any version row / carried row (the workgroup is one wave)
     // (per kind, in cc_dsq_code form: 0 = the window / the carry set holds no row of the kind)
-    // (per class, see CC_DSQ_STRIDE; word 3 of the version rows' tiles: the largest h(W), for CC_FLAG_S0FAIL)
+    // (per class, see CC_DSQ_STRIDE)
     unsigned long long maxd[3] = {0ull, 0ull, 0ull}, maxd_car[3] = {0ull, 0ull, 0ull};
-    unsigned long long hmax = ctl->h_all;
     {
         for (int i = threadIdx.x; i < (B + 15) / 16; i += 64) {
             const unsigned long long* w = ver.tile_dsq + (size_t)i * CC_DSQ_STRIDE;
-            const unsigned long long v0 = w[0], v1 = w[1], v2 = w[2], v3 = w[3];
+            const unsigned long long v0 = w[0], v1 = w[1], v2 = w[2];
             maxd[0] = v0 > maxd[0] ? v0 : maxd[0];
             maxd[1] = v1 > maxd[1] ? v1 : maxd[1];
             maxd[2] = v2 > maxd[2] ? v2 : maxd[2];
-            hmax = v3 > hmax ? v3 : hmax;
         }
         if (la_mode)
             for (int i = threadIdx.x; i < (ctl->car_n + 15) / 16; i += 64) {
@@ -183,12 +181,10 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
                 maxd[K] = o > maxd[K] ? o : maxd[K];
                 maxd_car[K] = oc > maxd_car[K] ? oc : maxd_car[K];
             }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long o = __shfl_xor(hmax, off);
-            hmax = o > hmax ? o : hmax;
-        }
     }
-    bool flag_unprov = false, flag_unsafe = false, flag_s0 = false;
+    bool flag_unprov = false, flag_unsafe = false, flag_n1skip = false;
+    int flag_word = 0;
+    double tau_w[3] = {CC_INF, CC_INF, CC_INF};
     bool need_ver = false, need_car = false;  // this point's stages need rows only a dirty scan of the versions / the carry set covers
     if (j < B) {
     const Par par = cc_load_par(ctl);
@@ -431,64 +427,54 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
         t = (t == CC_INF) ? CC_INF : t * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
         tau[kd] = t;
     }
-    // Stage 0 (hddstream.py:288-343) can be ruled out as a whole.  Adding x to a MC (CF1, CF2, W) gives, per dimension,
-    //     var' = W / (W + 1) var + W / (W + 1)^2 (x - CF1 / W)^2  >=  (x - c)^2 / h(W),      h(W) = (W + 1)^2 / W,
-    // so the radius test's sum (mc_functions.py:45-56) is at least D / (kappa h(W)) for the MC's projected distance D
-    // from x (kappa = max(1, k) / min(1, k): the preferred-dimension weights of the two sums differ by at most that).
-    // If EVERY pcore MC that is live when j arrives has D > s0_coef * h_max (s0_coef = 1.25 kappa eps^2; the quarter
-    // covers the rounding of either side, the host checks that it does: Ctl::s0_on), whichever of them is nearest fails
-    // the test and j goes on to the outlier list - no pcore version can matter to it.  Lower bound of those D: the
-    // snapshot's best pcore distance (every untouched row), the seeded live versions of the list entries, and for the
-    // other touched rows their snapshot bound less the largest displacement of their class.
-    bool s0fail = false;
-    if (ctl->s0_on != 0 && provable && !filter) {
-        auto moved = [&](double base, unsigned long long code) -> double {
-            if (code == 0ull) return CC_INF;
-            const double dq = __longlong_as_double((long long)(code - 1ull));
-            if (!(dq < CC_INF) || base == CC_INF) return (base == CC_INF && dq < CC_INF) ? CC_INF : 0.0;
-            const double r = sqrt(base) * (1.0 - 1e-9) - sqrt(dq) * (1.0 + 1e-9);
-            return r > 0.0 ? r * r : 0.0;
-        };
-        const double base0 = have1[0] ? cq[0].dist : CC_INF;   // every pcore row of the snapshot is at least this far
-        const double base2 = d2v[1];                            // ... every outlier row outside the point's list
-        double lb = base0 < first0.dist ? base0 : first0.dist;
-        double m;
-        m = moved(base0, maxd[0]); lb = m < lb ? m : lb;
-        m = moved(base2, maxd[2]); lb = m < lb ? m : lb;
-        if (la_mode) {
-            m = moved(base0, maxd_car[0]); lb = m < lb ? m : lb;
-            m = moved(base2, maxd_car[2]); lb = m < lb ? m : lb;
-        }
-        s0fail = lb > ctl->s0_coef * cc_h_value(hmax);
-    }
     // Stage 1 (hddstream.py:345-395) is only reached when stage 0 fails.  A point whose previous decision was to join a
     // pcore MC is expected to do so again: the outlier-kind rows are not held against its tile, and k_decide refuses
     // the point (CC_T_UNKNOWN) if stage 0 fails after all and those rows were not covered.
-    const bool need0 = !s0fail;
+    const bool need0 = true;
     const bool need1 = !(T[j] >= 0 && dpath[j] == 0);
-    if (s0fail) { tau[0] = CC_INF; tau[2] = CC_INF; }
-    int flags = s0fail ? CC_FLAG_S0FAIL : 0;
+    int flags = 0;
     if (!(cc_dsq_below(maxd[0], tau[0]) && cc_dsq_below(maxd[2], tau[2]))) flags |= CC_FLAG_U0;
     if (!cc_dsq_below(maxd[1], tau[1])) flags |= CC_FLAG_U1;
     if (la_mode && !(cc_dsq_below(maxd_car[0], tau[0]) && cc_dsq_below(maxd_car[2], tau[2]))) flags |= CC_FLAG_C0;
     if (la_mode && !cc_dsq_below(maxd_car[1], tau[1])) flags |= CC_FLAG_C1;
-    if (!need1) { tau[1] = CC_INF; flags |= CC_FLAG_N1SKIP; }
-#pragma unroll
-    for (int kd = 0; kd < 3; ++kd) ver.tau[(size_t)j * CC_TAU_STRIDE + kd] = tau[kd];
-    ver.unsafe[j] = flags;
     need_ver = (need0 && (flags & CC_FLAG_U0)) || (need1 && (flags & CC_FLAG_U1));
     need_car = (need0 && (flags & CC_FLAG_C0)) || (need1 && (flags & CC_FLAG_C1));
     flag_unprov = !provable;
     flag_unsafe = need_ver || need_car;
-    flag_s0 = s0fail;
+    // (a point that goes on the sparse list keeps its real thresholds: its scans cover both kinds)
+    flag_n1skip = !need1;
+    flag_word = flags;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) tau_w[kd] = tau[kd];
+    }
+    // Sparse dirty scans (sparse_cap > 0: the host launches them instead of the tiles' scans): the points that need rows
+    // only a dirty scan covers go on the round's list, one atomic per wave that holds any; a point that finds the list
+    // full keeps its flags and is refused by k_decide (the window then commits up to it)
+    if (sparse_cap > 0) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(flag_unsafe);
+        if (m != 0ull) {
+            int base = 0;
+            if (threadIdx.x == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&ctl->n_sparse, __builtin_popcountll(m));
+            base = __shfl(base, __builtin_ctzll(m));
+            const int idx = base + __builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull));
+            if (flag_unsafe && idx < sparse_cap) {
+                sparse_list[idx] = j;
+                flag_word |= CC_FLAG_SPARSE;
+                flag_n1skip = false;
+            }
+        }
+    }
+    if (j < B) {
+        if (flag_n1skip) { tau_w[1] = CC_INF; flag_word |= CC_FLAG_N1SKIP; }
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) ver.tau[(size_t)j * CC_TAU_STRIDE + kd] = tau_w[kd];
+        ver.unsafe[j] = flag_word;
     }
     {
         // statistics for the host's trace line (one atomic per wave and only when something is flagged)
         const unsigned long long b1 = __builtin_amdgcn_ballot_w64(flag_unprov), b2 = __builtin_amdgcn_ballot_w64(flag_unsafe);
         if (threadIdx.x == 0 && b1) atomicAdd((unsigned long long*)&ctl->stat_unprovable, (unsigned long long)__builtin_popcountll(b1));
         if (threadIdx.x == 0 && b2) atomicAdd((unsigned long long*)&ctl->stat_unsafe, (unsigned long long)__builtin_popcountll(b2));
-        const unsigned long long b3 = __builtin_amdgcn_ballot_w64(flag_s0);
-        if (threadIdx.x == 0 && b3) atomicAdd((unsigned long long*)&ctl->stat_s0fail, (unsigned long long)__builtin_popcountll(b3));
     }
     // the tile as a whole: when no point of it needs a row that only a dirty scan covers - even the largest displacement
     // of every class stays below the point's threshold, for the stages the point is expected to evaluate -, the tile's
@@ -643,8 +629,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     const int flags = (round > 0) ? ver.unsafe[j] : 0;
     // a dirty scan that k_dseed ruled out for this point's tile was not run: the seeds are its whole result
     // (nodirty: the host did not launch the dirty scans at all; points that would have needed them are refused below)
-    const bool ran = round > 0 && nodirty == 0 && ver.skip[j >> 6] == 0;
-    const bool ran_car = round > 0 && nodirty == 0 && la_mode && ver.skip_car[j >> 6] == 0;
+    // (nodirty == 2: the sparse dirty scans ran instead - for the points on the round's list, both kinds covered)
+    const bool on_list = nodirty == 2 && (flags & CC_FLAG_SPARSE) != 0;
+    const bool ran = round > 0 && ((nodirty == 0 && ver.skip[j >> 6] == 0) || on_list);
+    const bool ran_car = round > 0 && la_mode && ((nodirty == 0 && ver.skip_car[j >> 6] == 0) || on_list);
     if (round > 0) {
         Cand dummy = none;
         if (!ran && !ran_car) {
@@ -750,9 +738,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         }
     };
     // A stage is evaluated only when the rows it needs were covered: by the seeds alone (no flag), or by the dirty scans
-    // of the point's tile.  Stage 0 is skipped when k_dseed proved that no live pcore MC can pass the radius test with
-    // this point (CC_FLAG_S0FAIL): whichever of them is nearest, the reference goes on to the outlier list.
-    if ((flags & CC_FLAG_S0FAIL) == 0) {
+    // of the point's tile.
+    {
         const bool missing = ((flags & CC_FLAG_U0) != 0 && !ran) || ((flags & CC_FLAG_C0) != 0 && la_mode && !ran_car);
         if (missing) T = CC_T_UNKNOWN;
         else run_stage(p1, p2, dvp, 0);
@@ -778,7 +765,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
-        if ((j & 15) == 0) {  // the next k_chain takes maxima into them (word 3, the h maximum, is never reset)
+        if ((j & 15) == 0) {  // the next k_chain takes maxima into them
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE] = 0ull;
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 1] = 0ull;
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 2] = 0ull;
@@ -881,7 +868,10 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     const int B = ctl->win_b;
     if (B == 0) return;
     if (ctl->fc[round - 1] >= B) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->last_round = round;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctl->last_round = round;
+        ctl->n_sparse = 0;  // (k_dseed of this round fills the list of points for the sparse dirty scans)
+    }
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
@@ -1088,7 +1078,6 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
                     int cls;
                     ver.dsq[cur] = cc_dsq_store(dq, bkind, isnew ? CC_KIND_DEAD : kind0, &cls);
                     atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
-                    atomicMax(&ver.tile_dsq[(size_t)(cur >> 4) * CC_DSQ_STRIDE + 3], cc_h_code(bw));
                 }
             }
         }
@@ -1409,7 +1398,6 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             int cls;
             ver.dsq[m] = cc_dsq_store(dq, kind, kind0, &cls);
             atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
-            atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * CC_DSQ_STRIDE + 3], cc_h_code((src >= 0) ? s_w[src] : s_bw));
         }
         __syncthreads();  // every read of the running state and of the queue slots is done
 
@@ -1533,26 +1521,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
                        ctl->la_cursor[qn] == next_cursor;
     if (la_ok)
         for (int i = tid; i < CC_DSQ_STRIDE * ((B + 15) / 16 + 1); i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into them
-    // the largest h(W) of this window's version rows (every round's: the words are never reset) joins the call's
-    // maximum, which therefore covers every state a table row has been committed in (CC_FLAG_S0FAIL)
-    __shared__ unsigned long long s_hmax;
-    if (tid == 0) s_hmax = ctl->h_all;
-    __syncthreads();
-    if (r >= 1) {
-        unsigned long long hm = 0ull;
-        for (int i = tid; i < (B + 15) / 16; i += 1024) {
-            const unsigned long long v = ver.tile_dsq[(size_t)i * CC_DSQ_STRIDE + 3];
-            hm = v > hm ? v : hm;
-        }
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long o = __shfl_xor(hm, off);
-            hm = o > hm ? o : hm;
-        }
-        if ((tid & 63) == 0 && hm != 0ull) atomicMax(&s_hmax, hm);
-    }
-    __syncthreads();
     if (tid == 0) {
-        ctl->h_all = s_hmax;
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         rec->carry = la_ok ? 1 : 0;
         rec->cursor = cursor;

@@ -118,9 +118,6 @@ typedef struct cc_stats {
                               * of more than 1 024 rows; smaller ones always run it)             */
     int64_t tiles;           /* 64-point tiles validated ...                                               */
     int64_t dirty_tiles;     /* ... and of those, tiles whose dirty scan had to run (last round of a window) */
-    int64_t stage0_skipped;  /* (point, validation round) pairs for which the pcore stage (hddstream.py:288-343)
-                              * was ruled out as a whole: no live pcore microcluster could pass the radius
-                              * test with the point                                 */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -319,7 +316,7 @@ typedef struct cc_policy_config {
     int32_t can_shard;         /* the handle belongs to a group and is not inside a relaxed super-step             */
     int32_t d;
     int32_t resume;            /* the call continues a stream this handle was clustering a moment ago              */
-    int32_t pad;
+    int32_t allow_sparse;      /* sparse dirty scans while at most one point in this many needs them (0: never)     */
     int64_t shard_min_row_dims;
     int64_t n_end;             /* end of the range of points the call clusters                                     */
 } cc_policy_config;
@@ -330,6 +327,7 @@ typedef struct cc_policy_obs {   /* cumulative device counters of the call as re
     int64_t cursor;
     int32_t m_rows, stall_b;
     int64_t stat_windows, stat_truncated, stat_trunc_unknown, stat_tiles, stat_dirty_tiles;
+    int64_t stat_unsafe;       /* (point, round) pairs that needed rows only a dirty scan covers                  */
     int64_t round_hist[CC_POLICY_MAX_ROUNDS + 2];
     uint64_t prune_rows, prune_full;
     int32_t after_sequential, pad;
@@ -341,7 +339,7 @@ typedef struct cc_policy_decision {
     int32_t restart;        /* the chain of windows restarts: pending lookahead scan dropped, control block pushed */
     int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
     int32_t stalled;        /* three batches without progress: the call fails with CC_ERR_INTERNAL                 */
-    int32_t pad;
+    int32_t sparse;         /* with nodirty: the sparse dirty scans run for the points that need rows of their own  */
     int64_t wins, pts, trunc, unk, tiles, dtiles, grew, prune_rows, prune_full;  /* what the batch did (deltas)     */
 } cc_policy_decision;
 int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,

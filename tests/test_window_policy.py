@@ -18,7 +18,7 @@ from chronoclust_amd import _lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TRACES = sorted(glob.glob(os.path.join(HERE, "golden", "policy", "*.jsonl")))
-DEC_KEYS = ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune", "shard", "restart", "bad", "stalled")
+DEC_KEYS = ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune", "shard", "restart", "bad", "stalled", "sparse")
 
 
 def calls_of(path):
@@ -28,7 +28,7 @@ def calls_of(path):
         rec = json.loads(line)
         if "call" in rec:
             c = rec["call"]
-            calls.append((dict(c["config"], pad=0), tuple(c["carry"]), tuple(c["start"]), c["dec"], []))
+            calls.append((dict(c["config"]), tuple(c["carry"]), tuple(c["start"]), c["dec"], []))
         else:
             calls[-1][4].append((rec["obs"], rec["dec"]))
     return calls
@@ -102,7 +102,7 @@ def test_decisions_do_not_depend_on_anything_but_the_counter_deltas():
 
 def test_three_batches_without_progress_stop_the_call():
     cfg = dict(window=24576, rounds_max=3, windows_per_sync=16, early_window=0, lookahead=0, allow_nodirty=1, prune_mode=2,
-               prune_applicable=1, can_shard=0, d=20, resume=0, pad=0, shard_min_row_dims=400000, n_end=100000)
+               prune_applicable=1, can_shard=0, d=20, resume=0, allow_sparse=1, shard_min_row_dims=400000, n_end=100000)
     stuck = dict(cursor=5000, m_rows=100, stat_windows=4, stat_tiles=16, stat_dirty_tiles=0, round_hist=[0, 4] + [0] * 8)
     obs = [dict(stuck)]
     for i in range(3):
