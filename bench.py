@@ -51,7 +51,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_VALU_FILE = os.path.join(ROOT, "profiles", "r04_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
 REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
 EXIT_LEG_FAILED = 3
 
@@ -267,18 +268,97 @@ def digest_of(h):
     return m.hexdigest()
 
 
+def load_pmc_valu(d):
+    """The per-kernel PMC figures of the scan kernels at dimensionality d (pruned chain, plain scan) - only when they were
+    measured on these kernel sources (the files carry the SHA-256 of chronoclust_amd/csrc/)."""
+    out, why = {}, None
+    digest = csrc_digest()
+    for suffix in ("", "_plain"):
+        path = PMC_VALU_FILE % (d, suffix)
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except (OSError, ValueError):
+            why = "no PMC passes on file for d = %d (%s)" % (d, os.path.basename(path))
+            continue
+        if pm.get("csrc_sha256") != digest:
+            why = "profiles/%s was measured on other kernel sources (csrc digest differs)" % os.path.basename(path)
+            continue
+        for name, k in pm["kernels"].items():
+            out[name] = dict(k, source=os.path.basename(path))
+    need = ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p")
+    return (out, None) if all(n in out for n in need) else (None, why or "incomplete PMC files for d = %d" % d)
+
+
 def scan_roofline(acc, d, kernel):
-    """The `roofline` object of a leg's snapshot scan from the library's own HIP-event timing of every launch
-    (cc_stats, time_kernels = 1): 3 fp64 VALU instructions per (point, microcluster, dim), see the headline's comment."""
+    """The `roofline` object of a snapshot scan from the library's own HIP-event timing of every launch (cc_stats,
+    time_kernels = 1).  The binding roof is fp64 / VALU issue, not HBM (intensity ~1.5 M flop/B).
+      achieved / frac   EXECUTED VALU instruction-lanes per second over all timed launches: per kernel of the chain the
+                        instructions per (wave of 64 points, table row) that rocprofv3's SQ_INSTS_VALU pass counted
+                        (profiles/r04_pmc_valu_*.json, quoted only for the kernel sources they were measured on) x the
+                        (wave, row) pairs this run's launches covered x 64 lanes.  What the hardware did.
+      effective         the ALGORITHMIC rate: 3 fp64 instructions per (point, microcluster, dim) - sub, mul, fma; k = 4 is
+                        a power of two, so x2 * 2^e + acc in one rounding is the reference's double - whether or not they
+                        were issued.  A pruned chain abandons a row as soon as its partial sum provably exceeds the
+                        point's threshold, so this figure can exceed what an every-pair scan could reach (or 1).
+      parts             the plain scans (start-up: the table is filling, most rows would be completed) and the pruned
+                        chains (steady state) apart, with their launch counts
+      executed          the per-kernel counters behind `achieved`: instructions per (wave, row), VALU- and LDS-busy
+                        fractions of full windows running alone, the named co-limiter"""
     secs = acc["scan_ms"] * 1e-3
     if not secs or not acc["scan_launches"]:
         return None
-    issued = 3.0 * acc["scan_pair_dims"] / secs / 1e12
-    return {"bound": "fp64_valu", "kernel": kernel, "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
-            "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
-            "launches": int(acc["scan_launches"]), "avg_launch_us": 1e3 * acc["scan_ms"] / acc["scan_launches"],
-            "pair_dims_per_launch": acc["scan_pair_dims"] / acc["scan_launches"], "instr_per_pair_dim": 3.0,
-            "pruning": prune_note(acc)}
+    pd_all, pd_p = acc["scan_pair_dims"], acc.get("scan_pair_dims_pruned", 0.0)
+    ms_p, n_p = acc.get("scan_ms_pruned", 0.0), int(acc.get("scan_launches_pruned", 0))
+    ms_u, n_u = acc["scan_ms"] - ms_p, int(acc["scan_launches"]) - n_p
+    issued = 3.0 * pd_all / secs / 1e12
+    out = {"bound": "fp64_valu", "kernel": kernel, "achieved": None, "peak": FP64_VALU_PEAK_TOPS,
+           "unit": "T VALU instruction-lanes/s (executed)", "frac": None, "traffic": None,
+           "launches": int(acc["scan_launches"]), "avg_launch_us": 1e3 * acc["scan_ms"] / acc["scan_launches"],
+           "pair_dims_per_launch": pd_all / acc["scan_launches"],
+           "effective": {"achieved": issued, "frac": issued / FP64_VALU_PEAK_TOPS, "instr_per_pair_dim": 3.0,
+                         "unit": "T fp64 VALU instruction-lanes/s (algorithmic: 3 per (point, microcluster, dim), issued or not)"},
+           "pruning": prune_note(acc)}
+    parts = {}
+    if n_u:
+        parts["plain"] = {"kernel": "k_scan_u (start-up: every row evaluated in full)", "launches": n_u,
+                          "avg_launch_us": 1e3 * ms_u / n_u, "effective_frac": 3.0 * (pd_all - pd_p) / (ms_u * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
+    if n_p:
+        parts["pruned"] = {"kernel": "k_seed + k_seed_merge + k_scan_p (steady state: rows abandoned on a prefix)", "launches": n_p,
+                           "avg_launch_us": 1e3 * ms_p / n_p, "effective_frac": 3.0 * pd_p / (ms_p * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
+    out["parts"] = parts
+    pm, why = load_pmc_valu(d)
+    if pm is None:
+        out["executed"] = None
+        out["executed_note"] = "not quoted: %s; re-run tools/profile_round.sh (SECTIONS=valu).  `effective` is the " \
+                               "algorithmic figure, not what the hardware issued" % why
+        return out
+    # instruction-lanes: instructions per (wave, row) x (wave, row) pairs x 64 lanes = instructions per (wave, row) x pairs
+    pairs_u, pairs_p = (pd_all - pd_p) / d, pd_p / d
+    full = (acc["pruned_scan_full_rows"] / acc["pruned_scan_rows"]) if acc.get("pruned_scan_rows") else 0.0
+    # a pruned launch of this run may complete more rows than the steady-state launches the counters were taken on (the
+    # first pruned windows of a stream): every completed row beyond that share is charged the plain scan's row
+    full_pmc = 0.013 if d <= 20 else 0.0013
+    extra = max(0.0, full - full_pmc) * pm["k_scan_u"]["valu_instructions_per_wave_row"]
+    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_p")) + extra
+    lanes_u = pairs_u * pm["k_scan_u"]["valu_instructions_per_wave_row"]
+    lanes_p = pairs_p * per_row_p
+    executed = (lanes_u + lanes_p) / secs / 1e12
+    out["achieved"], out["frac"] = executed, executed / FP64_VALU_PEAK_TOPS
+    if n_u:
+        parts["plain"]["executed_frac"] = lanes_u / (ms_u * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS
+    if n_p:
+        parts["pruned"]["executed_frac"] = lanes_p / (ms_p * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS
+        parts["pruned"]["valu_instr_per_wave_row"] = per_row_p
+    keys = ("valu_instructions_per_wave_row", "salu_instructions_per_wave_row", "lds_instructions_per_wave_row",
+            "valu_busy_fraction", "lds_busy_fraction", "lds_array_busy_fraction", "wave_time_parked_on_waitcnt",
+            "co_limiter", "avg_us_under_pmc", "source")
+    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p")},
+                       "instruction_lanes_per_launch": (lanes_u + lanes_p) / acc["scan_launches"],
+                       "note": "counters of full windows running alone (tools/steady.py under rocprofv3 --pmc, three passes); "
+                               "busy fractions are of the kernel's own run time, `frac` above is over this run's launches "
+                               "(short start-up windows and co-running validation kernels included)"}
+    return out
 
 
 def scan_kernel_name(s, d):
@@ -293,10 +373,10 @@ def prune_note(acc):
         return None
     return {"pruned_launches": int(acc["scan_p_launches"]), "of_scan_launches": int(acc["scan_u_launches"]),
             "rows_evaluated_in_full_frac": (acc["pruned_scan_full_rows"] / acc["pruned_scan_rows"]) if acc["pruned_scan_rows"] else None,
-            "note": "`achieved` counts the ALGORITHMIC 3 fp64 instructions per (point, microcluster, dim); a pruned launch "
-                    "(k_seed -> k_seed_merge -> k_scan_p, timed as one) abandons a row as soon as its partial sum provably "
-                    "exceeds the point's threshold and evaluates only this fraction of the (wave, row) pairs over all "
-                    "dimensions - exactly (same labels, same tables): frac may exceed what an every-pair scan can reach"}
+            "note": "a pruned launch (k_seed -> k_seed_merge -> k_scan_p, timed as one) abandons a row as soon as its partial "
+                    "sum provably exceeds the point's threshold and evaluates only this fraction of the (wave, row) pairs "
+                    "over all dimensions - exactly (same labels, same tables).  `effective` counts the algorithmic 3 fp64 "
+                    "instructions per (point, microcluster, dim) for those rows as well, `achieved` does not"}
 
 
 def join_group(h, rank, world, group):
@@ -354,7 +434,8 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     sync(h)
     t0 = time.perf_counter()
     acc = dict(scan_ms=0.0, scan_launches=0, comm_ms=0.0, comm_launches=0, run_ms=0.0, scan_pair_dims=0.0,
-               scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0, sharded_windows=0)
+               scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0, sharded_windows=0,
+               scan_ms_pruned=0.0, scan_launches_pruned=0, scan_pair_dims_pruned=0.0)
     for _ in range(args.stream_steps):
         s, n_clusters = step()
         for k in acc:
@@ -435,7 +516,8 @@ def relaxed_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label
     sync(h)
     t0 = time.perf_counter()
     acc = dict(scan_ms=0.0, scan_launches=0, scan_pair_dims=0.0, scan_p_launches=0, scan_u_launches=0,
-               pruned_scan_rows=0, pruned_scan_full_rows=0)
+               pruned_scan_rows=0, pruned_scan_full_rows=0, scan_ms_pruned=0.0, scan_launches_pruned=0,
+               scan_pair_dims_pruned=0.0)
     for _ in range(args.stream_steps):
         s, arrays = step()
         for k in acc:
@@ -600,17 +682,14 @@ def main():
         step()
     sync(h)
     t0 = time.perf_counter()
-    scan_ms = scan_launches = 0.0
-    pair_dims = table_rows = 0.0
+    table_rows = 0.0
     online_ms = 0.0
-    pacc = dict(scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0, pruned_scan_full_rows=0)
+    pacc = dict(scan_ms=0.0, scan_launches=0, scan_pair_dims=0.0, scan_p_launches=0, scan_u_launches=0, pruned_scan_rows=0,
+                pruned_scan_full_rows=0, scan_ms_pruned=0.0, scan_launches_pruned=0, scan_pair_dims_pruned=0.0)
     for _ in range(args.steps):
         s, n_clusters = step()
         for k in pacc:
             pacc[k] += s[k]
-        scan_ms += s["scan_ms"]
-        scan_launches += s["scan_launches"]
-        pair_dims += s["scan_pair_dims"]
         table_rows += s["table_rows_scanned"]
         online_ms += s["run_ms"]
     sync(h)
@@ -644,24 +723,14 @@ def main():
             "harness": "no torch: cc_sync for the timing bracket, chronoclust_amd.rendezvous (TCP) for barrier / max "
                        "over ranks / RCCL id",
         }
-        if scan_launches:
-            # The dominant kernel is bound by fp64 VALU issue, not by HBM (intensity ~1.5 M flop/B): per
-            # (point, microcluster, dim) the reference does sub, mul, div-by-pref, add; k = 4 is a power of two, so
-            # the kernel issues 3 fp64 instructions for them (v_add, v_mul, v_fma - one rounding of x2 * 2^e + acc is
-            # the same double, guarded against subnormal products).  achieved = those instruction-lanes per second
-            # over ALL timed launches of the kernel (short start-up windows and co-running lookahead scans
-            # included); the best-two update per (point, microcluster) is overhead and not counted.
+        if pacc["scan_launches"]:
+            # the dominant kernel: the snapshot scan (see scan_roofline for what achieved / effective / parts / executed are)
+            scan_ms, scan_launches = pacc["scan_ms"], pacc["scan_launches"]
             n_pts = n * args.steps
             alg_bytes = n_pts * (8 * d + 4) + table_rows * (16 * d + 8)
-            secs = scan_ms * 1e-3
-            hbm = alg_bytes / secs / 1e9
-            issued = 3.0 * pair_dims / secs / 1e12
-            out["roofline"] = {
-                "bound": "fp64_valu", "kernel": scan_kernel_name(s, d) + " (snapshot scan)", "achieved": issued, "peak": FP64_VALU_PEAK_TOPS,
-                "unit": "T fp64 VALU instruction-lanes/s", "frac": issued / FP64_VALU_PEAK_TOPS, "traffic": None,
-                "launches": int(scan_launches), "avg_launch_us": 1e3 * scan_ms / scan_launches,
-                "instr_per_pair_dim": 3.0, "pair_dims_per_launch": pair_dims / scan_launches,
-                "pruning": prune_note(pacc),
+            hbm = alg_bytes / (scan_ms * 1e-3) / 1e9
+            out["roofline"] = scan_roofline(pacc, d, scan_kernel_name(s, d) + " (snapshot scan)")
+            out["roofline"].update({
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes / scan_launches,
                         "note": "algorithmic bytes: the window's points (8d + 4 label bytes each) + the table columns "
@@ -670,7 +739,7 @@ def main():
                                 "cannot be met by an exact implementation at these table sizes (README.md)"},
                 "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead scans "
                                "(second stream, beside the validation kernels of the previous window, including the "
-                               "few that go unused) and in-place scans (short windows of the start-up phase included)"}
+                               "few that go unused) and in-place scans (short windows of the start-up phase included)"})
             # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
             # separate runs); only quoted when it was measured on this workload shape AND on these kernel sources
             try:

@@ -38,7 +38,8 @@ class CcStats(C.Structure):
                 ("comm_ms", C.c_double), ("seq_points", C.c_int64), ("scan_u_launches", C.c_int64),
                 ("scan_p_launches", C.c_int64), ("pruned_scan_rows", C.c_int64), ("pruned_scan_full_rows", C.c_int64),
                 ("window", C.c_int64), ("long_chains", C.c_int64), ("long_chain_launches", C.c_int64),
-                ("tiles", C.c_int64), ("dirty_tiles", C.c_int64)]
+                ("tiles", C.c_int64), ("dirty_tiles", C.c_int64),
+                ("scan_launches_pruned", C.c_int64), ("scan_ms_pruned", C.c_double), ("scan_pair_dims_pruned", C.c_double)]
 
 
 POLICY_MAX_ROUNDS = 8

@@ -1340,11 +1340,12 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
         size_t ev_used = 2;
-        std::vector<std::pair<size_t, double>> timed;  // (event index, pair-dims covered)
+        std::vector<std::pair<size_t, double>> timed;  // (event index, 1.0 for a pruned chain)
         std::vector<size_t> timed_comm;                // event index of every timed merge + all-gather
         const bool timing = h->tun.time_kernels != 0;
         bool shard_on = dec.shard != 0;
         double pair_rows_eff = 0.0, pair_rows_prev = 0.0;  // (window points x table rows) this rank's scans covered
+        double pair_rows_pruned = 0.0;                     // ... of those, by pruned chains
         long long sharded_windows = 0;
 
         const Versions ver = versions_view(h);
@@ -1505,7 +1506,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         HIPCHK(hipEventRecord(a, st));
                         launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
                         HIPCHK(hipEventRecord(b, st));
-                        timed.push_back({ev_used, 0.0});
+                        timed.push_back({ev_used, h->prune_now ? 1.0 : 0.0});  // (second: a pruned chain or a plain scan)
                         ev_used += 2;
                         if (!shard_on) scan_end = b;
                     } else {
@@ -1656,6 +1657,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     fprintf(stderr, "[cc] pruned scans of the batch (sample): %lld (wave, row) pairs, %.1f %% evaluated in full\n",
                             (long long)dec.prune_rows, 100.0 * (double)dec.prune_full / (double)dec.prune_rows);
                 pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
+                if (h->prune_now) pair_rows_pruned += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
                 pair_rows_prev = h->hc.stat_pair_rows;
                 if (shard_was) sharded_windows += dec.wins;
                 Rcur = dec.rounds;
@@ -1713,6 +1715,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.truncated += h->hc.stat_truncated;
         h->stats.rows = h->hc.m_rows;
         h->stats.scan_pair_dims += pair_rows_eff * (double)h->d;
+        h->stats.scan_pair_dims_pruned += pair_rows_pruned * (double)h->d;
         h->stats.sharded_windows += sharded_windows;
         h->stats.seq_points += h->hc.stat_seq_points;
         h->seq_sticky = seq_on;
@@ -1725,14 +1728,18 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.tiles += h->hc.stat_tiles;
         h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
         if (timing) {
-            double tot = 0.0;
+            double tot = 0.0, tot_p = 0.0;
+            int64_t n_p = 0;
             for (auto& t : timed) {
                 float e = 0.f;
                 HIPCHK(hipEventElapsedTime(&e, h->ev_pool[t.first], h->ev_pool[t.first + 1]));
                 tot += e;
+                if (t.second != 0.0) { tot_p += e; ++n_p; }
             }
             h->stats.scan_launches += (int64_t)timed.size();
             h->stats.scan_ms += tot;
+            h->stats.scan_launches_pruned += n_p;
+            h->stats.scan_ms_pruned += tot_p;
             double ctot = 0.0;
             for (size_t i : timed_comm) {
                 float e = 0.f;

@@ -1326,7 +1326,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
             // `!(q > t)`, not `q <= t`: coordinates beyond single precision's range (|x| >= 2^128) give inf - inf = NaN in
             // the prefix, and a row whose prefix sum is not a number has to be KEPT (phase B evaluates it exactly); an
             // overflow to +inf is a sum that really exceeds every finite T32 (tests/test_pruned_scan.py, huge coordinates)
-            surv |= (__builtin_amdgcn_ballot_w64(valid && !(q > t)) != 0ull) ? (1u << m) : 0u;
+            // (lanes without a point hold T32 = -inf and a finite or infinite q, never NaN: their own p is 0)
+            surv |= (__builtin_amdgcn_ballot_w64(!(q > t)) != 0ull) ? (1u << m) : 0u;
         };
         auto phase_a = [&](auto KSELC) {
             int m = 0;

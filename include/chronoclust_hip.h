@@ -118,6 +118,9 @@ typedef struct cc_stats {
                               * of more than 1 024 rows; smaller ones always run it)             */
     int64_t tiles;           /* 64-point tiles validated ...                                               */
     int64_t dirty_tiles;     /* ... and of those, tiles whose dirty scan had to run (last round of a window) */
+    int64_t scan_launches_pruned;  /* of scan_launches: the timed launches that were pruned chains ...       */
+    double  scan_ms_pruned;        /* ... their share of scan_ms ...                                          */
+    double  scan_pair_dims_pruned; /* ... and of scan_pair_dims (the rest: plain scans)                       */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

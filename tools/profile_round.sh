@@ -40,19 +40,24 @@ python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $(python -c "import js
 echo "pmc traffic done"
 fi
 if want valu; then
-# VALU counters of the snapshot-scan kernels of full windows running alone (tools/steady.py, LA=2), at d = 20, 40, 14
-for SH in "20 5000 1000000" "40 50000 2000000" "14 2000 2000000"; do
+# VALU / LDS counters of the snapshot-scan kernels of full windows running alone (tools/steady.py, LA=2), at d = 20, 40,
+# 14: the pruned chain (default policy) and the plain scan k_scan_u (CHRONOCLUST_HIP_PRUNE=0: what the start-up phase runs)
+PA="GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU"
+PB="GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES"
+PC="GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
+# (VALU_SHAPES="20 5000 1000000" picks one shape: "<d> <microclusters> <points>;...")
+IFS=';' read -ra SHAPES <<< "${VALU_SHAPES:-20 5000 1000000;40 50000 2000000;14 2000 2000000}"
+for SH in "${SHAPES[@]}"; do
   set -- $SH
-  D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_valu_a_d$1 -o r -- python tools/steady.py > $OUT/pmc_valu_a_d$1.txt 2>&1 || exit 1
-  D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_valu_b_d$1 -o r -- python tools/steady.py > $OUT/pmc_valu_b_d$1.txt 2>&1 || exit 1
-  python tools/pmc_valu_summary.py $OUT/pmc_valu_a_d$1 $OUT/pmc_valu_b_d$1 $1 $2 > $OUT/pmc_valu_d$1.json
+  for MODE in pruned plain; do
+    if [ $MODE = plain ]; then export CHRONOCLUST_HIP_PRUNE=0; SUF=_plain; else unset CHRONOCLUST_HIP_PRUNE; SUF=; fi
+    D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PA --output-format csv -d $OUT/pmc_valu_a_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_a_d$1$SUF.txt 2>&1 || exit 1
+    D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PB --output-format csv -d $OUT/pmc_valu_b_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_b_d$1$SUF.txt 2>&1 || exit 1
+    D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PC --output-format csv -d $OUT/pmc_valu_c_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_c_d$1$SUF.txt 2>&1 || exit 1
+    python tools/pmc_valu_summary.py $OUT/pmc_valu_a_d$1$SUF $OUT/pmc_valu_b_d$1$SUF $OUT/pmc_valu_c_d$1$SUF $1 $2 > $OUT/pmc_valu_d$1$SUF.json
+  done
 done
-# ... and of the plain scan k_scan_u<20> (what the start-up phase runs), the pruned scan switched off
-export CHRONOCLUST_HIP_PRUNE=0
-D=20 G=5000 N=1000000 LA=2 REPS=1 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $OUT/pmc_valu_a_plain -o r -- python tools/steady.py > $OUT/pmc_valu_a_plain.txt 2>&1 || exit 1
-D=20 G=5000 N=1000000 LA=2 REPS=1 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/pmc_valu_b_plain -o r -- python tools/steady.py > $OUT/pmc_valu_b_plain.txt 2>&1 || exit 1
 unset CHRONOCLUST_HIP_PRUNE
-python tools/pmc_valu_summary.py $OUT/pmc_valu_a_plain $OUT/pmc_valu_b_plain 20 5000 > $OUT/pmc_valu_d20_plain.json
 echo "pmc valu done"
 fi
 # (the raw traces and counter files are large: only the summaries made above travel back)
