@@ -39,7 +39,8 @@ class CcStats(C.Structure):
                 ("scan_p_launches", C.c_int64), ("pruned_scan_rows", C.c_int64), ("pruned_scan_full_rows", C.c_int64),
                 ("window", C.c_int64), ("long_chains", C.c_int64), ("long_chain_launches", C.c_int64),
                 ("tiles", C.c_int64), ("dirty_tiles", C.c_int64),
-                ("scan_launches_pruned", C.c_int64), ("scan_ms_pruned", C.c_double), ("scan_pair_dims_pruned", C.c_double)]
+                ("scan_launches_pruned", C.c_int64), ("scan_ms_pruned", C.c_double), ("scan_pair_dims_pruned", C.c_double),
+                ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -48,7 +49,8 @@ POLICY_MAX_ROUNDS = 8
 class CcPolicyConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
-                                         "allow_sparse")] + [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
+                                         "allow_sparse", "allow_guess", "pad")] + \
+               [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
 
 
 class CcPolicyCarry(C.Structure):
@@ -58,9 +60,9 @@ class CcPolicyCarry(C.Structure):
 class CcPolicyObs(C.Structure):
     _fields_ = [("cursor", C.c_int64), ("m_rows", C.c_int32), ("stall_b", C.c_int32)] + \
                [(k, C.c_int64) for k in ("stat_windows", "stat_truncated", "stat_trunc_unknown", "stat_tiles",
-                                         "stat_dirty_tiles", "stat_unsafe")] + \
+                                         "stat_dirty_tiles", "stat_unsafe", "stat_missed")] + \
                [("round_hist", C.c_int64 * (POLICY_MAX_ROUNDS + 2)), ("prune_rows", C.c_uint64), ("prune_full", C.c_uint64),
-                ("after_sequential", C.c_int32), ("pad", C.c_int32)]
+                ("after_sequential", C.c_int32), ("tg_ok", C.c_int32)]
 
 
 class CcPolicyDecision(C.Structure):

@@ -131,6 +131,11 @@ struct cc_handle {
     int prune_mode = 1;
     double prune_F = 16.0;
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
+    bool guess_now = false;   // ... with guessed thresholds (k_scan_p + k_missed + the seeded chain for the missed points)
+    bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
+    DevBuf<unsigned long long> found;  // [2][CC_MAX_WINDOW / 64] per point tile: the points a guessed-threshold scan found a pcore MC for
+    DevBuf<int> missed;                // [2][CC_MISSED_CAP] the others, listed by k_missed (two window parities)
+    double x_absmax = 0.0;             // the largest |coordinate| of the resident points (k_check_finite)
     int prune_rounds4 = 0;    // workgroups per CU a pruned scan is split into (CHRONOCLUST_HIP_PRUNE_WGS; 0: by width, see S)
     DevBuf<SeedCand> spart;   // [2][window, S, 2]  prefix-score winners per workgroup sub-range and kind (two window parities)
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
@@ -219,7 +224,7 @@ struct cc_handle {
         hipStream_t stream = nullptr;
         void* pin[2] = {nullptr, nullptr};
         size_t pin_bytes = 0;
-        int bad_host = 0;
+        int bad_host[4] = {0, 0, 0, 0};  // k_check_finite's words: [0] non-finite flag, [2..3] bits of the largest |value|
         int rc = 0;                     // hipError_t of the worker (0: fine)
         const char* what = "";
     } pf;
@@ -244,9 +249,10 @@ struct PolicyTrace {
     static void obs_json(FILE* f, const cc_policy_obs& o)
     {
         fprintf(f, "{\"cursor\": %lld, \"m_rows\": %d, \"stall_b\": %d, \"stat_windows\": %lld, \"stat_truncated\": %lld, "
-                   "\"stat_trunc_unknown\": %lld, \"stat_tiles\": %lld, \"stat_dirty_tiles\": %lld, \"stat_unsafe\": %lld, \"round_hist\": [",
+                   "\"stat_trunc_unknown\": %lld, \"stat_tiles\": %lld, \"stat_dirty_tiles\": %lld, \"stat_unsafe\": %lld, \"stat_missed\": %lld, \"tg_ok\": %d, \"round_hist\": [",
                 (long long)o.cursor, o.m_rows, o.stall_b, (long long)o.stat_windows, (long long)o.stat_truncated,
-                (long long)o.stat_trunc_unknown, (long long)o.stat_tiles, (long long)o.stat_dirty_tiles, (long long)o.stat_unsafe);
+                (long long)o.stat_trunc_unknown, (long long)o.stat_tiles, (long long)o.stat_dirty_tiles, (long long)o.stat_unsafe,
+                (long long)o.stat_missed, o.tg_ok);
         for (int r = 0; r < CC_POLICY_MAX_ROUNDS + 2; ++r) fprintf(f, "%s%lld", r ? ", " : "", (long long)o.round_hist[r]);
         fprintf(f, "], \"prune_rows\": %llu, \"prune_full\": %llu, \"after_sequential\": %d}", (unsigned long long)o.prune_rows,
                 (unsigned long long)o.prune_full, o.after_sequential);
@@ -268,9 +274,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"allow_sparse\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, (long long)c.shard_min_row_dims, (long long)c.n_end,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, (long long)c.shard_min_row_dims, (long long)c.n_end,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -437,6 +443,8 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->thr32.ensure(2 * h->thr_stride);
     h->cmax.ensure(2);
     h->pstat.ensure(4);
+    h->found.ensure(2 * (CC_MAX_WINDOW / 64));
+    h->missed.ensure(2 * CC_MISSED_CAP);
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
     h->clean.ensure(w * 4); h->dseed.ensure(w * 4);
     h->c_cf1v.ensure(w * d); h->c_cf2v.ensure(w * d); h->c_cenv.ensure(w * d); h->c_prefv.ensure(w * d);
@@ -512,19 +520,36 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
             ++h->stats.scan_u_launches;
             if constexpr (DP > 8) {
                 if (h->prune_now) {
-                    // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them
                     ++h->stats.scan_p_launches;
-                    // (k_seed holds two points per lane: point tiles of 128)
-                    hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
-                                       rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p);
-                    hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
-                                       rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
-                                       h->prune_F, round, mode, h->cmax.p, h->pstat.p);
-                    // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
-                    // that every rank abandons against the same T -, phases A / B over the rank's own rows)
-                    hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
-                                       rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                       h->part_stride, shard_rank, shard_world, h->pstat.p);
+                    // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them; for the
+                    // window's points (plist == nullptr) or for the ones a guessed threshold missed
+                    auto seeded_chain = [&](int n_pts, const int* plist) {
+                        // (k_seed holds two points per lane: point tiles of 128)
+                        hipLaunchKernelGGL((k_seed<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                           rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p, plist);
+                        hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * n_pts + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
+                                           rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
+                                           h->prune_F, round, mode, h->cmax.p, h->pstat.p, plist);
+                        // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
+                        // that every rank abandons against the same T -, phases A / B over the rank's own rows)
+                        hipLaunchKernelGGL((k_scan_p<DP, NW>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                           rows.scl, rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
+                                           h->part_stride, shard_rank, shard_world, h->pstat.p, plist, 0.0,
+                                           (unsigned long long*)nullptr);
+                    };
+                    if (h->guess_now && shard_world == 1) {
+                        // guessed thresholds: one scan, the list of the points it missed, the seeded chain for those
+                        // (list of the window's parity: the lookahead scan of the next window fills the other one)
+                        ++h->stats.scan_g_launches;
+                        int* const list = h->missed.p;  // (the kernels take the half of the window's parity)
+                        hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                           rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
+                                           h->part_stride, 0, 1, h->pstat.p, (const int*)nullptr, h->prune_F, h->found.p);
+                        hipLaunchKernelGGL(k_missed, dim3(1), dim3(1024), 0, st, h->ctl.p, h->found.p, list, CC_MISSED_CAP, round, mode);
+                        seeded_chain(CC_MISSED_CAP, list);
+                        return;
+                    }
+                    seeded_chain(win, nullptr);
                     return;
                 }
             }
@@ -700,7 +725,7 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
-        h->badflag.ensure(1);
+        h->badflag.ensure(4);
         memset(&h->hc, 0, sizeof(Ctl));
         h->tun.window = 32768;
         h->tun.rounds = 3;
@@ -731,6 +756,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
+        h->allow_guess = !(gs && gs[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
         if (sp && atoi(sp) >= 0) h->allow_sparse = atoi(sp);
         push_ctl(h);
@@ -900,6 +927,14 @@ static void prefetch_discard(cc_handle* h)
     h->pf.active = false;
 }
 
+// the largest |value| k_check_finite saw (words 2..3 of its flag buffer)
+static double absmax_of(const int* flag_words)
+{
+    double m;
+    memcpy(&m, flag_words + 2, 8);
+    return m;
+}
+
 static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, const double* scale, const double* mn)
 {
     int rc = set_dim(h, d);
@@ -917,10 +952,11 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
             h->lab_uid.ensure((size_t)n);
             h->lab_path.ensure((size_t)n);
             h->n_points = n;
-            if (pf.bad_host) {
+            if (pf.bad_host[0]) {
                 h->n_points = 0;
                 return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
             }
+            h->x_absmax = absmax_of(pf.bad_host);
             return (int)CC_OK;
         }
     }
@@ -931,7 +967,7 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     h->n_points = n;
     if (n == 0) return (int)CC_OK;
     HIPCHK(hipMemcpyAsync(h->X.p, x, (size_t)n * d * 8, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->badflag.p, 0, 16, h->stream));
     const long long tot = (long long)n * d;
     if (scale) {
         h->scr2.ensure((size_t)2 * d);
@@ -944,13 +980,14 @@ static int upload_points(cc_handle* h, const double* x, int64_t n, int32_t d, co
     hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, h->stream, h->X.p, tot, h->badflag.p);
     hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->X.p,
                        h->Xt.p, (long long)n, (int)d);
-    int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, h->badflag.p, 4, hipMemcpyDeviceToHost, h->stream));
+    int bad[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(bad, h->badflag.p, 16, hipMemcpyDeviceToHost, h->stream));
     sync_stream(h, h->stream);
-    if (bad) {
+    if (bad[0]) {
         h->n_points = 0;
         return fail(h, CC_ERR_NONFINITE, "input points contain NaN or Inf");
     }
+    h->x_absmax = absmax_of(bad);
     return (int)CC_OK;
 }
 
@@ -963,7 +1000,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
         pf.x = x; pf.n = n; pf.d = d; pf.scaled = scale != nullptr;
         pf.scale.assign(scale ? scale : x, scale ? scale + d : x);
         pf.mn.assign(min_ ? min_ : x, min_ ? min_ + d : x);
-        pf.rc = 0; pf.what = ""; pf.bad_host = 0;
+        pf.rc = 0; pf.what = ""; pf.bad_host[0] = pf.bad_host[1] = pf.bad_host[2] = pf.bad_host[3] = 0;
         if (!pf.stream) HIPCHK(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
         const size_t chunk = (size_t)16 << 20;
         if (pf.pin_bytes < chunk) {
@@ -974,7 +1011,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             pf.pin_bytes = chunk;
         }
-        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(1);
+        pf.X.ensure((size_t)n * d); pf.Xt.ensure((size_t)n * d); pf.sm.ensure((size_t)2 * d); pf.bad.ensure(4);
         pf.active = true;
         const int device = h->device;
         pf.worker = std::thread([&pf, device, chunk]() {
@@ -997,7 +1034,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
             }
             const long long tot = pf.n * (long long)pf.d;
             if (pf.rc == 0) {
-                chk(hipMemsetAsync(pf.bad.p, 0, 4, pf.stream), "hipMemsetAsync");
+                chk(hipMemsetAsync(pf.bad.p, 0, 16, pf.stream), "hipMemsetAsync");
                 if (pf.scaled) {
                     chk(hipMemcpyAsync(pf.sm.p, pf.scale.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
                     chk(hipMemcpyAsync(pf.sm.p + pf.d, pf.mn.data(), (size_t)pf.d * 8, hipMemcpyHostToDevice, pf.stream), "hipMemcpyAsync");
@@ -1008,7 +1045,7 @@ int cc_points_prefetch(cc_handle* h, const double* x, int64_t n, int32_t d, cons
                 hipLaunchKernelGGL(k_check_finite, dim3(blocks), dim3(256), 0, pf.stream, pf.X.p, tot, pf.bad.p);
                 hipLaunchKernelGGL(k_transpose_points, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, pf.stream, pf.X.p, pf.Xt.p,
                                    pf.n, pf.d);
-                chk(hipMemcpyAsync(&pf.bad_host, pf.bad.p, 4, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
+                chk(hipMemcpyAsync(pf.bad_host, pf.bad.p, 16, hipMemcpyDeviceToHost, pf.stream), "hipMemcpyAsync");
                 chk(hipGetLastError(), "kernel launch");
             }
             chk(hipStreamSynchronize(pf.stream), "hipStreamSynchronize");
@@ -1283,6 +1320,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         pcfg.d = h->d;
         pcfg.resume = resume ? 1 : 0;
         pcfg.allow_sparse = h->allow_sparse;
+        pcfg.allow_guess = h->allow_guess ? 1 : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.n_end = N;
         cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
@@ -1306,6 +1344,13 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         c.stat_seq_points = 0;
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
+        c.stat_missed = 0;
+        for (int q = 0; q < 2; ++q) {
+            c.n_missed[q] = 0;
+            for (int K = 0; K < 2; ++K) { c.tg[q][K] = 0.0; c.tg_ok[q][K] = 0; }
+        }
+        c.cen_absmax = 0ull;            // (k_rebuild_scl takes the table's maximum into it)
+        c.x_absmax = h->x_absmax;
         // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
         bool la_on = false;
         auto set_lookahead = [&](bool on) {
@@ -1334,8 +1379,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
         HIPCHK(hipMemsetAsync(h->pstat.p, 0, 4 * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(h->found.p, 0, h->found.n * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
-            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->tab.view(),
+            hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
         hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
@@ -1378,6 +1424,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         int Rcur = dec.rounds;             // validation rounds enqueued per window of the batch
         int batch_windows = dec.batch_windows;
         h->prune_now = dec.prune != 0;
+        h->guess_now = dec.prune == 2;
         nodirty = dec.nodirty != 0;
         bool sparse_now = dec.sparse != 0;  // with nodirty: sparse dirty scans for the round's list of points
         long long cursor_prev = range_a;
@@ -1605,7 +1652,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
-                                   h->rk.p, h->rec.p);
+                                   h->rk.p, h->rec.p, (const Cand*)h->clean.p, (const int8_t*)h->dpath.p);
                 hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
                                    h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
                 if (la_on) {
@@ -1644,6 +1691,8 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 o.stat_tiles = h->hc.stat_tiles;
                 o.stat_dirty_tiles = h->hc.stat_dirty_tiles;
                 o.stat_unsafe = h->hc.stat_unsafe;
+                o.stat_missed = h->hc.stat_missed;
+                o.tg_ok = (h->hc.tg_ok[0][0] != 0 && h->hc.tg_ok[1][0] != 0) ? 1 : 0;  // (a mean for the pcore kind in both slots)
                 for (int r = 0; r < CC_MAX_ROUNDS + 2; ++r) o.round_hist[r] = h->hc.round_hist[r];
                 o.prune_rows = h->hc.stat_prune_rows;
                 o.prune_full = h->hc.stat_prune_full;
@@ -1654,8 +1703,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 if (dec.stalled)
                     return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
                 if (h->trace && dec.prune_rows > 0)
-                    fprintf(stderr, "[cc] pruned scans of the batch (sample): %lld (wave, row) pairs, %.1f %% evaluated in full\n",
-                            (long long)dec.prune_rows, 100.0 * (double)dec.prune_full / (double)dec.prune_rows);
+                    fprintf(stderr, "[cc] pruned scans of the batch%s (sample): %lld (wave, row) pairs, %.1f %% evaluated in full; points missed by guessed thresholds so far: %lld\n",
+                            h->guess_now ? ", guessed thresholds" : "", (long long)dec.prune_rows,
+                            100.0 * (double)dec.prune_full / (double)dec.prune_rows, (long long)h->hc.stat_missed);
                 pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
                 if (h->prune_now) pair_rows_pruned += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
                 pair_rows_prev = h->hc.stat_pair_rows;
@@ -1666,6 +1716,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 sparse_now = dec.sparse != 0;
                 shard_on = dec.shard != 0;
                 h->prune_now = dec.prune != 0;
+                h->guess_now = dec.prune == 2;
                 if (dec.restart) {
                     h->hc.win_cfg = dec.win_cfg;
                     h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);
@@ -1727,6 +1778,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.long_chain_launches += long_launches;
         h->stats.tiles += h->hc.stat_tiles;
         h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
+        h->stats.missed_points += h->hc.stat_missed;
         if (timing) {
             double tot = 0.0, tot_p = 0.0;
             int64_t n_p = 0;

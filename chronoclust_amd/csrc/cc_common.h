@@ -204,6 +204,18 @@ struct Ctl {
     // the round's list of points for the sparse dirty scans (k_dseed fills it, k_chain of the round resets the count)
     int n_sparse;
     int pad2;
+    // Pruned snapshot scans with a table-wide threshold (k_scan_p, GUESS; cc_scan.h): tg[q][K] = mean snapshot distance of
+    // the points of an earlier window that joined a MC of kind K (k_commit_a of window V writes slot V & 1; the scan of
+    // window U reads slot U & 1, i.e. what window U - 2 left: no commit writes a slot while a scan may read it),
+    // tg_ok[q][K] = 1 once such a mean exists.  n_missed[q]: points of the window of parity q whose own MC the guessed
+    // threshold missed (k_missed lists them, the seeded chain then runs for them alone); coord_bound: bits of a double
+    // >= every |coordinate| of the resident points and of the table's centroids (k_check_finite / k_rebuild_scl).
+    double tg[2][2];
+    int tg_ok[2][2];
+    int n_missed[2];
+    unsigned long long cen_absmax;   // bits of the largest |centroid coordinate| in the table at the start of the call
+    double x_absmax;                 // the largest |coordinate| of the resident points (host, from the upload)
+    long long stat_missed;
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against
@@ -213,6 +225,7 @@ struct Ctl {
 //   2  pcore now, OUTLIER in the snapshot  (promoted since: hddstream.py:416-430) competes in the pcore list, but its
 //      snapshot distance is bounded through the point's OUTLIER list - its dsq is stored negated (see cc_dsq_class)
 // Rows without a bound (new microclusters, changed preferred dimensions) carry dsq = +inf in class 0 / 1.
+#define CC_MISSED_CAP 2048  // points per window the seeded chain may run for after a guessed-threshold scan (k_missed)
 #define CC_DSQ_STRIDE 4
 #define CC_TAU_STRIDE 4   // Versions::tau: thresholds of classes 0, 1, 2 per window point (+ 1 pad)
 // Versions::unsafe, per window point (k_dseed -> k_decide):

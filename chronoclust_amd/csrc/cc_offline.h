@@ -31,12 +31,21 @@ __global__ void k_downgrade_flags(Table tab, int m_rows, int d, double beta_mu, 
 }
 
 // scl column from pref (run before every online phase: covers injected rows and parameter changes)
-__global__ void k_rebuild_scl(Table tab, int m_rows, int d, int pow2, double inv_k)
+// ... and Ctl::cen_absmax, the largest |centroid coordinate| of the table as it is now (the host zeroes the word first)
+__global__ __launch_bounds__(256) void k_rebuild_scl(Ctl* __restrict__ ctl, Table tab, int m_rows, int d, int pow2, double inv_k)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= m_rows * d) return;
-    const double pr = tab.pref[e];
-    tab.scl[e] = pow2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
+    double a = 0.0;
+    if (e < m_rows * d) {
+        const double pr = tab.pref[e];
+        tab.scl[e] = pow2 ? (pr == 1.0 ? 1.0 : inv_k) : pr;
+        a = __builtin_fabs(tab.cen[e]);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(a, off);
+        a = o > a ? o : a;
+    }
+    if ((threadIdx.x & 63) == 0 && a > 0.0) atomicMax(&ctl->cen_absmax, (unsigned long long)__double_as_longlong(a));
 }
 
 // dst row i <- src row perm[i]; kind / key / id are rewritten from the host-computed lists

@@ -12,16 +12,31 @@ __global__ void k_transpose_points(const double* __restrict__ x, double* __restr
 }
 
 // NaN / Inf check of the uploaded points (cc_points_upload)
-__global__ void k_check_finite(const double* __restrict__ x, long long n, int* __restrict__ bad)
+// bad[0]: 1 if any value is NaN or Inf; bad[2..3] (one 64-bit word): bits of the largest |value| (Ctl::x_absmax: the
+// single-precision prefix of the pruned scans needs a bound on the magnitudes it converts)
+__global__ __launch_bounds__(256) void k_check_finite(const double* __restrict__ x, long long n, int* __restrict__ bad)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     int b = 0;
+    double m = 0.0;
     for (; i < n; i += stride) {
         const double v = x[i];
         b |= !(v - v == 0.0);
+        const double a = __builtin_fabs(v);
+        m = a > m ? a : m;  // (NaN never enters)
     }
     if (b) atomicOr(bad, 1);
+    __shared__ unsigned long long s_m;
+    if (threadIdx.x == 0) s_m = 0ull;
+    __syncthreads();
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(m, off);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_m, (unsigned long long)__double_as_longlong(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_m != 0ull) atomicMax(reinterpret_cast<unsigned long long*>(bad + 2), s_m);
 }
 
 // ---------------------------------------------------------------------------------

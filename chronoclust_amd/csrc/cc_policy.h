@@ -50,6 +50,8 @@ public:
         prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0;  // (independent of the split: k_scan_p takes a row range)
         prune_resume_at_ = 0;
         prune_backoff_ = 65536;
+        guess_on_ = false;
+        guess_resume_at_ = 0;
         stalled_ = 0;
         first_batch_ = true;
         prev_ = cc_policy_obs{};
@@ -181,6 +183,12 @@ public:
                                  (nodirty_ && prune_resume_at_ != std::numeric_limits<long long>::max()));
         const bool prune_flip = prune_next != prune_on_;
         prune_on_ = prune_next;
+        // Guessed thresholds (k_scan_p with Ctl::tg instead of k_seed + k_seed_merge, which cost as much as the scan they
+        // serve): while a mean join distance exists, the scan is not split over ranks (the list of missed points would
+        // have to be agreed on across them) and few points are missed - more than one in sixteen: back to seeds for 2^18 points
+        const long long missed = o.stat_missed - prev_.stat_missed;
+        if (guess_on_ && pts > 0 && missed * 16 > pts) guess_resume_at_ = o.cursor + (1ll << 18);
+        guess_on_ = prune_on_ && !shard_on_ && c_.allow_guess != 0 && o.tg_ok != 0 && o.cursor >= guess_resume_at_;
         const bool more = done < c_.n_end;
         const int restart = ((want != win_cfg_ || want_la != la_on_ || o.stall_b > 0 || shard_flip || prune_flip) && more) ? 1 : 0;
         if (restart) {
@@ -217,7 +225,7 @@ private:
         d.lookahead = la_on_ ? 1 : 0;
         d.nodirty = nodirty_ ? 1 : 0;
         d.sparse = sparse_ ? 1 : 0;
-        d.prune = prune_on_ ? 1 : 0;
+        d.prune = prune_on_ ? (guess_on_ ? 2 : 1) : 0;
         d.shard = shard_on_ ? 1 : 0;
         d.restart = restart;
         d.bad = bad;
@@ -230,6 +238,8 @@ private:
     cc_policy_obs prev_{};
     int win_cfg_ = 0, rcur_ = 0, batch_windows_ = 2, stalled_ = 0;
     long long prune_resume_at_ = 0, prune_backoff_ = 65536;  // pruned scans are tried again from this point on / stretch after the next failed try
+    long long guess_resume_at_ = 0;                          // guessed thresholds are tried again from this point on
+    bool guess_on_ = false;
     bool la_on_ = false, nodirty_ = false, sparse_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
 };
 

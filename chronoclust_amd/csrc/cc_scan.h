@@ -965,14 +965,17 @@ template <int DP, int NW>
 __global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
                                                    const double* __restrict__ g_cen, const int* __restrict__ g_kind,
                                                    SeedCand* __restrict__ spart, int round, int mode, size_t spart_stride,
-                                                   unsigned long long* __restrict__ cmax)
+                                                   unsigned long long* __restrict__ cmax, const int* __restrict__ plist)
 {
     static_assert(CC_PRE == 8 && CC_PRE <= DP, "prefix dimensions");
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
     const int j0 = (int)blockIdx.x * 128;
-    if (j0 >= B) return;
+    // (plist: not the window's points but the ones a guessed threshold missed, k_missed's list of the window's parity)
+    if (plist) plist += (size_t)win.q * CC_MISSED_CAP;
+    const int n_pts_here = plist ? ctl->n_missed[win.q] : B;
+    if (j0 >= n_pts_here) return;
     spart += (size_t)win.q * spart_stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -991,8 +994,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl
     cc_f2 p2[2][CC_PRE / 2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        jj[u] = j0 + u * 64 + lane;
-        valid[u] = jj[u] < B;
+        const int e = j0 + u * 64 + lane;
+        valid[u] = e < n_pts_here;
+        jj[u] = plist ? (valid[u] ? plist[e] : 0) : e;
         const double* xp = Xt + win.cursor + (valid[u] ? jj[u] : 0);
 #pragma unroll
         for (int i = 0; i < CC_PRE / 2; ++i)
@@ -1137,20 +1141,42 @@ __global__ __launch_bounds__(64 * NW, 4) void k_seed(const Ctl* __restrict__ ctl
 //     P >= sum s_i (|x_i| - e)^2 >= Q - 2 e sum s_i |x_i| >= Q - a sqrt(Q),   a = 2 e sqrt(8 smax),  Q = sum s_i x_i^2 >= smin sum x_i^2
 // (Cauchy-Schwarz), g(Q) = Q - a sqrt(Q) grows for sqrt(Q) > a / 2, so P > T follows from sqrt(Q) > u = (a + sqrt(a^2 + 4 T)) / 2.
 // The nine roundings of Qf (relative 2^-24 each, all terms >= 0) are covered by the factor 1 + 2^-19; T32 is rounded up.
+// T32 of a threshold T for a point whose prefix coordinates are at most pm in magnitude, the scanned rows' at most cmx
+// (derivation above k_seed_merge: exceeding T32 in single precision implies exceeding T exactly)
+__device__ __forceinline__ float cc_thr32(double T, double pm, double cmx, double inv_k)
+{
+    if (!(T < CC_INF)) return __builtin_inff();
+    const double e = 0x1p-21 * __builtin_fmax(pm, cmx);
+    const double smax = inv_k > 1.0 ? inv_k : 1.0, smin = inv_k < 1.0 ? inv_k : 1.0;
+    const double a = 2.0 * e * sqrt(8.0 * smax);
+    const double u = 0.5 * (a + sqrt(a * a + 4.0 * T)) * (1.0 + 0x1p-40);
+    // the kernel compares sum x^2 (without smin) with T32 = u^2 (1 + 2^-19) / smin
+    const double t64 = u * u * (1.0 + 0x1p-19) / smin * (1.0 + 0x1p-40);
+    float t32 = (float)t64;
+    if ((double)t32 < t64) t32 = __uint_as_float(__float_as_uint(t32) + 1u);  // (t32 >= 0 and finite here: the next float up)
+    return t32;
+}
+
 template <int DP>
 __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, const double* __restrict__ X,
                                                    const double* __restrict__ g_cen, const double* __restrict__ g_scl,
                                                    const SeedCand* __restrict__ spart, size_t spart_stride, int S,
                                                    double* __restrict__ thr, float* __restrict__ thr32, size_t thr_stride,
                                                    double F, int round, int mode, const unsigned long long* __restrict__ cmax,
-                                                   unsigned long long* __restrict__ pstat)
+                                                   unsigned long long* __restrict__ pstat, const int* __restrict__ plist)
 {
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = t >> 1, K = t & 1;
-    if (j >= win.B) return;
-    // the sample counters of this window's k_scan_p (split scans only: see there) start at zero
-    if (t < 2) pstat[win.q * 2 + t] = 0ull;
+    const int K = t & 1;
+    int j = t >> 1;
+    if (plist) {
+        if (win.B == 0 || j >= ctl->n_missed[win.q]) return;
+        j = plist[(size_t)win.q * CC_MISSED_CAP + j];
+    } else {
+        if (j >= win.B) return;
+        // the sample counters of this window's k_scan_p (split scans only: see there) start at zero
+        if (t < 2) pstat[win.q * 2 + t] = 0ull;
+    }
     constexpr int d = DP;  // (the pruned scan runs for d == DP only: every loop below unrolls, its loads go out together)
     spart += (size_t)win.q * spart_stride;
     thr += (size_t)win.q * thr_stride;
@@ -1196,22 +1222,9 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
         out = F * dmin;
     }
     thr[(size_t)j * 2 + K] = out;
-    float t32 = __builtin_inff();
-    if (out < CC_INF) {
-        double pm = 0.0;
-        for (int i = 0; i < CC_PRE; ++i) pm = __builtin_fmax(pm, __builtin_fabs(p[i]));
-        const double cmx = __longlong_as_double((long long)cmax[win.q]);
-        const double e = 0x1p-21 * __builtin_fmax(pm, cmx);
-        const double inv_k = ctl->inv_k;
-        const double smax = inv_k > 1.0 ? inv_k : 1.0, smin = inv_k < 1.0 ? inv_k : 1.0;
-        const double a = 2.0 * e * sqrt(8.0 * smax);
-        const double u = 0.5 * (a + sqrt(a * a + 4.0 * out)) * (1.0 + 0x1p-40);
-        // the kernel compares sum x^2 (without smin) with T32 = u^2 (1 + 2^-19) / smin
-        const double t64 = u * u * (1.0 + 0x1p-19) / smin * (1.0 + 0x1p-40);
-        t32 = (float)t64;
-        if ((double)t32 < t64) t32 = __uint_as_float(__float_as_uint(t32) + 1u);  // (t32 >= 0 and finite here: the next float up)
-    }
-    thr32[(size_t)j * 2 + K] = t32;
+    double pm = 0.0;
+    for (int i = 0; i < CC_PRE; ++i) pm = __builtin_fmax(pm, __builtin_fabs(p[i]));
+    thr32[(size_t)j * 2 + K] = cc_thr32(out, pm, __longlong_as_double((long long)cmax[win.q]), ctl->inv_k);
 }
 
 // Per wave and tile of 16 rows two phases:
@@ -1235,14 +1248,18 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
     const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride,
-    int shard_rank, int shard_world, unsigned long long* __restrict__ pstat)
+    int shard_rank, int shard_world, unsigned long long* __restrict__ pstat, const int* __restrict__ plist, double guess_F,
+    unsigned long long* __restrict__ found)
 {
     static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
     const int j0 = (int)blockIdx.x * 64;
-    if (j0 >= B) return;
+    // plist: the points a guessed threshold missed (k_missed's list of the window's parity) instead of the window's tiles
+    if (plist) plist += (size_t)win.q * CC_MISSED_CAP;
+    const int n_pts_here = plist ? ctl->n_missed[win.q] : B;
+    if (j0 >= n_pts_here) return;
     part += (size_t)win.q * part_stride;
     thr += (size_t)win.q * thr_stride;
     thr32 += (size_t)win.q * thr_stride;
@@ -1259,8 +1276,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     const int r0 = row_lo + sub * per;
     const int r1 = min(row_hi, r0 + per);
     const size_t n_pts = (size_t)ctl->xt_stride;
-    const int jj = j0 + lane;
-    const bool valid = jj < B;
+    const bool valid = j0 + lane < n_pts_here;
+    const int jj = plist ? (valid ? plist[j0 + lane] : 0) : j0 + lane;
 
     constexpr int TILE_BYTES = NW * CC_SCAN_TM * CC_PRE * 4;
     constexpr int MERGE_BYTES = (NW - 1) * 4 * 64 * (int)sizeof(Cand);
@@ -1280,10 +1297,31 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // a point keep no row alive
     double th[2], lb[2] = {CC_INF, CC_INF};
     float th32[2];
+    // found != nullptr: GUESSED thresholds - not F x the point's own seed distance (k_seed, k_seed_merge: as much work
+    // again as this kernel) but F x the mean distance at which the points of an earlier window joined a MC of the
+    // kind (Ctl::tg).  Any threshold is a valid one: what falls under it is evaluated exactly, what is abandoned is
+    // bounded by it.  A point whose own MC lies beyond the guess ends with a bound in first place; the wave that does
+    // find a pcore MC within the threshold marks its points in `found`, k_missed lists the unmarked ones and the seeded
+    // chain runs for them alone (plist).  No mean for the kind yet: +inf, every row of the kind is evaluated.
+    const bool guessed = found != nullptr;
+    if (guessed) {
+        double pm = 0.0;
 #pragma unroll
-    for (int K = 0; K < 2; ++K) {
-        th[K] = valid ? thr[(size_t)jj * 2 + K] : -CC_INF;
-        th32[K] = valid ? thr32[(size_t)jj * 2 + K] : -__builtin_inff();
+        for (int i = 0; i < CC_PRE; ++i) pm = __builtin_fmax(pm, __builtin_fabs(p[i]));
+        const double cmx = __builtin_fmax(ctl->x_absmax, __longlong_as_double((long long)ctl->cen_absmax));
+        const double inv_k = ctl->inv_k;
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            const double T = (ctl->tg_ok[win.q][K] != 0) ? guess_F * ctl->tg[win.q][K] : CC_INF;
+            th[K] = valid ? T : -CC_INF;
+            th32[K] = valid ? cc_thr32(T, pm, cmx, inv_k) : -__builtin_inff();
+        }
+    } else {
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            th[K] = valid ? thr[(size_t)jj * 2 + K] : -CC_INF;
+            th32[K] = valid ? thr32[(size_t)jj * 2 + K] : -__builtin_inff();
+        }
     }
     bool dropped[2] = {false, false};  // (wave-uniform) phase A abandoned a row of the kind: every lane's bound is its T
     double bd[2][2];
@@ -1416,6 +1454,11 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // recorded of them
     if (dropped[0]) lb[0] = cc_vmin(lb[0], th[0]);
     if (dropped[1]) lb[1] = cc_vmin(lb[1], th[1]);
+    if (guessed) {
+        // the points for which this wave evaluated a pcore MC within the guessed threshold: their pcore list's best is exact
+        const unsigned long long fm = __builtin_amdgcn_ballot_w64(valid && bs[0][0] >= 0 && bd[0][0] <= th[0]);
+        if (lane == 0 && fm != 0ull) atomicOr(found + (size_t)win.q * (CC_MAX_WINDOW / 64) + blockIdx.x, fm);
+    }
     // statistics for the host's policy: a sample - the waves of the window's first point tile (atomics of every wave on
     // one address serialise: 30 000 of them cost more than the scan)
     // A split scan's sample describes this rank's rows only, and the host policy that reads the counters has to decide
@@ -1459,6 +1502,70 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     }
     Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// ---------------------------------------------------------------------------------
+// k_missed: after a snapshot scan with guessed thresholds - the window points no wave found a pcore MC for (their own MC
+// lies beyond the guess, or they have none), in point order, for the seeded chain that follows (k_seed / k_seed_merge /
+// k_scan_p over `list`).  One workgroup; the marks are cleared for the window's next use of them.  A list that would
+// exceed `cap` is cut: the points beyond it keep a bound in first place and k_decide refuses them.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_missed(Ctl* __restrict__ ctl, unsigned long long* __restrict__ found,
+                                                 int* __restrict__ list, int cap, int round, int mode)
+{
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    if (win.B == 0) return;  // (mode 0 and the window was scanned ahead: that scan's list stands)
+    found += (size_t)win.q * (CC_MAX_WINDOW / 64);
+    list += (size_t)win.q * CC_MISSED_CAP;
+    const int tiles = (win.B + 63) / 64;
+    const int tid = threadIdx.x;
+    constexpr int PER = (CC_MAX_WINDOW / 64 + 1023) / 1024;  // tiles per thread
+    unsigned long long miss[PER];
+    int mine = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int t = tid * PER + q;
+        miss[q] = 0ull;
+        if (t < tiles) {
+            const int left = win.B - t * 64;
+            const unsigned long long all = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            miss[q] = ~found[t] & all;
+            found[t] = 0ull;
+            mine += __builtin_popcountll(miss[q]);
+        }
+    }
+    __shared__ int wsum[16];
+    __shared__ int total;
+    int v = mine;
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[wid] = v;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 16; ++i) { const int x = wsum[i]; wsum[i] = run; run += x; }
+        total = run;
+    }
+    __syncthreads();
+    int pos = v - mine + wsum[wid];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        unsigned long long m = miss[q];
+        const int t = tid * PER + q;
+        while (m != 0ull) {
+            const int b = __builtin_ctzll(m);
+            m &= m - 1ull;
+            if (pos < cap) list[pos] = t * 64 + b;
+            ++pos;
+        }
+    }
+    if (tid == 0) {
+        ctl->n_missed[win.q] = total < cap ? total : cap;
+        ctl->stat_missed += total;
+    }
 }
 
 // ---------------------------------------------------------------------------------

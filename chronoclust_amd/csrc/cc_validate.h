@@ -194,7 +194,10 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     const double* p = X + (ctl->cursor + j) * d;
     Cand first0 = Cand{CC_INF, CC_IDX_INF, -1}, first1 = Cand{CC_INF, CC_IDX_INF, -1};
     double cap[2] = {CC_INF, CC_INF};
-    bool provable = par.k > 0.0;  // false: some live version of a list MC could not be located -> no pruning
+    // per candidate list (0 pcore, 1 outlier): lk_ok - the live versions of its entries were located; lbound - its first
+    // place is a bound (a pruned scan whose threshold lay below every row of the kind: nothing is known of the list but
+    // that bound, k_decide refuses the point if it has to evaluate that stage)
+    bool lk_ok[2] = {par.k > 0.0, par.k > 0.0}, lbound[2] = {false, false};
     // Ratio of a dimension's weight before / after, for the rows the threshold below is applied to: 1.  A version whose
     // preferred dimensions differ from its MC's at window start carries no bound (k_chain, k_chain_long, k_commit_b give
     // it dsq = +inf like a new or promoted MC), so every bounded row has the window-start metric itself and the bound is
@@ -219,7 +222,9 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
         // needed of d2 below is that no MC outside the list was closer than it at window start)
         if (cq[kd * 2 + 1].slot != -1) d2v[kd] = cq[kd * 2 + 1].dist;
         have1[kd] = cq[kd * 2].slot >= 0;  // no snapshot candidate of this kind: cap stays +inf
-        if (cq[kd * 2].slot == CC_SLOT_BOUND) provable = false;  // (never left in first place; k_decide refuses the point)
+        // a bound in FIRST place (guessed thresholds, k_scan_p): every row of the kind is at least that far
+        lbound[kd] = cq[kd * 2].slot == CC_SLOT_BOUND;
+        if (lbound[kd]) d2v[kd] = cq[kd * 2].dist;
         look[kd * 2] = have1[kd];
         look[kd * 2 + 1] = have1[kd] && cq[kd * 2 + 1].slot >= 0;
     }
@@ -326,9 +331,9 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
         if (v1 == -1) cap[kd] = cq[kd * 2].dist;  // c1 is clean at j: a live version has to beat c1 itself
         else {
             cap[kd] = d2v[kd];
-            if (v1 < 0) provable = false;
+            if (v1 < 0) lk_ok[kd] = false;
         }
-        if (look[kd * 2 + 1] && lv[kd * 2 + 1] == -2) provable = false;
+        if (look[kd * 2 + 1] && lv[kd * 2 + 1] == -2) lk_ok[kd] = false;
     }
     // step 3: kind and key of the (up to four) version rows; step 4: their exact distances to point j, four
     // dimensions of all rows per pass, every sum left to right
@@ -423,7 +428,9 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
             // (d2 = +inf: the snapshot held no other MC of that kind; cap = +inf: nothing to beat yet - every row matters)
             t = (d2v[from] == CC_INF) ? CC_INF : (sqrt(d2v[from]) - sqrt(K * ce));
         }
-        if (!provable) t = -CC_INF;
+        // no threshold for a list that is only a bound or whose entries' live versions were not all found; the promoted
+        // rows' bound also rests on the outlier list's entries being seeded
+        if (!lk_ok[list] || lbound[list] || (kd == 2 && !lk_ok[1])) t = -CC_INF;
         t = (t == CC_INF) ? CC_INF : t * (1.0 - 1e-9) - 1e-290;  // margin for the rounding of all of the above
         tau[kd] = t;
     }
@@ -439,7 +446,7 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     if (la_mode && !cc_dsq_below(maxd_car[1], tau[1])) flags |= CC_FLAG_C1;
     need_ver = (need0 && (flags & CC_FLAG_U0)) || (need1 && (flags & CC_FLAG_U1));
     need_car = (need0 && (flags & CC_FLAG_C0)) || (need1 && (flags & CC_FLAG_C1));
-    flag_unprov = !provable;
+    flag_unprov = !(lk_ok[0] && lk_ok[1]);
     flag_unsafe = need_ver || need_car;
     // (a point that goes on the sparse list keeps its real thresholds: its scans cover both kinds)
     flag_n1skip = !need1;
@@ -1434,7 +1441,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
 
 __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table tab, Versions ver, Carry car,
                                                    const int* __restrict__ Tbuf0, const int* __restrict__ Tbuf1,
-                                                   int* __restrict__ rk, CommitRec* __restrict__ rec)
+                                                   int* __restrict__ rk, CommitRec* __restrict__ rec,
+                                                   const Cand* __restrict__ clean, const int8_t* __restrict__ dpath)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1521,7 +1529,40 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
                        ctl->la_cursor[qn] == next_cursor;
     if (la_ok)
         for (int i = tid; i < CC_DSQ_STRIDE * ((B + 15) / 16 + 1); i += 1024) car.tile_dsq[i] = 0ull;  // k_commit_b takes maxima into them
+    // Ctl::tg - the mean snapshot distance at which the committed points joined a MC of either kind: what a later
+    // window's pruned scan takes its guessed thresholds from (k_scan_p).  Slot = parity of this window; a window without
+    // such points passes on what the previous one left.
+    __shared__ double s_sum[2][16];
+    __shared__ int s_cnt[2][16];
+    {
+        double sm[2] = {0.0, 0.0};
+        int cn[2] = {0, 0};
+        for (int j = tid; j < n; j += 1024) {
+            const int pth = dpath[j];
+            if (T[j] >= 0 && (pth == 0 || pth == 1)) {
+                const double dist = clean[(size_t)j * 4 + pth * 2].dist;
+                if (dist < CC_INF) { sm[pth] += dist; cn[pth] += 1; }
+            }
+        }
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            for (int off = 32; off >= 1; off >>= 1) {
+                sm[K] += __shfl_xor(sm[K], off);
+                cn[K] += __shfl_xor(cn[K], off);
+            }
+            if ((tid & 63) == 0) { s_sum[K][tid >> 6] = sm[K]; s_cnt[K][tid >> 6] = cn[K]; }
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
+        const int slot = (int)(seq & 1ull);
+        for (int K = 0; K < 2; ++K) {
+            double sm = 0.0;
+            int cn = 0;
+            for (int i = 0; i < 16; ++i) { sm += s_sum[K][i]; cn += s_cnt[K][i]; }
+            if (cn > 0) { ctl->tg[slot][K] = sm / (double)cn; ctl->tg_ok[slot][K] = 1; }
+            else { ctl->tg[slot][K] = ctl->tg[slot ^ 1][K]; ctl->tg_ok[slot][K] = ctl->tg_ok[slot ^ 1][K]; }
+        }
         rec->n = n; rec->M0 = M0; rec->pk0 = pk0; rec->ok0 = ok0; rec->pid0 = pid0; rec->oid0 = oid0; rec->T = T;
         rec->carry = la_ok ? 1 : 0;
         rec->cursor = cursor;

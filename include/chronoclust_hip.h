@@ -121,6 +121,8 @@ typedef struct cc_stats {
     int64_t scan_launches_pruned;  /* of scan_launches: the timed launches that were pruned chains ...       */
     double  scan_ms_pruned;        /* ... their share of scan_ms ...                                          */
     double  scan_pair_dims_pruned; /* ... and of scan_pair_dims (the rest: plain scans)                       */
+    int64_t scan_g_launches;       /* of scan_p_launches: with guessed thresholds (no seed pass over the window) */
+    int64_t missed_points;         /* ... points those scans missed (the seeded chain ran for them alone)        */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -320,6 +322,8 @@ typedef struct cc_policy_config {
     int32_t d;
     int32_t resume;            /* the call continues a stream this handle was clustering a moment ago              */
     int32_t allow_sparse;      /* sparse dirty scans while at most one point in this many needs them (0: never)     */
+    int32_t allow_guess;       /* pruned scans may take table-wide guessed thresholds (CHRONOCLUST_HIP_GUESS != 0)    */
+    int32_t pad;
     int64_t shard_min_row_dims;
     int64_t n_end;             /* end of the range of points the call clusters                                     */
 } cc_policy_config;
@@ -331,14 +335,18 @@ typedef struct cc_policy_obs {   /* cumulative device counters of the call as re
     int32_t m_rows, stall_b;
     int64_t stat_windows, stat_truncated, stat_trunc_unknown, stat_tiles, stat_dirty_tiles;
     int64_t stat_unsafe;       /* (point, round) pairs that needed rows only a dirty scan covers                  */
+    int64_t stat_missed;       /* points a guessed threshold missed (the seeded chain ran for them)               */
     int64_t round_hist[CC_POLICY_MAX_ROUNDS + 2];
     uint64_t prune_rows, prune_full;
-    int32_t after_sequential, pad;
+    int32_t after_sequential;
+    int32_t tg_ok;             /* a mean join distance exists: guessed thresholds are available                   */
 } cc_policy_obs;
 typedef struct cc_policy_decision {
     int32_t win_cfg;        /* window size of the next batch (changes only with `restart`)                         */
     int32_t want;           /* the size the policy is heading for                                                  */
-    int32_t rounds, batch_windows, lookahead, nodirty, prune, shard;
+    int32_t rounds, batch_windows, lookahead, nodirty;
+    int32_t prune;          /* 0: plain scans, 1: pruned with seeded thresholds, 2: pruned with guessed thresholds   */
+    int32_t shard;
     int32_t restart;        /* the chain of windows restarts: pending lookahead scan dropped, control block pushed */
     int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
     int32_t stalled;        /* three batches without progress: the call fails with CC_ERR_INTERNAL                 */
