@@ -1608,7 +1608,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                 hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                    dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                    h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail);
+                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0);
                 if (scan_rows > 0)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
                 for (int r = 1; r <= Rcur; ++r) {
@@ -1647,8 +1647,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                     }
                     hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                        dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
-                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1);
-                    if (scan_rows > 0)
+                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
+                                       r == Rcur ? 1 : 0);
+                    // (the claims of the last round are not replayed: nothing to gather either)
+                    if (scan_rows > 0 && r < Rcur)
                         hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
                 hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
-                                                int* __restrict__ long_list, int long_cap, int stat_tail)
+                                                int* __restrict__ long_list, int long_cap, int stat_tail, int last_round)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -778,7 +778,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 2] = 0ull;
         }
         // (claims on the first scan_rows table rows are gathered by k_claims instead, without atomics)
-        if (T >= 0 && !(T < M0 && T < scan_rows)) {
+        // Nobody replays the claims of the last round the host enqueued for this window - no k_chain follows it, the
+        // commit reads the claims themselves -, so they are not registered: three atomics per point saved, and the ones
+        // that serialise when a population takes a large share of the events (one address per MC)
+        if (last_round == 0 && T >= 0 && !(T < M0 && T < scan_rows)) {
             // first / last point of this window that targets T, for the round that replays these claims
             // (provisional ids of new MCs index the free rows behind the table)
             const unsigned long long sn = (stamp + 1ull) << 20;
