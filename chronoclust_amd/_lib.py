@@ -40,7 +40,7 @@ class CcStats(C.Structure):
                 ("window", C.c_int64), ("long_chains", C.c_int64), ("long_chain_launches", C.c_int64),
                 ("tiles", C.c_int64), ("dirty_tiles", C.c_int64),
                 ("scan_launches_pruned", C.c_int64), ("scan_ms_pruned", C.c_double), ("scan_pair_dims_pruned", C.c_double),
-                ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64)]
+                ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64), ("probe_launches", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -49,7 +49,7 @@ POLICY_MAX_ROUNDS = 8
 class CcPolicyConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
-                                         "allow_sparse", "allow_guess", "pad")] + \
+                                         "allow_sparse", "allow_guess", "allow_probe")] + \
                [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
 
 
@@ -67,7 +67,7 @@ class CcPolicyObs(C.Structure):
 
 class CcPolicyDecision(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune",
-                                         "shard", "restart", "bad", "stalled", "sparse")] + \
+                                         "shard", "restart", "bad", "stalled", "sparse", "probe", "pad")] + \
                [(k, C.c_int64) for k in ("wins", "pts", "trunc", "unk", "tiles", "dtiles", "grew", "prune_rows", "prune_full")]
 
 

@@ -132,7 +132,10 @@ struct cc_handle {
     double prune_F = 16.0;
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
     bool guess_now = false;   // ... with guessed thresholds (k_scan_p + k_missed + the seeded chain for the missed points)
+    bool probe_now = false;   // the next plain scan also runs the pruned chain on 128 points (cc_policy_decision::probe)
+    DevBuf<Cand> probe_part;  // ... into these scratch partials
     bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
+    bool allow_probe = true;  // CHRONOCLUST_HIP_PROBE=0: pruned scans are retried blindly after a stretch of points
     DevBuf<unsigned long long> found;  // [2][CC_MAX_WINDOW / 64] per point tile: the points a guessed-threshold scan found a pcore MC for
     DevBuf<int> missed;                // [2][CC_MISSED_CAP] the others, listed by k_missed (two window parities)
     double x_absmax = 0.0;             // the largest |coordinate| of the resident points (k_check_finite)
@@ -260,8 +263,8 @@ struct PolicyTrace {
     static void dec_json(FILE* f, const cc_policy_decision& d)
     {
         fprintf(f, "{\"win_cfg\": %d, \"want\": %d, \"rounds\": %d, \"batch_windows\": %d, \"lookahead\": %d, \"nodirty\": %d, "
-                   "\"prune\": %d, \"shard\": %d, \"restart\": %d, \"bad\": %d, \"stalled\": %d, \"sparse\": %d}",
-                d.win_cfg, d.want, d.rounds, d.batch_windows, d.lookahead, d.nodirty, d.prune, d.shard, d.restart, d.bad, d.stalled, d.sparse);
+                   "\"prune\": %d, \"shard\": %d, \"restart\": %d, \"bad\": %d, \"stalled\": %d, \"sparse\": %d, \"probe\": %d}",
+                d.win_cfg, d.want, d.rounds, d.batch_windows, d.lookahead, d.nodirty, d.prune, d.shard, d.restart, d.bad, d.stalled, d.sparse, d.probe);
     }
     // rank >= 0: the handle is rank `rank` of a group and writes <file>.rank<rank>
     PolicyTrace(const cc_policy_config& c, const cc_policy_carry& k, long long cursor, int rows, const cc_policy_decision& d0,
@@ -274,9 +277,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, (long long)c.shard_min_row_dims, (long long)c.n_end,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -519,11 +522,9 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
         if (scan_u_applies(h, DP)) {
             ++h->stats.scan_u_launches;
             if constexpr (DP > 8) {
-                if (h->prune_now) {
-                    ++h->stats.scan_p_launches;
-                    // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them; for the
-                    // window's points (plist == nullptr) or for the ones a guessed threshold missed
-                    auto seeded_chain = [&](int n_pts, const int* plist) {
+                // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them; for the
+                // window's points (plist == nullptr) or for the ones a guessed threshold missed
+                auto seeded_chain = [&](int n_pts, const int* plist, Cand* part, size_t part_stride, int S) {
                         // (k_seed holds two points per lane: point tiles of 128)
                         hipLaunchKernelGGL((k_seed<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                            rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p, plist);
@@ -534,9 +535,11 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         // that every rank abandons against the same T -, phases A / B over the rank's own rows)
                         hipLaunchKernelGGL((k_scan_p<DP, NW>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                            rows.scl, rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           h->part_stride, shard_rank, shard_world, h->pstat.p, plist, 0.0,
+                                           part_stride, shard_rank, shard_world, h->pstat.p, plist, 0.0,
                                            (unsigned long long*)nullptr);
-                    };
+                };
+                if (h->prune_now) {
+                    ++h->stats.scan_p_launches;
                     if (h->guess_now && shard_world == 1) {
                         // guessed thresholds: one scan, the list of the points it missed, the seeded chain for those
                         // (list of the window's parity: the lookahead scan of the next window fills the other one)
@@ -546,12 +549,28 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                            rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
                                            h->part_stride, 0, 1, h->pstat.p, (const int*)nullptr, h->prune_F, h->found.p);
                         hipLaunchKernelGGL(k_missed, dim3(1), dim3(1024), 0, st, h->ctl.p, h->found.p, list, CC_MISSED_CAP, round, mode);
-                        seeded_chain(CC_MISSED_CAP, list);
+                        seeded_chain(CC_MISSED_CAP, list, part, h->part_stride, S);
                         return;
                     }
-                    seeded_chain(win, nullptr);
+                    seeded_chain(win, nullptr, part, h->part_stride, S);
                     return;
                 }
+                hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
+                                   rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
+                if (h->probe_now) {
+                    // the probe: the pruned chain on the window's first 128 points, over all rows, into scratch partials -
+                    // only its sample of completed rows (Ctl::stat_prune_*) is used, by the window policy
+                    ++h->stats.probe_launches;
+                    const int keep_rank = shard_rank, keep_world = shard_world;
+                    shard_rank = 0; shard_world = 1;  // (the whole table on every rank: the same sample everywhere)
+                    // (few points, so many sub-ranges of rows: while the table fills most rows are completed, at the
+                    // latency of scalar loads - 128 workgroups per point tile keep that to a hundred rows per wave)
+                    const int Sp = (int)std::max<size_t>(1, std::min<size_t>(128, h->spart_stride / 2 / 128));  // (what the seed buffer holds for 128 points)
+                    h->probe_part.ensure((size_t)2 * 128 * Sp * 4);
+                    seeded_chain(std::min(win, 128), nullptr, h->probe_part.p, (size_t)128 * Sp * 4, Sp);
+                    shard_rank = keep_rank; shard_world = keep_world;
+                }
+                return;
             }
             hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
@@ -756,6 +775,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* pb = getenv("CHRONOCLUST_HIP_PROBE");
+        h->allow_probe = !(pb && pb[0] == '0');
         const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
         h->allow_guess = !(gs && gs[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
@@ -1321,6 +1342,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         pcfg.resume = resume ? 1 : 0;
         pcfg.allow_sparse = h->allow_sparse;
         pcfg.allow_guess = h->allow_guess ? 1 : 0;
+        pcfg.allow_probe = h->allow_probe ? 1 : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.n_end = N;
         cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
@@ -1542,10 +1564,13 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
                                 scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
             if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
+            int probe_left = (dec.probe != 0) ? 1 : 0;
             for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
                 hipEvent_t scan_end = nullptr;  // the event recorded right behind the last timed scan (nothing after it yet)
                 auto timed_scan = [&](hipStream_t st, int mode, int round) {
                     const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
+                    h->probe_now = probe_left > 0 && !h->prune_now;  // (the batch's first scan carries the probe)
+                    if (h->probe_now) --probe_left;
                     const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
                     scan_end = nullptr;
                     if (timing) {
@@ -1781,6 +1806,7 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         h->stats.tiles += h->hc.stat_tiles;
         h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
         h->stats.missed_points += h->hc.stat_missed;
+        h->probe_now = false;
         if (timing) {
             double tot = 0.0, tot_p = 0.0;
             int64_t n_p = 0;

@@ -57,7 +57,10 @@ public:
         prev_ = cc_policy_obs{};
         prev_.cursor = cursor;
         prev_.m_rows = m_rows;
-        return decision(0, 0);
+        probe_ok_ = false;
+        cc_policy_decision d0 = decision(0, 0);
+        prev_probe_ = d0.probe != 0;
+        return d0;
     }
 
     // the stream comes back from the sequential kernel: a fresh window at the cursor, dirty scans launched again, no
@@ -91,6 +94,7 @@ public:
             if (pr > 0 && pfu * 12 > pr) {
                 prune_resume_at_ = o.cursor + prune_backoff_;
                 prune_backoff_ = std::min<long long>(1ll << 20, prune_backoff_ * 2);
+                probe_ok_ = false;
             } else if (pr > 0) prune_backoff_ = 65536;
             // a window that commits nothing although its first point is always decidable: cannot happen with exact
             // first candidates - should it, the plain scan takes over for good
@@ -175,14 +179,23 @@ public:
         const bool shard_next = policy_want_shard(c_, o.m_rows);
         const bool shard_flip = shard_next != shard_on_;
         shard_on_ = shard_next;
+        // While plain scans run, the batch's first window also runs the pruned chain on 128 of its points (a probe: its
+        // results are not used, its sample is): pruned scans come back as soon as the probe says they would pay, instead
+        // of being tried on whole batches that cost twice the plain scan when they fail.
+        if (!prune_on_ && pr > 0) probe_ok_ = pfu * 12 <= pr;
+        const bool probing = c_.prune_applicable != 0 && c_.prune_mode == 1 && !prune_on_ && prev_probe_;
+        const bool blind = c_.allow_probe == 0 && o.cursor >= prune_resume_at_;  // (the round-3 rule: try again after a stretch)
         const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 &&
                                 ((c_.prune_mode == 2 && prune_resume_at_ != std::numeric_limits<long long>::max()) ||
-                                 o.cursor >= prune_resume_at_ ||
+                                 // on: stays on until a batch completes too many rows (prune_resume_at_ moves ahead of the
+                                 // cursor); off: comes back on a probe's word - no blind tries on whole batches
+                                 (prune_on_ ? o.cursor >= prune_resume_at_ : ((probing && probe_ok_) || blind)) ||
                                  // a settled stream (no tile needed its dirty scan: nothing created, promoted or moved far)
                                  // is where pruned scans pay: tried at once, whatever the earlier tries said
                                  (nodirty_ && prune_resume_at_ != std::numeric_limits<long long>::max()));
         const bool prune_flip = prune_next != prune_on_;
         prune_on_ = prune_next;
+        probe_gate_ = grew == 0 && !unpruned && want >= std::min(8192, c_.window);
         // Guessed thresholds (k_scan_p with Ctl::tg instead of k_seed + k_seed_merge, which cost as much as the scan they
         // serve): while a mean join distance exists, the scan is not split over ranks (the list of missed points would
         // have to be agreed on across them) and few points are missed - more than one in sixteen: back to seeds for 2^18 points
@@ -205,6 +218,7 @@ public:
         const int bad = (trunc_batch > 0 && trunc_batch * 4 >= wins && want <= 1024) ? 1 : 0;
         prev_ = o;
         cc_policy_decision d = decision(restart, bad);
+        prev_probe_ = d.probe != 0;
         d.want = want;
         d.wins = wins; d.pts = pts; d.trunc = trunc_batch; d.unk = unk_batch; d.tiles = tiles; d.dtiles = dtiles; d.grew = grew;
         d.prune_rows = (long long)pr; d.prune_full = (long long)pfu;
@@ -225,6 +239,10 @@ private:
         d.lookahead = la_on_ ? 1 : 0;
         d.nodirty = nodirty_ ? 1 : 0;
         d.sparse = sparse_ ? 1 : 0;
+        // (no probe while the table still grows, most tiles need their dirty scans or the windows are held short: pruned
+        // scans cannot pay yet, and on short windows even the probe's three small launches are a few per cent of a batch)
+        d.probe = (c_.allow_probe != 0 && c_.prune_applicable != 0 && c_.prune_mode == 1 && !prune_on_ && probe_gate_ &&
+                   prune_resume_at_ != std::numeric_limits<long long>::max()) ? 1 : 0;
         d.prune = prune_on_ ? (guess_on_ ? 2 : 1) : 0;
         d.shard = shard_on_ ? 1 : 0;
         d.restart = restart;
@@ -240,6 +258,9 @@ private:
     long long prune_resume_at_ = 0, prune_backoff_ = 65536;  // pruned scans are tried again from this point on / stretch after the next failed try
     long long guess_resume_at_ = 0;                          // guessed thresholds are tried again from this point on
     bool guess_on_ = false;
+    bool probe_ok_ = false;    // the last probe of the pruned chain completed few rows: pruned scans would pay
+    bool prev_probe_ = false;  // the batch that just ran carried a probe
+    bool probe_gate_ = false;  // the last batch's table did not grow and most of its tiles were clean: a probe is worth its cost
     bool la_on_ = false, nodirty_ = false, sparse_ = false, shard_on_ = false, prune_on_ = false, first_batch_ = true;
 };
 

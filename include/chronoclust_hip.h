@@ -123,6 +123,7 @@ typedef struct cc_stats {
     double  scan_pair_dims_pruned; /* ... and of scan_pair_dims (the rest: plain scans)                       */
     int64_t scan_g_launches;       /* of scan_p_launches: with guessed thresholds (no seed pass over the window) */
     int64_t missed_points;         /* ... points those scans missed (the seeded chain ran for them alone)        */
+    int64_t probe_launches;        /* plain scans that carried a probe of the pruned chain (128 points)          */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -323,7 +324,8 @@ typedef struct cc_policy_config {
     int32_t resume;            /* the call continues a stream this handle was clustering a moment ago              */
     int32_t allow_sparse;      /* sparse dirty scans while at most one point in this many needs them (0: never)     */
     int32_t allow_guess;       /* pruned scans may take table-wide guessed thresholds (CHRONOCLUST_HIP_GUESS != 0)    */
-    int32_t pad;
+    int32_t allow_probe;       /* pruned scans come back on a probe's word (CHRONOCLUST_HIP_PROBE != 0), else after a
+                                * stretch of points that doubles with every failed try                               */
     int64_t shard_min_row_dims;
     int64_t n_end;             /* end of the range of points the call clusters                                     */
 } cc_policy_config;
@@ -351,6 +353,9 @@ typedef struct cc_policy_decision {
     int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
     int32_t stalled;        /* three batches without progress: the call fails with CC_ERR_INTERNAL                 */
     int32_t sparse;         /* with nodirty: the sparse dirty scans run for the points that need rows of their own  */
+    int32_t probe;          /* plain scans, and the pruned chain runs beside the batch's first one on 128 points: its
+                             * sample tells the policy whether pruned scans would pay, at 1 / 256 of a scan's cost    */
+    int32_t pad;
     int64_t wins, pts, trunc, unk, tiles, dtiles, grew, prune_rows, prune_full;  /* what the batch did (deltas)     */
 } cc_policy_decision;
 int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,

@@ -158,7 +158,10 @@ def test_default_policy_uses_it_in_the_steady_state_and_not_while_microclusters_
     _same_state(auto, plain)
     s = auto.stats()
     assert 0 < s["scan_p_launches"] < s["scan_u_launches"]  # (scan_u_launches counts both kinds of launch)
-    assert s["pruned_scan_full_rows"] < 0.2 * s["pruned_scan_rows"]
+    # while the table filled, plain scans ran and probes of the pruned chain (128 points of a batch's first window) told
+    # the policy when pruned scans would start to pay
+    assert s["probe_launches"] > 0 and s["scan_g_launches"] > 0
+    assert s["pruned_scan_full_rows"] < 0.5 * s["pruned_scan_rows"]  # (the sample includes the probes of the start-up phase)
 
 
 def _fuzz_case(seed):
@@ -208,3 +211,35 @@ def test_forced_pruning_fuzz(seed):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
         _against_oracle(h, o)
+
+
+def test_guessed_thresholds_miss_a_loose_population():
+    """Guessed thresholds (F x the mean distance at which earlier points joined their microclusters) suit the tight
+    populations of this stream and miss the loose ones: those points go through k_missed and the seeded chain - more of
+    them per window than the list holds at times, the rest are refused and the windows commit short.  The oracle's
+    results all the same, and the same results with the guesses switched off."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(31)
+    n, d, g = 60_000, 20, 300
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    sig = np.where(np.arange(g) < 240, 0.004, 0.03)  # 60 loose populations: their points lie 50 x farther from their centroids
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.25))
+    o = O.OracleHDDStream(cfg)
+    guess = _hdd(cfg, 1, window=8192)
+    with _env(CHRONOCLUST_HIP_GUESS=0):
+        seeded = _hdd(cfg, 1, window=8192)
+    missed = guessed = 0
+    for t in range(3):
+        lab = rng.integers(0, g, n)
+        X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 1.0, (n, d)) * sig[lab, None], 0.0, 1.0))
+        for h in (guess, seeded):
+            h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _against_oracle(guess, o)
+        _same_state(guess, seeded)
+        s = guess.stats()
+        missed += s["missed_points"]
+        guessed += s["scan_g_launches"]
+        assert seeded.stats()["scan_g_launches"] == 0
+    assert guessed > 0 and missed > 0
+    print("guessed-threshold launches %d, points missed %d" % (guessed, missed))

@@ -18,7 +18,7 @@ from chronoclust_amd import _lib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TRACES = sorted(glob.glob(os.path.join(HERE, "golden", "policy", "*.jsonl")))
-DEC_KEYS = ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune", "shard", "restart", "bad", "stalled", "sparse")
+DEC_KEYS = ("win_cfg", "want", "rounds", "batch_windows", "lookahead", "nodirty", "prune", "shard", "restart", "bad", "stalled", "sparse", "probe")
 
 
 def calls_of(path):
