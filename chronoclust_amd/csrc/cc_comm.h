@@ -5,11 +5,13 @@
 // Two transports behind one call:
 //   RCCL   one process per GPU; ncclAllGather over xGMI on the stream of the scan that produced the records.
 //          librccl is opened with dlopen when a communicator is first asked for, so single-GPU users of the
-//          library never load it (and the library has no link-time dependency on it).  TWO communicators per
-//          group, one per HIP stream of the handle (lane 0: main stream, lane 1: lookahead stream): operations on
-//          one ncclComm_t are serialised by RCCL whatever stream they are enqueued on, which would tie the
-//          lookahead scans' all-gathers to the in-place ones of the validation stream.  The second communicator is
-//          created from an id that travels through the first (all-gather of 128 bytes).  Nothing in the library
+//          library never load it (and the library has no link-time dependency on it).  One communicator per
+//          group serves both HIP streams of the handle by default; with CHRONOCLUST_HIP_TWO_COMMS=1 the lookahead
+//          stream gets one of its own (lane 0: main stream, lane 1: lookahead stream): operations on one
+//          ncclComm_t are serialised by RCCL whatever stream they are enqueued on, which ties the lookahead scans'
+//          all-gathers to the in-place ones of the validation stream.  The second communicator is created from
+//          an id that travels through the first (all-gather of 128 bytes); concurrent communicators have never run
+//          on more than one GPU in a build session, hence opt-in.  Nothing in the library
 //          waits for a collective without a bound: host waits on a stream that may hold one poll
 //          ncclCommGetAsyncError and a deadline (wait_stream); on an error or when the deadline passes both
 //          communicators are aborted (ncclCommAbort) and the call returns CC_ERR_COMM.

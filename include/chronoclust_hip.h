@@ -237,10 +237,11 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
  * Small tables are not split (cc_set_shard_thresholds): below ~1 ms of scan per window the exchange costs more
  * than it saves.
  *   cc_comm_unique_id  : rank 0 obtains the 128-byte RCCL id and hands it to the other ranks (any channel)
- *   cc_comm_init_rccl  : joins the group (collective; librccl is loaded here, not before).  Two communicators are
- *                        created, one per HIP stream of the handle, so that the all-gathers of lookahead scans
- *                        (second stream) are not serialised with those of the validation stream; the second
- *                        one's id travels through the first.  No wait for a collective is unbounded: host waits
+ *   cc_comm_init_rccl  : joins the group (collective; librccl is loaded here, not before).  One communicator
+ *                        serves both HIP streams of the handle; CHRONOCLUST_HIP_TWO_COMMS=1 adds a second one for
+ *                        the lookahead stream (its id travels through the first), so that the all-gathers of
+ *                        lookahead scans are not ordered with those of the validation stream - opt-in until a
+ *                        multi-GPU run has confirmed it.  No wait for a collective is unbounded: host waits
  *                        poll ncclCommGetAsyncError and a deadline (CHRONOCLUST_HIP_COMM_TIMEOUT_S, default
  *                        120 s); on an error, a missed deadline or any failing call of a member the
  *                        communicators are aborted (ncclCommAbort) and calls return CC_ERR_COMM
