@@ -13,6 +13,7 @@
 #include <thread>
 #include <type_traits>
 #include <limits>
+#include <optional>
 #include <vector>
 
 #include "../../include/chronoclust_hip.h"
@@ -1273,39 +1274,129 @@ int online_relaxed(cc_handle* h)
     return (int)CC_OK;
 }
 
-// The exact windowed online phase over the resident points [range_a, range_e), in row order.  no_create: a point that
-// no MC absorbs does not create one; it is set aside (label -1, path code 8) and changes nothing - the first half of a
-// super-step of the relaxed multi-GPU mode (section 6 of DESIGN.md).  Statistics are added to h->stats.
-// resume: the range continues a stream this handle was clustering a moment ago (a later mini-batch of a timepoint): the
-// window size carries over as it is instead of restarting small.
-int online_range(cc_handle* h, long long range_a, long long range_e, bool no_create, bool resume)
-{
+// One call of the exact windowed online phase over the resident points [range_a, range_e): the state that lives across its
+// batches of windows, and what happens to it - prepare(), then per iteration either a stint of the sequential kernel or a
+// batch of windows enqueued (enqueue_batch) and read back (after_batch: the policy's decision for the next one) -, finish().
+// online_range() below is its only user.
+struct OnlineRun {
+    cc_handle* const h;
+    const long long range_a, N;
+    const bool no_create, resume;
+    Ctl& c;  // the host mirror of the control block (h->hc)
+
+    // ---- constants of the call ----
+    int win = 0, R = 0;
+    int S_cfg = 1, Sd_full = 1, Sd = 1;  // partials per point: clean scans (refined per batch) / dirty scans
+    int world = 1, myrank = 0;
+    bool grouped = false;
+    size_t batch_max = 2;
+    bool timing = false;
+    int seq_mode = 0, seq_cap = 0;
+    Versions ver{};
+    Carry car{};
+    hipStream_t sA = nullptr, sB = nullptr;
+    static constexpr size_t ev_base = 4;
+
+    // ---- the window policy and its current decision ----
+    cc_policy_config pcfg{};
+    std::optional<cc::WindowPolicy> policy;
+    std::optional<PolicyTrace> ptrace;
+    cc_policy_decision dec{};
+    // While k_dseed rules the dirty scans out for every tile they are not launched at all (beside a lookahead scan
+    // even a launch whose workgroups all return at once waits for registers until the scan has dispatched its last
+    // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
+    // if that stops a window at its first point, and the next batch launches them again.
+    bool nodirty = false;
+    bool sparse_now = false;  // with nodirty: sparse dirty scans for the round's list of points
+    bool la_on = false;       // lookahead scans are being enqueued
+    bool shard_on = false;    // snapshot scans are split over the ranks of the group
+    int Rcur = 1;             // validation rounds enqueued per window of the batch
+    int batch_windows = 2;
+
+    // ---- progress ----
+    long long done = 0;       // the device's cursor as last read back
+    int m_known = 0;          // table rows as last read back
+    unsigned long long seq_host = 0;  // sequence number of the window the next iteration validates
+    long long cursor_prev = 0;
+    double batch_t0 = 0.0;
+
+    // ---- events, timing, statistics ----
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evCommit = nullptr, evScan = nullptr;
+    size_t ev_used = 2, ev_sync = ev_base;
+    std::vector<std::pair<size_t, double>> timed;  // (event index, 1.0 for a pruned chain)
+    std::vector<size_t> timed_comm;                // event index of every timed merge + all-gather
+    double pair_rows_eff = 0.0, pair_rows_prev = 0.0;  // (window points x table rows) this rank's scans covered
+    double pair_rows_pruned = 0.0;                     // ... of those, by pruned chains
+    long long sharded_windows = 0;
+
+    // ---- the sequential kernel's wall-clock rule (off inside a group) ----
+    bool seq_on = false;
+    int bad_batches = 0;              // consecutive batches of short, truncated windows
+    long long seq_stint_len = 32768, seq_stint_left = 32768;
+    bool seq_probe = false;           // the batch of windows in flight is a probe after a sequential stint
+    double win_rate = 0.0, seq_rate_last = 0.0;  // points per millisecond (wall clock) of the last batch / chunk
+
+    // ---- long chains (k_chain_long over the list k_decide keeps) ----
+    long long long_prev = 0;   // Ctl::stat_long at the end of the previous batch
+    bool long_seen = false;    // ... and whether that batch added to it
+    bool long_few = true;      // ... by no more than 64 chains per validation round
+    long long rounds_prev = 0, long_avg = 1;
+    long long long_launches = 0;
+
+    OnlineRun(cc_handle* handle, long long a, long long e, bool no_create_, bool resume_)
+        : h(handle), range_a(a), N(e), no_create(no_create_), resume(resume_), c(handle->hc) {}
+
+    static double now_ms()
     {
-        const long long N = range_e;
-        const int win = h->tun.window, R = h->tun.rounds;
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
+    bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; }
+
+    // lookahead (re)start: the current window is a fresh one (scanned in place), the lookahead scan enqueued next covers
+    // the one after it
+    void set_lookahead(bool on)
+    {
+        // (re)start: the current window is a fresh one, the lookahead scan enqueued next covers the one after it
+        la_on = on;
+        c.la_on = on ? 1 : 0;
+        c.stall_b = 0;
+        c.mode = 0;
+        c.car_n = 0;
+        const int q = (int)((c.window_seq + 1ull) & 1ull);
+        const long long c1 = c.cursor + c.win_b;
+        const long long left1 = c.n_points - c1;
+        c.la_cursor[q] = c1;
+        c.la_b[q] = (on && left1 > 0) ? (int)std::min<long long>(left1, c.win_cfg) : 0;
+        c.la_rows[q] = c.m_rows;
+        c.la_cursor[q ^ 1] = 0;
+        c.la_b[q ^ 1] = 0;
+        c.la_rows[q ^ 1] = 0;
+    }
+
+    // buffers, control block, policy: everything before the first batch
+    void prepare()
+    {
+        win = h->tun.window; R = h->tun.rounds;
         // `segments` MC sub-ranges per point tile = S workgroups of 4 waves -> S partials per point
-        const int S_cfg = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
-        const int Sd_full = std::max(1, (h->tun.dirty_segments > 0 ? h->tun.dirty_segments : h->tun.segments) /
+        S_cfg = std::max(1, h->tun.segments / scan_waves_for_dim(h->d, false));
+        Sd_full = std::max(1, (h->tun.dirty_segments > 0 ? h->tun.dirty_segments : h->tun.segments) /
                                             scan_waves_for_dim(h->d, true));
         // while the dirty scans are ruled out tile by tile (k_dseed) their launches only have to be scheduled: a
         // few workgroups per point tile then, the full split while they really run (set per batch below)
-        int Sd = Sd_full;
-        const int S = S_cfg;  // (refined per batch below)
+        Sd = Sd_full;
         // While k_dseed rules the dirty scans out for every tile they are not launched at all (beside a lookahead scan
         // even a launch whose workgroups all return at once waits for registers until the scan has dispatched its last
         // workgroup); k_decide then refuses points that would have needed them, the device idles the rest of the batch
         // if that stops a window at its first point, and the next batch launches them again.
-        bool nodirty = false;
-        if (range_e <= range_a) return (int)CC_OK;
-        if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
+        nodirty = false;
         refresh_ctl_params(h);
-        ensure_window_buffers(h, win, std::max(S, Sd_full));
+        ensure_window_buffers(h, win, std::max(S_cfg, Sd_full));
         // Exact multi-GPU path: while the table is large enough, every rank scans its share of the table rows and
         // the ranks all-gather one merged candidate record per window point; the rest of the window runs replicated.
         // All ranks take the same decision: it depends on the row count only, which is the same everywhere.
-        const int world = h->comm.world, myrank = h->comm.rank;
+        world = h->comm.world; myrank = h->comm.rank;
         // (a communicator of one rank takes the same path: that is how the RCCL calls are exercised on one GPU)
-        const bool grouped = h->comm.active();
+        grouped = h->comm.active();
         if (grouped) {
             // (+ 4: the record behind the last point's carries the rank's pruned-scan sample, see k_merge_partials)
             // (grids cover at least 64 points, see gw below: the blocks are sized for that even when the window is smaller)
@@ -1316,10 +1407,9 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             h->gpart.ensure(2 * h->gpart_stride);
         }
         // every window of a batch may create one MC per point: rows for the largest batch that can be enqueued
-        const size_t batch_max = (size_t)std::max(2, h->tun.windows_per_sync);
+        batch_max = (size_t)std::max(2, h->tun.windows_per_sync);
         ensure_table(h, (size_t)h->hc.m_rows + (size_t)win * batch_max + 1);
 
-        Ctl& c = h->hc;
         c.cursor = range_a;
         c.n_points = N;
         c.xt_stride = h->n_points;
@@ -1327,7 +1417,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         // How the batches of windows run - window size, validation rounds, windows per batch, lookahead, dirty scans,
         // pruned or plain scans, split over the ranks - is decided by cc::WindowPolicy (cc_policy.h) from the device
         // counters alone; this function carries the decisions out.
-        cc_policy_config pcfg{};
         pcfg.window = win;
         pcfg.rounds_max = R;
         pcfg.windows_per_sync = h->tun.windows_per_sync;
@@ -1345,10 +1434,10 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         pcfg.allow_probe = h->allow_probe ? 1 : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.n_end = N;
-        cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
-        cc::WindowPolicy policy(pcfg, pcarry);
-        cc_policy_decision dec = policy.start(range_a, c.m_rows);
-        PolicyTrace ptrace(pcfg, pcarry, range_a, c.m_rows, dec, grouped ? myrank : -1);
+        const cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
+        policy.emplace(pcfg, pcarry);
+        dec = policy->start(range_a, c.m_rows);
+        ptrace.emplace(pcfg, pcarry, range_a, c.m_rows, dec, grouped ? myrank : -1);
         c.win_cfg = dec.win_cfg;
         c.win_b = (int)std::min<long long>(c.win_cfg, N - range_a);
         c.max_rounds = R;
@@ -1373,25 +1462,6 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         }
         c.cen_absmax = 0ull;            // (k_rebuild_scl takes the table's maximum into it)
         c.x_absmax = h->x_absmax;
-        // lookahead: the first window of a call is scanned in place; the scan enqueued beside it covers the second one
-        bool la_on = false;
-        auto set_lookahead = [&](bool on) {
-            // (re)start: the current window is a fresh one, the lookahead scan enqueued next covers the one after it
-            la_on = on;
-            c.la_on = on ? 1 : 0;
-            c.stall_b = 0;
-            c.mode = 0;
-            c.car_n = 0;
-            const int q = (int)((c.window_seq + 1ull) & 1ull);
-            const long long c1 = c.cursor + c.win_b;
-            const long long left1 = c.n_points - c1;
-            c.la_cursor[q] = c1;
-            c.la_b[q] = (on && left1 > 0) ? (int)std::min<long long>(left1, c.win_cfg) : 0;
-            c.la_rows[q] = c.m_rows;
-            c.la_cursor[q ^ 1] = 0;
-            c.la_b[q ^ 1] = 0;
-            c.la_rows[q ^ 1] = 0;
-        };
         set_lookahead(dec.lookahead != 0);
         c.stat_pair_rows = 0.0;
         for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i) c.round_hist[i] = 0;
@@ -1405,389 +1475,388 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
-        hipEvent_t ev0 = get_event(h, 0), ev1 = get_event(h, 1);
+        ev0 = get_event(h, 0); ev1 = get_event(h, 1);
         HIPCHK(hipEventRecord(ev0, h->stream));
-        size_t ev_used = 2;
-        std::vector<std::pair<size_t, double>> timed;  // (event index, 1.0 for a pruned chain)
-        std::vector<size_t> timed_comm;                // event index of every timed merge + all-gather
-        const bool timing = h->tun.time_kernels != 0;
-        bool shard_on = dec.shard != 0;
-        double pair_rows_eff = 0.0, pair_rows_prev = 0.0;  // (window points x table rows) this rank's scans covered
-        double pair_rows_pruned = 0.0;                     // ... of those, by pruned chains
-        long long sharded_windows = 0;
+        ev_used = 2;
+        timing = h->tun.time_kernels != 0;
+        shard_on = dec.shard != 0;
 
-        const Versions ver = versions_view(h);
-        const Carry car = carry_view(h);
-        hipStream_t sA = h->stream, sB = h->stream2;
+        ver = versions_view(h);
+        car = carry_view(h);
+        sA = h->stream; sB = h->stream2;
         // cross-stream hand-offs: a fresh event per hand-off (the pool is reused from batch to batch)
-        hipEvent_t evCommit = get_event(h, 2), evScan = nullptr;
-        const size_t ev_base = 4;
-        size_t ev_sync = ev_base;
+        evCommit = get_event(h, 2); evScan = nullptr;
+        ev_sync = ev_base;
         ev_used = ev_base + 3 * (batch_max + 2);
 
-        long long done = range_a;
-        int m_known = c.m_rows;
+        done = range_a;
+        m_known = c.m_rows;
         // The sequential kernel (k_seq) for streams on which speculation does not pay: used while the table fits its
         // LDS image and either the caller forces it or (default) the windows keep being cut short and it measures
         // faster than they do.  Never inside a multi-GPU group (every rank has to take the same path, and wall-clock
         // measurements differ between ranks).
-        const int seq_mode = h->tun.sequential;
-        const int seq_cap = cc_seq_cap_rows(h->d);
-        auto seq_possible = [&]() { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; };
-        bool seq_on = seq_possible() && (seq_mode == 2 || h->seq_sticky);
+        seq_mode = h->tun.sequential;
+        seq_cap = cc_seq_cap_rows(h->d);
+        seq_on = seq_possible() && (seq_mode == 2 || h->seq_sticky);
         // default policy: the sequential kernel takes over after two batches in a row whose windows were cut short
         // at a few hundred points; it works in stints (32 k points, doubling), after each of which one batch of
         // windows is run again and the two measured rates decide who continues
-        int bad_batches = 0;              // consecutive batches of short, truncated windows
-        long long seq_stint_len = 32768, seq_stint_left = seq_stint_len;
-        bool seq_probe = false;           // the batch of windows in flight is a probe after a sequential stint
-        double win_rate = 0.0, seq_rate_last = 0.0;  // points per millisecond (wall clock) of the last batch / chunk
-        auto now_ms = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        int Rcur = dec.rounds;             // validation rounds enqueued per window of the batch
-        int batch_windows = dec.batch_windows;
+        Rcur = dec.rounds;
+        batch_windows = dec.batch_windows;
         h->prune_now = dec.prune != 0;
         h->guess_now = dec.prune == 2;
         nodirty = dec.nodirty != 0;
-        bool sparse_now = dec.sparse != 0;  // with nodirty: sparse dirty scans for the round's list of points
-        long long cursor_prev = range_a;
-        long long long_prev = 0;   // Ctl::stat_long at the end of the previous batch
-        bool long_seen = false;    // ... and whether that batch added to it
-        bool long_few = true;      // ... by no more than 64 chains per validation round
-        long long rounds_prev = 0, long_avg = 1;
-        long long long_launches = 0;
-        unsigned long long seq_host = c.window_seq;  // sequence number of the window the next iteration validates
-        while (done < N) {
-            ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
-            const Table tab = h->tab.view();
-            if (seq_on) {
-                const int chunk = 8192;
-                const double t0 = now_ms();
-                {
-                    const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
+        sparse_now = dec.sparse != 0;
+        cursor_prev = range_a;
+        seq_host = c.window_seq;
+    }
+
+    // a stint of the sequential kernel (k_seq): one chunk of points, then back to the windows if the table outgrew its LDS
+    // image or the stint is over
+    void sequential_stint(const Table& tab)
+    {
+        const int chunk = 8192;
+        const double t0 = now_ms();
+        {
+            const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
 #define CC_SEQ(F, P) hipLaunchKernelGGL((k_seq<F, P>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk)
-                    if (f && p2) CC_SEQ(true, true);
-                    else if (f) CC_SEQ(true, false);
-                    else if (p2) CC_SEQ(false, true);
-                    else CC_SEQ(false, false);
+            if (f && p2) CC_SEQ(true, true);
+            else if (f) CC_SEQ(true, false);
+            else if (p2) CC_SEQ(false, true);
+            else CC_SEQ(false, false);
 #undef CC_SEQ
-                }
-                HIPCHK(hipGetLastError());
-                pull_ctl(h);
-                const double dt = now_ms() - t0;
-                const long long got = h->hc.cursor - done;
-                done = h->hc.cursor;
-                m_known = h->hc.m_rows;
-                seq_host = h->hc.window_seq;
-                cursor_prev = h->hc.cursor;
-                const double seq_rate = got > 0 ? (double)got / std::max(dt, 1e-3) : 0.0;
-                if (h->trace)
-                    fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms (so far %lld shader cycles, %.3f ms of kernel time)\n",
-                            done, h->hc.m_rows, got, dt, (long long)h->hc.stat_seq_clk, (double)h->hc.stat_seq_wall / 1e5);
-                if (got >= 1024) seq_rate_last = seq_rate;
-                seq_stint_left -= got;
-                const bool full = !seq_possible() || (got < chunk && done < N);
-                const bool stint_over = seq_mode != 2 && seq_stint_left <= 0;
-                if ((full || stint_over) && done < N) {
-                    // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
-                    seq_on = false;
-                    seq_probe = stint_over && !full;
-                    bad_batches = 0;
-                    HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
-                    h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
-                    dec = policy.after_sequential(h->hc.cursor, h->hc.m_rows);
-                    ptrace.sequential(h->hc.cursor, h->hc.m_rows, dec);
-                    nodirty = dec.nodirty != 0;
-                    sparse_now = dec.sparse != 0;
-                    set_lookahead(dec.lookahead != 0);
-                    push_ctl(h);
-                }
-                continue;
-            }
-            const double batch_t0 = now_ms();
-            // pruned snapshot scans for this batch?  (a function of device counters only: every rank decides alike)
-            // (h->prune_now was set for this batch at the end of the previous one, together with the lookahead restart a
-            // change of it needs: a pruned scan leaves fewer partials per point than a plain one)
-            const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
-                             nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-            const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
-                             ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, nullptr, 0};
-            const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
-                             car.tile_dsq, car.dsq, ver.tau, ver.skip_car, nullptr, car.slot, tab.touch, tab.cap};
-            // the sparse dirty scans: the same rows for the round's list of points instead of the window's tiles
-            Rows vrows_sp = vrows, crows_sp = crows;
-            vrows_sp.skip = nullptr; vrows_sp.plist = h->sp_list.p;
-            crows_sp.skip = nullptr; crows_sp.plist = h->sp_list.p;
-            ev_sync = ev_base;
-            // grids cover the window size of this batch (no window of the batch is larger), not the configured maximum
-            const int gw = std::max(64, std::min(win, h->hc.win_cfg));
-            // partials per point of this batch's clean scans (a pending lookahead scan was launched with the same value:
-            // it only depends on the window size, and a change of that restarts the lookahead chain)
-            // A pruned scan spends a few VALU instructions per row, so a wave must own many rows for its fixed costs
-            // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
-            // the machine once (about a fifth of the plain scan's partials at the full window).
-            const int scan_cus = h->n_cus;
-            // (measured, `profiles/r03_tool_prune_split.txt`: four rounds of the resident workgroups at d <= 20 - k_scan_p is
-            // compiled for four per CU there -, eight of the three per CU beyond)
-            const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? 16 : 24);
-            const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * prune_wgs) / std::max(1, (gw + 63) / 64)))
-                                       : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
-            // capacity of the round's list for the sparse dirty scans: a sixteenth of the window (the policy's bound on
-            // the batch's average), in whole tiles
-            const int sparse_cap = std::min(CC_MAX_WINDOW / 16, std::max(64, ((gw / 16 + 63) / 64) * 64));
-            const int decide_threads = h->decide_threads;
-            const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
-            const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
-            const int cblocks = (gw + chain_threads / 32 - 1) / (chain_threads / 32);
-            const int commit_threads = h->commit_threads;
-            const int rblocks = std::min((gw + commit_threads / 32 - 1) / (commit_threads / 32), 1024 * (256 / commit_threads));
-            // few MCs: the claims of a window are gathered per MC by k_claims (rows beyond scan_rows, e.g. rows created
-            // during the batch, keep k_decide's atomics)
-            const int scan_rows = (h->allow_claims && h->hc.m_rows > 0 && h->hc.m_rows <= 1024) ? h->hc.m_rows : 0;
-            // ... and their long chains (more than CC_CHAIN_MEMB claimants; k_claims leaves the exact count) are replayed
-            // by k_chain_long, one workgroup per MC, instead of one point after the other
-            const int long_rows = h->allow_long ? scan_rows : 0;
-            // On a larger table long chains are rare on evenly spread data and the rule on skewed data (one population
-            // that takes a third of the events): k_chain_long is launched, over the list k_decide keeps, in the batches
-            // that follow one in which such chains were seen (a function of device counters: every rank decides alike)
-            const bool long_listed = h->allow_long && scan_rows == 0 && long_seen;
-            int* const long_list = long_listed ? h->long_list.p : nullptr;
-            // workgroups of its launches = entries k_decide may list per round: a few more than the previous batch's
-            // average when that was small (a launch of hundreds of workgroups that return at once is not free)
-            const int long_cap = long_few ? (int)std::min<long long>(CC_LONG_CAP, 2 * long_avg + 8) : CC_LONG_CAP;
-            // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
-            // a batch, then kept up commit by commit
-            ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
-            if (la_on) scan_copy_sync(h, scopy);
-            Rows srows[2];
-            for (int q = 0; q < 2; ++q)
-                srows[q] = Rows{scopy[q].cen, scopy[q].scl, nullptr, scopy[q].cf1, scopy[q].cf2, scopy[q].w, scopy[q].kind,
-                                scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-            evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
-            if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
-            int probe_left = (dec.probe != 0) ? 1 : 0;
-            for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
-                hipEvent_t scan_end = nullptr;  // the event recorded right behind the last timed scan (nothing after it yet)
-                auto timed_scan = [&](hipStream_t st, int mode, int round) {
-                    const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
-                    h->probe_now = probe_left > 0 && !h->prune_now;  // (the batch's first scan carries the probe)
-                    if (h->probe_now) --probe_left;
-                    const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
-                    scan_end = nullptr;
-                    if (timing) {
-                        hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
-                        HIPCHK(hipEventRecord(a, st));
-                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
-                        HIPCHK(hipEventRecord(b, st));
-                        timed.push_back({ev_used, h->prune_now ? 1.0 : 0.0});  // (second: a pruned chain or a plain scan)
-                        ev_used += 2;
-                        if (!shard_on) scan_end = b;
-                    } else {
-                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
-                    }
-                    if (shard_on) {
-                        // the rank's S partials per point -> one record per point -> the records of all ranks, in rank
-                        // order, in the gathered buffer of the window's parity (what k_decide round 0 reads)
-                        const int q = (mode == 1) ? (round & 1) : (int)(seq_host & 1ull);
-                        if (timing) HIPCHK(hipEventRecord(get_event(h, ev_used), st));
-                        hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
-                                           h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode,
-                                           (const unsigned long long*)(h->prune_now && sworld > 1 ? h->pstat.p : nullptr), gw * 4);
-                        h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
-                                           ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
-                        if (timing) {
-                            HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
-                            timed_comm.push_back(ev_used);
-                            ev_used += 2;
-                        }
-                    }
-                };
-                // where k_decide round 0 finds the snapshot candidates of a point
-                const Cand* const dec_part = shard_on ? h->gpart.p : h->part.p;
-                const size_t dec_stride = shard_on ? h->gpart_stride : h->part_stride;
-                const int dec_S = shard_on ? world : S, dec_inner = shard_on ? 1 : S;
-                const size_t dec_outer = shard_on ? (size_t)gw * 4 + 4 : 0;
-                const int dec_tail = shard_on ? gw * 4 : -1;  // where each rank's pruned-scan sample sits in its block
-                if (la_on) {
-                    // first stream: this window's snapshot scan (enqueued one iteration ago on the second stream)
-                    if (evScan) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));
-                    // second stream: the snapshot scan of the window after this one, against the scan copy of its
-                    // parity (= the table as the previous commit left it), while this window is validated on the first
-                    HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
-                    timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
-                    if (scan_end) evScan = scan_end;  // the timing event already marks the end of the scan: no second record
-                    else {
-                        evScan = get_sync_event(h, ev_sync++);
-                        HIPCHK(hipEventRecord(evScan, sB));
-                    }
-                    // only the first window of a lookahead batch can need an in-place scan (the device idles the
-                    // rest of a batch whose lookahead chain breaks, see Ctl::stall_b)
-                    if (wv == 0 && h->hc.mode == 0) timed_scan(sA, 0, 0);
+        }
+        HIPCHK(hipGetLastError());
+        pull_ctl(h);
+        const double dt = now_ms() - t0;
+        const long long got = h->hc.cursor - done;
+        done = h->hc.cursor;
+        m_known = h->hc.m_rows;
+        seq_host = h->hc.window_seq;
+        cursor_prev = h->hc.cursor;
+        const double seq_rate = got > 0 ? (double)got / std::max(dt, 1e-3) : 0.0;
+        if (h->trace)
+            fprintf(stderr, "[cc] done %lld rows %d | sequential kernel: %lld points in %.3f ms (so far %lld shader cycles, %.3f ms of kernel time)\n",
+                    done, h->hc.m_rows, got, dt, (long long)h->hc.stat_seq_clk, (double)h->hc.stat_seq_wall / 1e5);
+        if (got >= 1024) seq_rate_last = seq_rate;
+        seq_stint_left -= got;
+        const bool full = !seq_possible() || (got < chunk && done < N);
+        const bool stint_over = seq_mode != 2 && seq_stint_left <= 0;
+        if ((full || stint_over) && done < N) {
+            // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
+            seq_on = false;
+            seq_probe = stint_over && !full;
+            bad_batches = 0;
+            HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
+            h->hc.win_b = (int)std::min<long long>(h->hc.win_cfg, N - done);
+            dec = policy->after_sequential(h->hc.cursor, h->hc.m_rows);
+            ptrace->sequential(h->hc.cursor, h->hc.m_rows, dec);
+            nodirty = dec.nodirty != 0;
+            sparse_now = dec.sparse != 0;
+            set_lookahead(dec.lookahead != 0);
+            push_ctl(h);
+        }
+    }
+
+    // one batch of windows: per window the snapshot scan (in place or one window ahead on the second stream), round 0 of
+    // the decisions, the validation rounds, the commit - all enqueued without a host round-trip
+    void enqueue_batch(const Table& tab)
+    {
+        batch_t0 = now_ms();
+        // pruned snapshot scans for this batch?  (a function of device counters only: every rank decides alike)
+        // (h->prune_now was set for this batch at the end of the previous one, together with the lookahead restart a
+        // change of it needs: a pruned scan leaves fewer partials per point than a plain one)
+        const Rows trows{tab.cen, tab.scl, tab.pref, tab.cf1, tab.cf2, tab.w, tab.kind, tab.key, nullptr, nullptr, nullptr,
+                         nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        const Rows vrows{ver.cen, ver.scl, ver.pref, ver.cf1, ver.cf2, ver.w, ver.kind, ver.key, ver.next,
+                         ver.tile_dsq, ver.dsq, ver.tau, ver.skip, nullptr, nullptr, nullptr, 0};
+        const Rows crows{car.cen, car.scl, car.pref, car.cf1, car.cf2, car.w, car.kind, car.key, nullptr,
+                         car.tile_dsq, car.dsq, ver.tau, ver.skip_car, nullptr, car.slot, tab.touch, tab.cap};
+        // the sparse dirty scans: the same rows for the round's list of points instead of the window's tiles
+        Rows vrows_sp = vrows, crows_sp = crows;
+        vrows_sp.skip = nullptr; vrows_sp.plist = h->sp_list.p;
+        crows_sp.skip = nullptr; crows_sp.plist = h->sp_list.p;
+        ev_sync = ev_base;
+        // grids cover the window size of this batch (no window of the batch is larger), not the configured maximum
+        const int gw = std::max(64, std::min(win, h->hc.win_cfg));
+        // partials per point of this batch's clean scans (a pending lookahead scan was launched with the same value:
+        // it only depends on the window size, and a change of that restarts the lookahead chain)
+        // A pruned scan spends a few VALU instructions per row, so a wave must own many rows for its fixed costs
+        // (points, thresholds, tile pipeline, candidate merge: microseconds) not to dominate: as few sub-ranges as fill
+        // the machine once (about a fifth of the plain scan's partials at the full window).
+        const int scan_cus = h->n_cus;
+        // (measured, `profiles/r03_tool_prune_split.txt`: four rounds of the resident workgroups at d <= 20 - k_scan_p is
+        // compiled for four per CU there -, eight of the three per CU beyond)
+        const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? 16 : 24);
+        const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * prune_wgs) / std::max(1, (gw + 63) / 64)))
+                                   : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
+        // capacity of the round's list for the sparse dirty scans: a sixteenth of the window (the policy's bound on
+        // the batch's average), in whole tiles
+        const int sparse_cap = std::min(CC_MAX_WINDOW / 16, std::max(64, ((gw / 16 + 63) / 64) * 64));
+        const int decide_threads = h->decide_threads;
+        const int dblocks = (gw + decide_threads / 32 - 1) / (decide_threads / 32);   // one 32-lane group per point
+        const int chain_threads = h->chain_threads;  // 32-lane groups of k_chain per workgroup x 32
+        const int cblocks = (gw + chain_threads / 32 - 1) / (chain_threads / 32);
+        const int commit_threads = h->commit_threads;
+        const int rblocks = std::min((gw + commit_threads / 32 - 1) / (commit_threads / 32), 1024 * (256 / commit_threads));
+        // few MCs: the claims of a window are gathered per MC by k_claims (rows beyond scan_rows, e.g. rows created
+        // during the batch, keep k_decide's atomics)
+        const int scan_rows = (h->allow_claims && h->hc.m_rows > 0 && h->hc.m_rows <= 1024) ? h->hc.m_rows : 0;
+        // ... and their long chains (more than CC_CHAIN_MEMB claimants; k_claims leaves the exact count) are replayed
+        // by k_chain_long, one workgroup per MC, instead of one point after the other
+        const int long_rows = h->allow_long ? scan_rows : 0;
+        // On a larger table long chains are rare on evenly spread data and the rule on skewed data (one population
+        // that takes a third of the events): k_chain_long is launched, over the list k_decide keeps, in the batches
+        // that follow one in which such chains were seen (a function of device counters: every rank decides alike)
+        const bool long_listed = h->allow_long && scan_rows == 0 && long_seen;
+        int* const long_list = long_listed ? h->long_list.p : nullptr;
+        // workgroups of its launches = entries k_decide may list per round: a few more than the previous batch's
+        // average when that was small (a launch of hundreds of workgroups that return at once is not free)
+        const int long_cap = long_few ? (int)std::min<long long>(CC_LONG_CAP, 2 * long_avg + 8) : CC_LONG_CAP;
+        // lookahead scans read a scan copy of the table (see ScanCopy): both in line with the table at the start of
+        // a batch, then kept up commit by commit
+        ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
+        if (la_on) scan_copy_sync(h, scopy);
+        Rows srows[2];
+        for (int q = 0; q < 2; ++q)
+            srows[q] = Rows{scopy[q].cen, scopy[q].scl, nullptr, scopy[q].cf1, scopy[q].cf2, scopy[q].w, scopy[q].kind,
+                            scopy[q].key, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
+        if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
+        int probe_left = (dec.probe != 0) ? 1 : 0;
+        for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
+            hipEvent_t scan_end = nullptr;  // the event recorded right behind the last timed scan (nothing after it yet)
+            auto timed_scan = [&](hipStream_t st, int mode, int round) {
+                const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
+                h->probe_now = probe_left > 0 && !h->prune_now;  // (the batch's first scan carries the probe)
+                if (h->probe_now) --probe_left;
+                const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
+                scan_end = nullptr;
+                if (timing) {
+                    hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
+                    HIPCHK(hipEventRecord(a, st));
+                    launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
+                    HIPCHK(hipEventRecord(b, st));
+                    timed.push_back({ev_used, h->prune_now ? 1.0 : 0.0});  // (second: a pruned chain or a plain scan)
+                    ev_used += 2;
+                    if (!shard_on) scan_end = b;
                 } else {
-                    timed_scan(sA, 0, 0);
+                    launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld);
                 }
-                // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
-                // of the previous commit (cc_apply_carry, extra workgroups of this launch: before this window's commit
-                // overwrites the carry set), then, in k_commit_b, this window's own
-                const ScanCopy sc_now = scopy[seq_host & 1ull];
-                const int ac_blocks = la_on ? rblocks : 0;
-                hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                   dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
-                                   h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                                   (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0);
-                if (scan_rows > 0)
-                    hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
-                for (int r = 1; r <= Rcur; ++r) {
-                    const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
-                    int* tnew = (r & 1) ? h->T1.p : h->T0.p;
-                    hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(chain_threads), 0, sA,
-                                       h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
-                    // k_chain_long: one workgroup per table row while k_claims serves the table, else per entry of the
-                    // round's list.  The large workgroups (SPLIT) while they are few - rows <= 256, or a short list, judged by
-                    // the previous batch's count -, the small ones (two per CU) when hundreds of chains are long
-                    if (long_rows > 0 && long_rows <= 256)
-                        hipLaunchKernelGGL(k_chain_long<true>, dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
-                                           ver, car, told, r, long_rows, (const int*)nullptr);
-                    else if (long_rows > 0)
-                        hipLaunchKernelGGL(k_chain_long<false>, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                           told, r, long_rows, (const int*)nullptr);
-                    else if (long_listed && ++long_launches > 0) {
-                        if (long_few)
-                            hipLaunchKernelGGL(k_chain_long<true>, dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
-                                               tab, ver, car, told, r, 0, (const int*)long_list);
-                        else
-                            hipLaunchKernelGGL(k_chain_long<false>, dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
-                                               car, told, r, 0, (const int*)long_list);
+                if (shard_on) {
+                    // the rank's S partials per point -> one record per point -> the records of all ranks, in rank
+                    // order, in the gathered buffer of the window's parity (what k_decide round 0 reads)
+                    const int q = (mode == 1) ? (round & 1) : (int)(seq_host & 1ull);
+                    if (timing) HIPCHK(hipEventRecord(get_event(h, ev_used), st));
+                    hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
+                                       h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode,
+                                       (const unsigned long long*)(h->prune_now && sworld > 1 ? h->pstat.p : nullptr), gw * 4);
+                    h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
+                                       ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
+                    if (timing) {
+                        HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
+                        timed_comm.push_back(ev_used);
+                        ev_used += 2;
                     }
-                    const bool sparse_r = nodirty && sparse_now;
-                    hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                       h->clean.p, h->dseed.p, told, r, (const int8_t*)h->dpath.p, h->sp_list.p,
-                                       sparse_r ? sparse_cap : 0);
-                    if (!nodirty) {
-                        launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
-                        if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
-                    } else if (sparse_r) {
-                        // (the grid covers the list's capacity; workgroups beyond the round's count return at once)
-                        launch_scan<true>(h, sA, sparse_cap, vrows_sp, h->dseed.p, h->dpart.p, Sd, r, 0);
-                        if (la_on) launch_scan<true>(h, sA, sparse_cap, crows_sp, h->dseed.p, h->dpart2.p, Sd, r, 1);
-                    }
-                    hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
-                                       dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
-                                       dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
-                                       r == Rcur ? 1 : 0);
-                    // (the claims of the last round are not replayed: nothing to gather either)
-                    if (scan_rows > 0 && r < Rcur)
-                        hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
                 }
-                hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
-                                   h->rk.p, h->rec.p, (const Cand*)h->clean.p, (const int8_t*)h->dpath.p);
-                hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
-                                   h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
-                if (la_on) {
-                    evCommit = get_sync_event(h, ev_sync++);
-                    HIPCHK(hipEventRecord(evCommit, sA));
+            };
+            // where k_decide round 0 finds the snapshot candidates of a point
+            const Cand* const dec_part = shard_on ? h->gpart.p : h->part.p;
+            const size_t dec_stride = shard_on ? h->gpart_stride : h->part_stride;
+            const int dec_S = shard_on ? world : S, dec_inner = shard_on ? 1 : S;
+            const size_t dec_outer = shard_on ? (size_t)gw * 4 + 4 : 0;
+            const int dec_tail = shard_on ? gw * 4 : -1;  // where each rank's pruned-scan sample sits in its block
+            if (la_on) {
+                // first stream: this window's snapshot scan (enqueued one iteration ago on the second stream)
+                if (evScan) HIPCHK(hipStreamWaitEvent(sA, evScan, 0));
+                // second stream: the snapshot scan of the window after this one, against the scan copy of its
+                // parity (= the table as the previous commit left it), while this window is validated on the first
+                HIPCHK(hipStreamWaitEvent(sB, evCommit, 0));
+                timed_scan(sB, 1, (int)((seq_host + 1ull) & 1ull));
+                if (scan_end) evScan = scan_end;  // the timing event already marks the end of the scan: no second record
+                else {
+                    evScan = get_sync_event(h, ev_sync++);
+                    HIPCHK(hipEventRecord(evScan, sB));
                 }
+                // only the first window of a lookahead batch can need an in-place scan (the device idles the
+                // rest of a batch whose lookahead chain breaks, see Ctl::stall_b)
+                if (wv == 0 && h->hc.mode == 0) timed_scan(sA, 0, 0);
+            } else {
+                timed_scan(sA, 0, 0);
             }
-            HIPCHK(hipGetLastError());
-            pull_ctl(h);
-            if (la_on) sync_stream(h, sB);
-            seq_host = h->hc.window_seq;
-            done = h->hc.cursor;
-            m_known = h->hc.m_rows;
-            const bool shard_was = shard_on;
-            {
-                const double dt = now_ms() - batch_t0;
-                const long long pts_b = h->hc.cursor - cursor_prev;
-                if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
-                cursor_prev = h->hc.cursor;
-                long_seen = h->hc.stat_long > long_prev;
-                // (long chains per window and validation round of the batch: up to 64 count as few)
-                long_avg = (h->hc.stat_long - long_prev) / std::max<long long>(1, h->hc.stat_rounds - rounds_prev) + 1;
-                long_few = long_avg <= 64;
-                long_prev = h->hc.stat_long;
-                rounds_prev = h->hc.stat_rounds;
+            // the scan copy of this window's parity was last read by this window's own snapshot scan: first the rows
+            // of the previous commit (cc_apply_carry, extra workgroups of this launch: before this window's commit
+            // overwrites the carry set), then, in k_commit_b, this window's own
+            const ScanCopy sc_now = scopy[seq_host & 1ull];
+            const int ac_blocks = la_on ? rblocks : 0;
+            hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                               dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
+                               h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
+                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0);
+            if (scan_rows > 0)
+                hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
+            for (int r = 1; r <= Rcur; ++r) {
+                const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
+                int* tnew = (r & 1) ? h->T1.p : h->T0.p;
+                hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(chain_threads), 0, sA,
+                                   h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
+                // k_chain_long: one workgroup per table row while k_claims serves the table, else per entry of the
+                // round's list.  The large workgroups (SPLIT) while they are few - rows <= 256, or a short list, judged by
+                // the previous batch's count -, the small ones (two per CU) when hundreds of chains are long
+                if (long_rows > 0 && long_rows <= 256)
+                    hipLaunchKernelGGL(k_chain_long<true>, dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
+                                       ver, car, told, r, long_rows, (const int*)nullptr);
+                else if (long_rows > 0)
+                    hipLaunchKernelGGL(k_chain_long<false>, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                       told, r, long_rows, (const int*)nullptr);
+                else if (long_listed && ++long_launches > 0) {
+                    if (long_few)
+                        hipLaunchKernelGGL(k_chain_long<true>, dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
+                                           tab, ver, car, told, r, 0, (const int*)long_list);
+                    else
+                        hipLaunchKernelGGL(k_chain_long<false>, dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
+                                           car, told, r, 0, (const int*)long_list);
+                }
+                const bool sparse_r = nodirty && sparse_now;
+                hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                   h->clean.p, h->dseed.p, told, r, (const int8_t*)h->dpath.p, h->sp_list.p,
+                                   sparse_r ? sparse_cap : 0);
+                if (!nodirty) {
+                    launch_scan<true>(h, sA, gw, vrows, h->dseed.p, h->dpart.p, Sd, r, 0);
+                    if (la_on) launch_scan<true>(h, sA, gw, crows, h->dseed.p, h->dpart2.p, Sd, r, 1);
+                } else if (sparse_r) {
+                    // (the grid covers the list's capacity; workgroups beyond the round's count return at once)
+                    launch_scan<true>(h, sA, sparse_cap, vrows_sp, h->dseed.p, h->dpart.p, Sd, r, 0);
+                    if (la_on) launch_scan<true>(h, sA, sparse_cap, crows_sp, h->dseed.p, h->dpart2.p, Sd, r, 1);
+                }
+                hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
+                                   dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
+                                   dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
+                                   r == Rcur ? 1 : 0);
+                // (the claims of the last round are not replayed: nothing to gather either)
+                if (scan_rows > 0 && r < Rcur)
+                    hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
             }
-            {
-                // what the device counted, and the policy's decision for the next batch
-                cc_policy_obs o{};
-                o.cursor = h->hc.cursor;
-                o.m_rows = h->hc.m_rows;
-                o.stall_b = h->hc.stall_b;
-                o.stat_windows = h->hc.stat_windows;
-                o.stat_truncated = h->hc.stat_truncated;
-                o.stat_trunc_unknown = h->hc.stat_trunc_unknown;
-                o.stat_tiles = h->hc.stat_tiles;
-                o.stat_dirty_tiles = h->hc.stat_dirty_tiles;
-                o.stat_unsafe = h->hc.stat_unsafe;
-                o.stat_missed = h->hc.stat_missed;
-                o.tg_ok = (h->hc.tg_ok[0][0] != 0 && h->hc.tg_ok[1][0] != 0) ? 1 : 0;  // (a mean for the pcore kind in both slots)
-                for (int r = 0; r < CC_MAX_ROUNDS + 2; ++r) o.round_hist[r] = h->hc.round_hist[r];
-                o.prune_rows = h->hc.stat_prune_rows;
-                o.prune_full = h->hc.stat_prune_full;
-                dec = policy.after_batch(o);
-                ptrace.batch(o, dec);
-                const cc_policy_carry& k = policy.carry();
-                h->adapt_win = k.adapt_win; h->clean_batches = k.clean_batches; h->since_shrink = k.since_shrink;
-                if (dec.stalled)
-                    return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
-                if (h->trace && dec.prune_rows > 0)
-                    fprintf(stderr, "[cc] pruned scans of the batch%s (sample): %lld (wave, row) pairs, %.1f %% evaluated in full; points missed by guessed thresholds so far: %lld\n",
-                            h->guess_now ? ", guessed thresholds" : "", (long long)dec.prune_rows,
-                            100.0 * (double)dec.prune_full / (double)dec.prune_rows, (long long)h->hc.stat_missed);
-                pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
-                if (h->prune_now) pair_rows_pruned += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
-                pair_rows_prev = h->hc.stat_pair_rows;
-                if (shard_was) sharded_windows += dec.wins;
-                Rcur = dec.rounds;
-                Sd = Sd_full;
-                nodirty = dec.nodirty != 0;
-                sparse_now = dec.sparse != 0;
-                shard_on = dec.shard != 0;
-                h->prune_now = dec.prune != 0;
-                h->guess_now = dec.prune == 2;
-                if (dec.restart) {
-                    h->hc.win_cfg = dec.win_cfg;
-                    h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);
-                    set_lookahead(dec.lookahead != 0);
-                    push_ctl(h);
-                }
-                if (h->trace)
-                    fprintf(stderr, "[cc] %.2f ms done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
-                            now_ms() - batch_t0, done, h->hc.m_rows, (long long)dec.wins, (long long)dec.pts, (long long)dec.trunc, (long long)dec.unk, (long long)h->hc.stat_lookahead, (long long)dec.dtiles, (long long)dec.tiles,
-                            (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, dec.want, Rcur);
-                batch_windows = dec.batch_windows;
-                // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back
-                // if it measures slower than this batch did)
-                {
-                    const bool bad = dec.bad != 0;
-                    bad_batches = bad ? bad_batches + 1 : 0;
-                    if (seq_mode == 0 && seq_possible() && done < N) {
-                        if (seq_probe) {
-                            // after a stint: back to the sequential kernel (for twice as long) only if the windows
-                            // are still being cut short and were measurably slower
-                            if (bad && seq_rate_last > 0.0 && win_rate < seq_rate_last) {
-                                seq_on = true;
-                                seq_stint_len = std::min<long long>(seq_stint_len * 2, 1 << 20);
-                            } else {
-                                seq_stint_len = 32768;
-                            }
-                        } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : 700.0)) {
-                            // (700 points per millisecond: what k_seq delivers whatever the data, until it has been measured
-                            // in this call; the short windows of a stream that is merely starting up run faster than that)
-                            seq_on = true;
-                        }
-                        if (seq_on) seq_stint_left = seq_stint_len;
-                    }
-                    seq_probe = false;
-                    if (seq_mode == 2 && seq_possible() && done < N) seq_on = true;
-                }
+            hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
+                               h->rk.p, h->rec.p, (const Cand*)h->clean.p, (const int8_t*)h->dpath.p);
+            hipLaunchKernelGGL(k_commit_b, dim3(rblocks), dim3(commit_threads), 0, sA, h->rec.p, tab, ver, car, h->rk.p, h->dpath.p,
+                               h->lab_uid.p, h->lab_path.p, h->d, sc_now, h->hc.filter);
+            if (la_on) {
+                evCommit = get_sync_event(h, ev_sync++);
+                HIPCHK(hipEventRecord(evCommit, sA));
             }
         }
+    }
+
+    // the batch has been enqueued: wait for it, read the control block back, let the policy decide how the next one runs
+    int after_batch()
+    {
+        HIPCHK(hipGetLastError());
+        pull_ctl(h);
+        if (la_on) sync_stream(h, sB);
+        seq_host = h->hc.window_seq;
+        done = h->hc.cursor;
+        m_known = h->hc.m_rows;
+        const bool shard_was = shard_on;
+        {
+            const double dt = now_ms() - batch_t0;
+            const long long pts_b = h->hc.cursor - cursor_prev;
+            if (pts_b > 0) win_rate = (double)pts_b / std::max(dt, 1e-3);
+            cursor_prev = h->hc.cursor;
+            long_seen = h->hc.stat_long > long_prev;
+            // (long chains per window and validation round of the batch: up to 64 count as few)
+            long_avg = (h->hc.stat_long - long_prev) / std::max<long long>(1, h->hc.stat_rounds - rounds_prev) + 1;
+            long_few = long_avg <= 64;
+            long_prev = h->hc.stat_long;
+            rounds_prev = h->hc.stat_rounds;
+        }
+        {
+            // what the device counted, and the policy's decision for the next batch
+            cc_policy_obs o{};
+            o.cursor = h->hc.cursor;
+            o.m_rows = h->hc.m_rows;
+            o.stall_b = h->hc.stall_b;
+            o.stat_windows = h->hc.stat_windows;
+            o.stat_truncated = h->hc.stat_truncated;
+            o.stat_trunc_unknown = h->hc.stat_trunc_unknown;
+            o.stat_tiles = h->hc.stat_tiles;
+            o.stat_dirty_tiles = h->hc.stat_dirty_tiles;
+            o.stat_unsafe = h->hc.stat_unsafe;
+            o.stat_missed = h->hc.stat_missed;
+            o.tg_ok = (h->hc.tg_ok[0][0] != 0 && h->hc.tg_ok[1][0] != 0) ? 1 : 0;  // (a mean for the pcore kind in both slots)
+            for (int r = 0; r < CC_MAX_ROUNDS + 2; ++r) o.round_hist[r] = h->hc.round_hist[r];
+            o.prune_rows = h->hc.stat_prune_rows;
+            o.prune_full = h->hc.stat_prune_full;
+            dec = policy->after_batch(o);
+            ptrace->batch(o, dec);
+            const cc_policy_carry& k = policy->carry();
+            h->adapt_win = k.adapt_win; h->clean_batches = k.clean_batches; h->since_shrink = k.since_shrink;
+            if (dec.stalled)
+                return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
+            if (h->trace && dec.prune_rows > 0)
+                fprintf(stderr, "[cc] pruned scans of the batch%s (sample): %lld (wave, row) pairs, %.1f %% evaluated in full; points missed by guessed thresholds so far: %lld\n",
+                        h->guess_now ? ", guessed thresholds" : "", (long long)dec.prune_rows,
+                        100.0 * (double)dec.prune_full / (double)dec.prune_rows, (long long)h->hc.stat_missed);
+            pair_rows_eff += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
+            if (h->prune_now) pair_rows_pruned += (h->hc.stat_pair_rows - pair_rows_prev) / (shard_was ? (double)world : 1.0);
+            pair_rows_prev = h->hc.stat_pair_rows;
+            if (shard_was) sharded_windows += dec.wins;
+            Rcur = dec.rounds;
+            Sd = Sd_full;
+            nodirty = dec.nodirty != 0;
+            sparse_now = dec.sparse != 0;
+            shard_on = dec.shard != 0;
+            h->prune_now = dec.prune != 0;
+            h->guess_now = dec.prune == 2;
+            if (dec.restart) {
+                h->hc.win_cfg = dec.win_cfg;
+                h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);
+                set_lookahead(dec.lookahead != 0);
+                push_ctl(h);
+            }
+            if (h->trace)
+                fprintf(stderr, "[cc] %.2f ms done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
+                        now_ms() - batch_t0, done, h->hc.m_rows, (long long)dec.wins, (long long)dec.pts, (long long)dec.trunc, (long long)dec.unk, (long long)h->hc.stat_lookahead, (long long)dec.dtiles, (long long)dec.tiles,
+                        (long long)h->hc.stat_unprovable, (long long)h->hc.stat_unsafe, dec.want, Rcur);
+            batch_windows = dec.batch_windows;
+            // windows that keep stopping short on a small table: the sequential kernel takes over (and hands back
+            // if it measures slower than this batch did)
+            {
+                const bool bad = dec.bad != 0;
+                bad_batches = bad ? bad_batches + 1 : 0;
+                if (seq_mode == 0 && seq_possible() && done < N) {
+                    if (seq_probe) {
+                        // after a stint: back to the sequential kernel (for twice as long) only if the windows
+                        // are still being cut short and were measurably slower
+                        if (bad && seq_rate_last > 0.0 && win_rate < seq_rate_last) {
+                            seq_on = true;
+                            seq_stint_len = std::min<long long>(seq_stint_len * 2, 1 << 20);
+                        } else {
+                            seq_stint_len = 32768;
+                        }
+                    } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : 700.0)) {
+                        // (700 points per millisecond: what k_seq delivers whatever the data, until it has been measured
+                        // in this call; the short windows of a stream that is merely starting up run faster than that)
+                        seq_on = true;
+                    }
+                    if (seq_on) seq_stint_left = seq_stint_len;
+                }
+                seq_probe = false;
+                if (seq_mode == 2 && seq_possible() && done < N) seq_on = true;
+            }
+        }
+        return (int)CC_OK;
+    }
+
+    // statistics of the call
+    void finish()
+    {
         HIPCHK(hipEventRecord(ev1, h->stream));
         HIPCHK(hipEventSynchronize(ev1));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev0, ev1));
         h->stats.run_ms += ms;
-        h->stats.points += range_e - range_a;
+        h->stats.points += N - range_a;
         h->stats.windows += h->hc.stat_windows;
         h->stats.rounds += h->hc.stat_rounds;
         h->stats.truncated += h->hc.stat_truncated;
@@ -1829,8 +1898,38 @@ int online_range(cc_handle* h, long long range_a, long long range_e, bool no_cre
             h->stats.comm_launches += (int64_t)timed_comm.size();
             h->stats.comm_ms += ctot;
         }
+    }
+
+    int run()
+    {
+        prepare();
+        while (done < N) {
+            ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
+            const Table tab = h->tab.view();
+            if (seq_on) {
+                sequential_stint(tab);
+                continue;
+            }
+            enqueue_batch(tab);
+            const int rc = after_batch();
+            if (rc != CC_OK) return rc;
+        }
+        finish();
         return (int)CC_OK;
     }
+};
+
+// The exact windowed online phase over the resident points [range_a, range_e), in row order.  no_create: a point that
+// no MC absorbs does not create one; it is set aside (label -1, path code 8) and changes nothing - the first half of a
+// super-step of the relaxed multi-GPU mode (section 6 of DESIGN.md).  Statistics are added to h->stats.
+// resume: the range continues a stream this handle was clustering a moment ago (a later mini-batch of a timepoint): the
+// window size carries over as it is instead of restarting small.
+int online_range(cc_handle* h, long long range_a, long long range_e, bool no_create, bool resume)
+{
+    if (range_e <= range_a) return (int)CC_OK;
+    if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
+    OnlineRun run(h, range_a, range_e, no_create, resume);
+    return run.run();
 }
 
 }  // namespace

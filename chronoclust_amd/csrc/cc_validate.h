@@ -1540,7 +1540,9 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     {
         double sm[2] = {0.0, 0.0};
         int cn[2] = {0, 0};
-        for (int j = tid; j < n; j += 1024) {
+        // (every eighth point: a mean is all that is wanted, and three dependent loads per point are 15 us of a kernel
+        // the whole window waits for when every point is read)
+        for (int j = tid * 8; j < n; j += 8192) {
             const int pth = dpath[j];
             if (T[j] >= 0 && (pth == 0 || pth == 1)) {
                 const double dist = clean[(size_t)j * 4 + pth * 2].dist;

@@ -2,7 +2,7 @@
 `bench.py --steps 1 --warmup 0 --no-cpu-baseline`), per scan launch as bench.py counts them: a launch is one k_scan_u /
 clean k_scan dispatch or, when the scan is pruned, the chain k_seed -> k_seed_merge -> k_scan_p.  Records the SHA-256 of the
 kernel sources (bench.csrc_digest): bench.py only quotes the figure for the kernels it was measured on.
-Usage: pmc_summary.py <fetch_dir> <write_dir> <window> > json"""
+Usage: pmc_summary.py <fetch_dir> <write_dir> <bench line of the fetch run> <bench line of the write run> > json"""
 import glob
 import json
 import os
@@ -13,8 +13,8 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-CHAIN = ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<")
-HEADS = ("k_scan_p<", "k_scan_u<")
+CHAIN = ("k_seed<", "k_seed_merge", "k_scan_p<", "k_missed", "k_scan_u<")
+HEADS = ("k_scan_u<",)
 
 
 def totals(d, counter):
@@ -32,12 +32,18 @@ def totals(d, counter):
 
 
 if __name__ == "__main__":
-    fetch, n1 = totals(sys.argv[1], "FETCH_SIZE")
-    write, n2 = totals(sys.argv[2], "WRITE_SIZE")
+    # launches as bench.py counts (and times) them: the figure of the line each profiled run printed - a plain launch may
+    # carry a probe of the pruned chain, a pruned launch is a chain of three or five kernels
+    line1 = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
+    line2 = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    n1, n2 = int(line1["roofline"]["launches"]), int(line2["roofline"]["launches"])
+    fetch, _ = totals(sys.argv[1], "FETCH_SIZE")
+    write, _ = totals(sys.argv[2], "WRITE_SIZE")
     fetch_kb = sum(v["KB_total"] for v in fetch.values()) / max(n1, 1)
     write_kb = sum(v["KB_total"] for v in write.values()) / max(n2, 1)
-    out = {"points": 1000000, "dim": 20, "window": int(sys.argv[3]), "csrc_sha256": bench.csrc_digest(),
-           "kernel": "snapshot scan: k_seed + k_seed_merge + k_scan_p chains and k_scan_u launches", "launches": n1,
+    out = {"points": int(line1["config"]["points"]), "dim": int(line1["config"]["dim"]), "window": int(line1["config"]["window"]),
+           "csrc_sha256": bench.csrc_digest(),
+           "kernel": "snapshot scan: pruned chains (k_scan_p with guessed thresholds + k_missed + k_seed / k_seed_merge / k_scan_p for the missed points, or the seeded chain for the whole window) and k_scan_u launches", "launches": n1,
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "k_scan_clean_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
            "per_kernel_FETCH_SIZE": fetch, "per_kernel_WRITE_SIZE": write,

@@ -32,10 +32,14 @@ def full_launches(d, pat):
     t = df.groupby("Dispatch_Id").agg(s=("Start_Timestamp", "first"), e=("End_Timestamp", "first"), grid=("Grid_Size", "first"))
     g["us"] = (t["e"] - t["s"]) / 1e3
     g["grid"] = t["grid"]
-    # the full-window launches: the most frequent grid, and of those the typical ones - within a factor of 1.5 of the
-    # median duration (a launch whose window was scanned ahead returns at once; the launches of the build-up run, where
-    # every other row still survives its prefix, take several times as long as the steady state's)
-    common = g[g["grid"] == g["grid"].mode().iloc[0]]
+    # the full-window launches: the largest grid that at least a tenth of the dispatches have (k_scan_p also runs on small
+    # grids - the points a guessed threshold missed, probes -, k_seed / k_seed_merge in the steady state ONLY on those:
+    # their figures are then what a window really spends on them), and of those the typical ones - within a factor of
+    # 1.5 of the median duration (a launch whose window was scanned ahead returns at once; the launches of the build-up
+    # run, where every other row still survives its prefix, take several times as long as the steady state's)
+    counts = g["grid"].value_counts()
+    big = max(k for k, v in counts.items() if v >= max(1, len(g) // 10))
+    common = g[g["grid"] == big]
     med = common["us"].median()
     full = common[(common["us"] > med / 1.5) & (common["us"] < med * 1.5)]
     return full.mean(), int(len(full))

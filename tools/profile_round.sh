@@ -36,7 +36,7 @@ fi
 if want traffic; then
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o r -- $B --steps 1 --warmup 0 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o r -- $B --steps 1 --warmup 0 > $OUT/pmc_write.json 2> $OUT/pmc_write.err || exit 1
-python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $(python -c "import json;print(json.load(open('$OUT/pmc_fetch.json'))['config']['window'])") > $OUT/pmc_traffic.json
+python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_fetch.json $OUT/pmc_write.json > $OUT/pmc_traffic.json
 echo "pmc traffic done"
 fi
 if want valu; then

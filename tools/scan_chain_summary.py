@@ -16,7 +16,7 @@ df = pd.read_csv(f)
 df["dur"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
 name = df["Kernel_Name"]
 parts = {"k_seed": name.str.contains("k_seed<"), "k_seed_merge": name.str.contains("k_seed_merge"),
-         "k_scan_p": name.str.contains("k_scan_p<"), "k_scan_u": name.str.contains("k_scan_u<"),
+         "k_scan_p": name.str.contains("k_scan_p<"), "k_missed": name.str.contains("k_missed"), "k_scan_u": name.str.contains("k_scan_u<"),
          "k_scan (LDS-staged, clean)": name.str.contains(r"k_scan<\d+, (?:true|false), (?:true|false), false", regex=True)}
 out = {"kernels": {}}
 total = 0.0
@@ -25,7 +25,15 @@ for k, m in parts.items():
     if len(g):
         out["kernels"][k] = {"calls": int(len(g)), "total_ms": float(g["dur"].sum() / 1e3), "avg_us": float(g["dur"].mean())}
         total += float(g["dur"].sum())
-chains = sum(out["kernels"].get(k, {}).get("calls", 0) for k in ("k_scan_p", "k_scan_u", "k_scan (LDS-staged, clean)"))
+# launches as bench.py times them: a plain scan (which may carry a probe of the pruned chain: three small kernels more) or
+# a pruned chain - seeded for the window, or a guessed-threshold scan + k_missed + the seeded chain for the missed points.
+# Every seeded chain has one k_seed_merge: a pruned launch's (the window's, or the missed points' behind k_missed) or a
+# probe's; a probe's k_seed splits the rows over 128 workgroups per point tile (grid y), a launch's over at most 16.
+ks = df[parts["k_seed"]]
+probes = int((ks["Grid_Size_Y"] > 64).sum()) if len(ks) else 0
+out["probes"] = probes
+chains = out["kernels"].get("k_seed_merge", {}).get("calls", 0) - probes + \
+    sum(out["kernels"].get(k, {}).get("calls", 0) for k in ("k_scan_u", "k_scan (LDS-staged, clean)"))
 out["scan_chains"] = chains
 out["rocprof_avg_chain_us"] = total / chains if chains else None
 line = json.load(open(sys.argv[2]))
