@@ -471,8 +471,15 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
             }
         }
     }
+    // the tile as a whole: when no point of it needs a row that only a dirty scan covers - even the largest displacement
+    // of every class stays below the point's threshold, for the stages the point is expected to evaluate -, the tile's
+    // dirty scan is not run at all
+    const unsigned long long any_v = __builtin_amdgcn_ballot_w64(need_ver), any_c = __builtin_amdgcn_ballot_w64(need_car);
     if (j < B) {
-        if (flag_n1skip) { tau_w[1] = CC_INF; flag_word |= CC_FLAG_N1SKIP; }
+        // (the outlier-kind threshold is only withheld where that spares the tile its scans: in a tile whose scans run
+        // anyway every point gets both kinds covered, and a point whose stage 0 fails against expectation is decided
+        // all the same - on overlapping data that happens all the time while the table is young)
+        if (flag_n1skip && any_v == 0ull && any_c == 0ull) { tau_w[1] = CC_INF; flag_word |= CC_FLAG_N1SKIP; }
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) ver.tau[(size_t)j * CC_TAU_STRIDE + kd] = tau_w[kd];
         ver.unsafe[j] = flag_word;
@@ -483,10 +490,6 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
         if (threadIdx.x == 0 && b1) atomicAdd((unsigned long long*)&ctl->stat_unprovable, (unsigned long long)__builtin_popcountll(b1));
         if (threadIdx.x == 0 && b2) atomicAdd((unsigned long long*)&ctl->stat_unsafe, (unsigned long long)__builtin_popcountll(b2));
     }
-    // the tile as a whole: when no point of it needs a row that only a dirty scan covers - even the largest displacement
-    // of every class stays below the point's threshold, for the stages the point is expected to evaluate -, the tile's
-    // dirty scan is not run at all
-    const unsigned long long any_v = __builtin_amdgcn_ballot_w64(need_ver), any_c = __builtin_amdgcn_ballot_w64(need_car);
     if (threadIdx.x == 0) {
         ver.skip[blockIdx.x] = any_v == 0ull ? 1 : 0;  // (k_commit_a counts the tiles of the last round for the host's window policy)
         ver.skip_car[blockIdx.x] = (!la_mode || any_c == 0ull) ? 1 : 0;
