@@ -145,7 +145,8 @@ struct cc_handle {
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
-    DevBuf<unsigned long long> pstat; // [2][2]     a split pruned scan's sample {rows visited, rows completed} per window parity
+    // a pruned scan's sample {rows visited, rows completed} per window parity: Ctl::pstat, as the kernels take it
+    unsigned long long* pstat_p() const { return (unsigned long long*)((char*)ctl.p + offsetof(Ctl, pstat)); }
     size_t spart_stride = 0, thr_stride = 0;
     bool trace = false;     // CHRONOCLUST_HIP_TRACE=1: one stderr line per batch of windows
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
@@ -211,6 +212,7 @@ struct cc_handle {
     long long shard_min_row_dims = 400000;
     int offline_shard_min_rows = 8192;  // the pair matrices of the offline phase / association tracker likewise
     DevBuf<Cand> gsend, gpart;  // one merged record per window point (two parities) / the gathered records of all ranks
+    DevBuf<Cand> gsend2, gpart2;  // guessed thresholds in a group: the missed points' new records, compact / gathered
     size_t gsend_stride = 0, gpart_stride = 0;
     DevBuf<int> g_i32;          // gather scratch of the offline phase
 
@@ -378,7 +380,14 @@ void refresh_ctl_params(cc_handle* h)
     c.d = h->d;
 }
 
-void push_ctl(cc_handle* h) { HIPCHK(hipMemcpyAsync(h->ctl.p, &h->hc, sizeof(Ctl), hipMemcpyHostToDevice, h->stream)); }
+// (Every push opens a fresh window chain - start of a call, back from the sequential kernel, a restart -: whatever scans
+// left per window parity belongs to windows that will be scanned again, and the host's copy of it may be a half-summed one.)
+void push_ctl(cc_handle* h)
+{
+    memset(h->hc.pstat, 0, sizeof(h->hc.pstat));
+    h->hc.n_missed_all[0] = h->hc.n_missed_all[1] = 0;
+    HIPCHK(hipMemcpyAsync(h->ctl.p, &h->hc, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
+}
 void pull_ctl(cc_handle* h)
 {
     HIPCHK(hipMemcpyAsync(&h->hc, h->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
@@ -446,7 +455,6 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->thr.ensure(2 * h->thr_stride);
     h->thr32.ensure(2 * h->thr_stride);
     h->cmax.ensure(2);
-    h->pstat.ensure(4);
     h->found.ensure(2 * (CC_MAX_WINDOW / 64));
     h->missed.ensure(2 * CC_MISSED_CAP);
     h->part.ensure(2 * h->part_stride); h->dpart.ensure(w * seg * 2); h->dpart2.ensure(w * seg * 2);
@@ -505,7 +513,7 @@ bool scan_u_applies(const cc_handle* h, int DP) { return h->allow_scan_u && h->h
 
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                    int mode, int shard_rank, int shard_world)
+                    int mode, int shard_rank, int shard_world, int phase)
 {
     constexpr int NW = ScanShape<DP, DIRTY>::NW;
     const dim3 block(64 * NW);
@@ -531,24 +539,44 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                            rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p, plist);
                         hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * n_pts + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
                                            rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
-                                           h->prune_F, round, mode, h->cmax.p, h->pstat.p, plist);
+                                           h->prune_F, round, mode, h->cmax.p, h->pstat_p(), plist);
                         // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
                         // that every rank abandons against the same T -, phases A / B over the rank's own rows)
                         hipLaunchKernelGGL((k_scan_p<DP, NW>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                            rows.scl, rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           part_stride, shard_rank, shard_world, h->pstat.p, plist, 0.0,
+                                           part_stride, shard_rank, shard_world, h->pstat_p(), plist, 0.0,
                                            (unsigned long long*)nullptr);
                 };
+                if (phase == 1) {
+                    // guessed thresholds on the exact multi-GPU path, after the ranks' records were gathered: the points
+                    // whose merged pcore list starts with a bound (k_missed_g: the same list on every rank) go through the
+                    // seeded chain - seeds over all rows on every rank, phases A / B over the rank's rows
+                    hipLaunchKernelGGL(k_missed_g, dim3(1), dim3(1024), 0, st, h->ctl.p, (const Cand*)h->gpart.p, h->gpart_stride,
+                                       (size_t)win * 4 + 4, shard_world, h->missed.p, CC_MISSED_CAP, round, mode, h->found.p);
+                    seeded_chain(CC_MISSED_CAP, h->missed.p, part, h->part_stride, S);
+                    return;
+                }
                 if (h->prune_now) {
                     ++h->stats.scan_p_launches;
-                    if (h->guess_now && shard_world == 1) {
+                    if (h->guess_now && shard_world > 1) {
+                        // (split over ranks: every rank scans its rows against the same guess; who was missed is only known
+                        // once the records are gathered - phase 1, enqueued by the caller behind the all-gather)
+                        ++h->stats.scan_g_launches;
+                        hipLaunchKernelGGL(k_pstat_zero, dim3(1), dim3(2), 0, st, (const Ctl*)h->ctl.p, h->pstat_p(), round, mode);
+                        hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                           rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
+                                           h->part_stride, shard_rank, shard_world, h->pstat_p(), (const int*)nullptr,
+                                           h->prune_F, h->found.p);
+                        return;
+                    }
+                    if (h->guess_now) {
                         // guessed thresholds: one scan, the list of the points it missed, the seeded chain for those
                         // (list of the window's parity: the lookahead scan of the next window fills the other one)
                         ++h->stats.scan_g_launches;
                         int* const list = h->missed.p;  // (the kernels take the half of the window's parity)
                         hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                            rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           h->part_stride, 0, 1, h->pstat.p, (const int*)nullptr, h->prune_F, h->found.p);
+                                           h->part_stride, 0, 1, h->pstat_p(), (const int*)nullptr, h->prune_F, h->found.p);
                         hipLaunchKernelGGL(k_missed, dim3(1), dim3(1024), 0, st, h->ctl.p, h->found.p, list, CC_MISSED_CAP, round, mode);
                         seeded_chain(CC_MISSED_CAP, list, part, h->part_stride, S);
                         return;
@@ -593,10 +621,10 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
 // dirty scan: mode 0 = version rows, 1 = carry set.
 template <bool DIRTY>
 void launch_scan(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
-                 int mode, int shard_rank = 0, int shard_world = 1)
+                 int mode, int shard_rank = 0, int shard_world = 1, int phase = 0)
 {
     const int d = h->d;
-#define CC_SCAN_DP(DP) launch_scan_dp<DP, DIRTY>(h, st, win, rows, clean, part, S, round, mode, shard_rank, shard_world)
+#define CC_SCAN_DP(DP) launch_scan_dp<DP, DIRTY>(h, st, win, rows, clean, part, S, round, mode, shard_rank, shard_world, phase)
     // (padded dimensions cost full distance terms: the ladder follows the shapes of BASELINE.json - d = 14, 20, 40)
     if (d <= 4) CC_SCAN_DP(4);
     else if (d <= 8) CC_SCAN_DP(8);
@@ -1405,6 +1433,8 @@ struct OnlineRun {
             h->gpart_stride = (size_t)world * (gmax * 4 + 4);
             h->gsend.ensure(2 * h->gsend_stride);
             h->gpart.ensure(2 * h->gpart_stride);
+            h->gsend2.ensure((size_t)2 * CC_MISSED_CAP * 4);  // (per window parity, like the lists they serve)
+            h->gpart2.ensure((size_t)2 * world * CC_MISSED_CAP * 4);
         }
         // every window of a batch may create one MC per point: rows for the largest batch that can be enqueued
         batch_max = (size_t)std::max(2, h->tun.windows_per_sync);
@@ -1470,7 +1500,6 @@ struct OnlineRun {
         // no carry set yet: the commit record of an earlier call describes rows that may have moved since
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
-        HIPCHK(hipMemsetAsync(h->pstat.p, 0, 4 * sizeof(unsigned long long), h->stream));
         HIPCHK(hipMemsetAsync(h->found.p, 0, h->found.n * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
@@ -1650,9 +1679,25 @@ struct OnlineRun {
                     if (timing) HIPCHK(hipEventRecord(get_event(h, ev_used), st));
                     hipLaunchKernelGGL(k_merge_partials, dim3((gw + 255) / 256), dim3(256), 0, st, h->ctl.p, h->part.p,
                                        h->part_stride, S, h->gsend.p, h->gsend_stride, round, mode,
-                                       (const unsigned long long*)(h->prune_now && sworld > 1 ? h->pstat.p : nullptr), gw * 4);
+                                       (const unsigned long long*)h->pstat_p(), gw * 4,
+                                       (const int*)nullptr);
                     h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
                                        ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
+                    if (h->prune_now && h->guess_now && sworld > 1) {
+                        // guessed thresholds: the points no rank found a pcore MC for (a function of the gathered records:
+                        // the same list everywhere) go through the seeded chain on every rank's rows, their new records
+                        // are exchanged in a second, small all-gather of fixed size and take the place of the old ones
+                        launch_scan<false>(h, st, gw, rws, nullptr, h->part.p, S, round, mode, srank, sworld, 1);
+                        Cand* const send2 = h->gsend2.p + (size_t)q * CC_MISSED_CAP * 4;
+                        Cand* const recv2 = h->gpart2.p + (size_t)q * sworld * CC_MISSED_CAP * 4;
+                        hipLaunchKernelGGL(k_merge_partials, dim3((CC_MISSED_CAP + 255) / 256), dim3(256), 0, st, h->ctl.p,
+                                           h->part.p, h->part_stride, S, send2, (size_t)0, round, mode,
+                                           (const unsigned long long*)nullptr, 0, (const int*)h->missed.p);
+                        h->comm.all_gather(send2, recv2, (size_t)CC_MISSED_CAP * 4 * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
+                        hipLaunchKernelGGL(k_scatter_missed, dim3((CC_MISSED_CAP * sworld + 255) / 256), dim3(256), 0, st,
+                                           (const Ctl*)h->ctl.p, (const int*)h->missed.p, (const Cand*)recv2, sworld,
+                                           h->gpart.p, h->gpart_stride, (size_t)gw * 4 + 4, round, mode);
+                    }
                     if (timing) {
                         HIPCHK(hipEventRecord(get_event(h, ev_used + 1), st));
                         timed_comm.push_back(ev_used);

@@ -96,9 +96,10 @@ struct LocalGroup {
     unsigned long long generation = 0;
     bool broken = false;
     std::vector<const void*> send;
+    std::vector<size_t> bytes;            // what each rank brought to the current exchange (must agree)
     std::vector<hipEvent_t> ready, done;  // owned by the ranks that record them
 
-    explicit LocalGroup(int w) : world(w), send(w, nullptr), ready(w, nullptr), done(w, nullptr) {}
+    explicit LocalGroup(int w) : world(w), send(w, nullptr), bytes(w, 0), ready(w, nullptr), done(w, nullptr) {}
 
     void barrier()
     {
@@ -222,9 +223,18 @@ struct Comm {
         };
         chk(hipEventRecord(ev_ready, st), "hipEventRecord");
         g.send[rank] = send;
+        g.bytes[rank] = bytes;
         g.ready[rank] = ev_ready;
         g.done[rank] = ev_done;
         g.barrier();
+        // the ranks run the same sequence of exchanges (their policies read the same counters): one that arrives with
+        // another block size is out of step, and copying its block would read past a buffer
+        for (int p = 0; p < world; ++p)
+            if (g.bytes[p] != bytes) {
+                g.abandon();
+                throw CommErr{"ranks out of step: rank " + std::to_string(p) + " exchanges " + std::to_string(g.bytes[p]) +
+                              " bytes, rank " + std::to_string(rank) + " " + std::to_string(bytes)};
+            }
         for (int p = 0; p < world; ++p) {
             if (p != rank) chk(hipStreamWaitEvent(st, g.ready[p], 0), "hipStreamWaitEvent");
             char* dst = (char*)recv + (size_t)p * bytes;

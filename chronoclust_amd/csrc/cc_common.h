@@ -216,6 +216,14 @@ struct Ctl {
     unsigned long long cen_absmax;   // bits of the largest |centroid coordinate| in the table at the start of the call
     double x_absmax;                 // the largest |coordinate| of the resident points (host, from the upload)
     long long stat_missed;
+    // What the scan kernels count per window parity - they may run on the lookahead stream, whose progress the host does
+    // not wait for before it reads this block - and k_decide (round 0 of that window, main stream) moves into the counters
+    // the window policy reads, so that those are a function of the windows validated so far and nothing else:
+    // pstat[q] = {(wave, row) pairs visited, pairs completed} of the window's pruned scan (k_scan_p's sample; on the exact
+    // multi-GPU path it travels with the rank's records instead, k_merge_partials), n_missed_all[q] = points its guessed
+    // thresholds missed (k_missed / k_missed_g; not cut at the list's capacity).
+    unsigned long long pstat[2][2];
+    int n_missed_all[2];
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against

@@ -197,11 +197,11 @@ public:
         prune_on_ = prune_next;
         probe_gate_ = grew == 0 && !unpruned && want >= std::min(8192, c_.window);
         // Guessed thresholds (k_scan_p with Ctl::tg instead of k_seed + k_seed_merge, which cost as much as the scan they
-        // serve): while a mean join distance exists, the scan is not split over ranks (the list of missed points would
-        // have to be agreed on across them) and few points are missed - more than one in sixteen: back to seeds for 2^18 points
+        // serve): while a mean join distance exists and few points are missed - more than one in sixteen: back to seeds
+        // for 2^18 points.  (Split over ranks as well: the list of missed points is derived from the gathered records.)
         const long long missed = o.stat_missed - prev_.stat_missed;
         if (guess_on_ && pts > 0 && missed * 16 > pts) guess_resume_at_ = o.cursor + (1ll << 18);
-        guess_on_ = prune_on_ && !shard_on_ && c_.allow_guess != 0 && o.tg_ok != 0 && o.cursor >= guess_resume_at_;
+        guess_on_ = prune_on_ && c_.allow_guess != 0 && o.tg_ok != 0 && o.cursor >= guess_resume_at_;
         const bool more = done < c_.n_end;
         const int restart = ((want != win_cfg_ || want_la != la_on_ || o.stall_b > 0 || shard_flip || prune_flip) && more) ? 1 : 0;
         if (restart) {

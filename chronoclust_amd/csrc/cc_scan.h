@@ -1464,11 +1464,9 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // A split scan's sample describes this rank's rows only, and the host policy that reads the counters has to decide
     // alike on every rank: the sample then goes to the window's own pair of counters, travels with the rank's candidate
     // records (k_merge_partials) and k_decide adds up what all ranks sent - the same sum everywhere.
-    if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
-        unsigned long long* const rows_to = shard_world > 1 ? pstat + win.q * 2 : &ctl->stat_prune_rows;
-        unsigned long long* const full_to = shard_world > 1 ? pstat + win.q * 2 + 1 : &ctl->stat_prune_full;
-        atomicAdd(rows_to, (unsigned long long)n_rows);
-        atomicAdd(full_to, (unsigned long long)n_full);
+    if (lane == 0 && blockIdx.x == 0 && n_rows > 0 && !(plist != nullptr && shard_world > 1)) {
+        atomicAdd(pstat + win.q * 2, (unsigned long long)n_rows);
+        atomicAdd(pstat + win.q * 2 + 1, (unsigned long long)n_full);
     }
 
     // the survivors' list-order keys; every kind's pair then takes in the bound of what the wave abandoned; the waves'
@@ -1564,7 +1562,7 @@ __global__ __launch_bounds__(1024) void k_missed(Ctl* __restrict__ ctl, unsigned
     }
     if (tid == 0) {
         ctl->n_missed[win.q] = total < cap ? total : cap;
-        ctl->stat_missed += total;
+        ctl->n_missed_all[win.q] = total;  // (k_decide adds it to Ctl::stat_missed)
     }
 }
 
@@ -1580,7 +1578,8 @@ __global__ __launch_bounds__(1024) void k_missed(Ctl* __restrict__ ctl, unsigned
 __global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ ctl, const Cand* __restrict__ part,
                                                         size_t part_stride, int S, Cand* __restrict__ out,
                                                         size_t out_stride, int round, int mode,
-                                                        const unsigned long long* __restrict__ pstat, int tail_at)
+                                                        const unsigned long long* __restrict__ pstat, int tail_at,
+                                                        const int* __restrict__ plist)
 {
     int B, q;
     if (mode == 1) {
@@ -1590,7 +1589,27 @@ __global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ 
         q = (int)(ctl->window_seq & 1ull);
         B = ctl->win_b;
     }
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (plist != nullptr) {
+        // the points a guessed-threshold scan missed (k_missed_g's list): their new partials -> one record each, COMPACT
+        // (record e = the list's e-th point), the unit of the second, small all-gather; no parity offset, no tail
+        if (B == 0 || j >= ctl->n_missed[q]) return;
+        const int e = j;
+        j = plist[(size_t)q * CC_MISSED_CAP + e];
+        part += (size_t)q * part_stride;
+        const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
+        Cand p1 = none, p2 = none, o1 = none, o2 = none;
+        for (int s2 = 0; s2 < S; ++s2) {
+            const Cand* c = part + ((size_t)j * S + s2) * 4;
+            cc_top2_push(p1, p2, c[0]);
+            cc_top2_push(p1, p2, c[1]);
+            cc_top2_push(o1, o2, c[2]);
+            cc_top2_push(o1, o2, c[3]);
+        }
+        Cand* o = out + (size_t)e * 4;
+        o[0] = p1; o[1] = p2; o[2] = o1; o[3] = o2;
+        return;
+    }
     // the record behind the last point's: this rank's sample of its pruned scan (k_scan_p), {rows visited, rows completed},
     // zeros after a plain scan - gathered with the candidates, summed over the ranks by k_decide
     if (j == 0) {
@@ -1612,4 +1631,93 @@ __global__ __launch_bounds__(256) void k_merge_partials(const Ctl* __restrict__ 
     }
     Cand* o = out + (size_t)j * 4;
     o[0] = p1; o[1] = p2; o[2] = o1; o[3] = o2;
+}
+
+// ---------------------------------------------------------------------------------
+// Guessed thresholds on the exact multi-GPU path.  Every rank scanned its share of the rows against the same guess; whether a
+// point's own MC was found is only known once the ranks' records are gathered: k_missed_g lists the points whose merged
+// pcore list starts with a bound (the same list on every rank: it is a function of the gathered records), the seeded chain
+// runs for them (seeds over all rows, replicated - they are few -, phases A / B over the rank's rows), k_merge_partials
+// packs their new records compactly, a second, small all-gather (CC_MISSED_CAP records per rank) exchanges those, and
+// k_scatter_missed puts every rank's new record in the place of the old one in the gathered buffer k_decide reads.
+// ---------------------------------------------------------------------------------
+// the sample counters of a split scan with guessed thresholds start at zero (the seeded chain: k_seed_merge does it)
+__global__ void k_pstat_zero(const Ctl* __restrict__ ctl, unsigned long long* __restrict__ pstat, int round, int mode)
+{
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    if (win.B == 0) return;
+    pstat[win.q * 2 + threadIdx.x] = 0ull;
+}
+
+__global__ __launch_bounds__(1024) void k_missed_g(Ctl* __restrict__ ctl, const Cand* __restrict__ gpart, size_t gpart_stride,
+                                                   size_t outer, int world, int* __restrict__ list, int cap, int round, int mode,
+                                                   unsigned long long* __restrict__ found)
+{
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;  // (mode 0 and the window was scanned ahead: that pass's list stands, the chain after it is idle)
+    gpart += (size_t)win.q * gpart_stride;
+    list += (size_t)win.q * CC_MISSED_CAP;
+    const int tid = threadIdx.x;
+    // (the scan's own marks are not what decides here; cleared for a later unsplit use of them)
+    for (int t = tid; t < (B + 63) / 64; t += 1024) found[(size_t)win.q * (CC_MAX_WINDOW / 64) + t] = 0ull;
+    const int per = (B + 1023) >> 10;
+    auto missed = [&](int j) -> bool {
+        Cand best = Cand{CC_INF, CC_IDX_INF, -1};
+        for (int r = 0; r < world; ++r) {
+            const Cand c = gpart[(size_t)r * outer + (size_t)j * 4];
+            if (c.slot != -1 && (best.slot == -1 || cand_less(c.dist, c.key, best.dist, best.key))) best = c;
+        }
+        return best.slot == CC_SLOT_BOUND;
+    };
+    int mine = 0;
+    for (int k = 0; k < per; ++k) {
+        const int j = tid * per + k;
+        if (j < B && missed(j)) ++mine;
+    }
+    __shared__ int wsum[16];
+    __shared__ int total;
+    int v = mine;
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    if (lane == 63) wsum[wid] = v;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 16; ++i) { const int x = wsum[i]; wsum[i] = run; run += x; }
+        total = run;
+    }
+    __syncthreads();
+    int pos = v - mine + wsum[wid];
+    for (int k = 0; k < per; ++k) {
+        const int j = tid * per + k;
+        if (j < B && missed(j)) {
+            if (pos < cap) list[pos] = j;
+            ++pos;
+        }
+    }
+    if (tid == 0) {
+        ctl->n_missed[win.q] = total < cap ? total : cap;
+        ctl->n_missed_all[win.q] = total;  // (k_decide adds it to Ctl::stat_missed)
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_missed(const Ctl* __restrict__ ctl, const int* __restrict__ list,
+                                                        const Cand* __restrict__ gathered, int world, Cand* __restrict__ gpart,
+                                                        size_t gpart_stride, size_t outer, int round, int mode)
+{
+    int q;
+    if (mode == 1) q = round & 1;
+    else q = (int)(ctl->window_seq & 1ull);
+    const int n = ctl->n_missed[q];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int e = t / world, r = t - e * world;
+    if (e >= n) return;
+    const int j = list[(size_t)q * CC_MISSED_CAP + e];
+    const Cand* src = gathered + ((size_t)r * CC_MISSED_CAP + e) * 4;
+    Cand* dst = gpart + (size_t)q * gpart_stride + (size_t)r * outer + (size_t)j * 4;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
 }

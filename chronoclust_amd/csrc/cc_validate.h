@@ -579,17 +579,27 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     if (B == 0) return;
     // exact multi-GPU path: the ranks' samples of their split pruned scans (the record behind each rank's candidates,
     // k_merge_partials) add up to the counters the host policy reads - the same sum on every rank
-    if (round == 0 && stat_tail >= 0 && blockIdx.x == 0 && threadIdx.x == 0) {
-        const Cand* g = part + (size_t)(ctl->window_seq & 1ull) * part_stride + (size_t)stat_tail;
+    // ... and a single GPU's own sample, and the count of points a guessed threshold missed: left per window parity by
+    // kernels that may have run on the lookahead stream (Ctl::pstat, Ctl::n_missed_all), taken over here
+    if (round == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int q = (int)(ctl->window_seq & 1ull);
         unsigned long long rows = 0ull, full = 0ull;
-        for (int r = 0; r < S; ++r) {
-            rows += (unsigned long long)(unsigned)g[(size_t)r * part_outer].key;
-            full += (unsigned long long)(unsigned)g[(size_t)r * part_outer].slot;
+        if (stat_tail >= 0) {
+            const Cand* g = part + (size_t)q * part_stride + (size_t)stat_tail;
+            for (int r = 0; r < S; ++r) {
+                rows += (unsigned long long)(unsigned)g[(size_t)r * part_outer].key;
+                full += (unsigned long long)(unsigned)g[(size_t)r * part_outer].slot;
+            }
+        } else {
+            rows = ctl->pstat[q][0];
+            full = ctl->pstat[q][1];
         }
-        if (rows > 0ull) {
-            atomicAdd(&ctl->stat_prune_rows, rows);
-            atomicAdd(&ctl->stat_prune_full, full);
-        }
+        ctl->pstat[q][0] = 0ull;
+        ctl->pstat[q][1] = 0ull;
+        ctl->stat_prune_rows += rows;
+        ctl->stat_prune_full += full;
+        ctl->stat_missed += ctl->n_missed_all[q];
+        ctl->n_missed_all[q] = 0;
     }
     if (round > 0 && ctl->fc[round - 1] >= B) return;
     const int gl = threadIdx.x & 31;

@@ -216,3 +216,35 @@ def test_pruned_and_split_in_the_steady_state(world):
         assert st["sharded_windows"] > 0 and 0 < st["scan_p_launches"] < st["scan_u_launches"]
         assert 0 < st["pruned_scan_full_rows"] < 0.2 * st["pruned_scan_rows"]
     assert len({(r[0]["stats"]["pruned_scan_rows"], r[0]["stats"]["pruned_scan_full_rows"], r[0]["stats"]["windows"]) for r in res}) == 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_guessed_thresholds_in_a_group_miss_a_loose_population(world):
+    """The stream of tests/test_pruned_scan.py::test_guessed_thresholds_miss_a_loose_population with every scan split:
+    each rank scans its rows against the same guessed thresholds, the list of missed points is derived from the gathered
+    records (the same list on every rank), the seeded chain runs for those points and their new records travel in a
+    second, small all-gather - at times more points are missed than the list holds.  The single-GPU results on every
+    rank, and the same counters everywhere (the ranks' policies must keep deciding alike)."""
+    rng = np.random.default_rng(31)
+    n, d, g = 60_000, 20, 300
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    sig = np.where(np.arange(g) < 240, 0.004, 0.03)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.25))
+    Xs = []
+    for _ in range(3):
+        lab = rng.integers(0, g, n)
+        Xs.append(np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 1.0, (n, d)) * sig[lab, None], 0.0, 1.0)))
+    single = P.run_pipeline(Xs, cfg)
+    res = run_group(world, Xs, cfg, tuning=dict(window=8192), env=dict(CHRONOCLUST_HIP_PRUNE=2))
+    for r in res:
+        P.same_results(r, single)
+    per_rank = [[(s["stats"]["scan_g_launches"], s["stats"]["missed_points"], s["stats"]["windows"],
+                  s["stats"]["sharded_windows"]) for s in r] for r in res]
+    assert all(p == per_rank[0] for p in per_rank)
+    assert sum(x[0] for x in per_rank[0]) > 0 and sum(x[1] for x in per_rank[0]) > 0
+    assert all(x[2] == x[3] for x in per_rank[0])
+    # and with the guesses switched off: seeds for every point, the same results
+    off = run_group(world, Xs, cfg, tuning=dict(window=8192), env=dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_GUESS=0))
+    for r in off:
+        P.same_results(r, single)
+        assert all(s["stats"]["scan_g_launches"] == 0 for s in r)

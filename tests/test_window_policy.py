@@ -84,8 +84,10 @@ def test_the_traces_cover_the_regimes():
     # round 4: a group no longer trades the pruned scan for the row split - at the stress config's table shape the
     # ranks split their scans from early on and prune them once the table has settled
     c5 = by_name["group_c5_shape_keeps_pruning"][0]
-    both = [d for _, d in c5[4] if d["shard"] == 1 and d["prune"] == 1]
+    both = [d for _, d in c5[4] if d["shard"] == 1 and d["prune"] != 0]
     assert both and c5[4][-1][1]["shard"] == 1  # (24 points per microcluster: the stream ends before it has settled)
+    # ... with guessed thresholds too (prune 2): the ranks agree on the missed points from the gathered records
+    assert any(d["shard"] == 1 and d["prune"] == 2 for _, d in c5[4])
     assert any(o["prune_rows"] > 0 for o, _ in c5[4])  # (the gathered samples of the ranks' split pruned scans)
 
 
