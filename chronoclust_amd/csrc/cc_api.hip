@@ -152,6 +152,7 @@ struct cc_handle {
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
+    bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
     int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
     DevBuf<int> sp_list;        // [window] the round's list of points for the sparse dirty scans
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
@@ -804,6 +805,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* sr = getenv("CHRONOCLUST_HIP_SEQR");
+        h->allow_seq_r = !(sr && sr[0] == '0');
         const char* pb = getenv("CHRONOCLUST_HIP_PROBE");
         h->allow_probe = !(pb && pb[0] == '0');
         const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
@@ -1378,6 +1381,9 @@ struct OnlineRun {
     {
         return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }
+    // points per ms the sequential kernel is assumed to manage before it has been measured in this call (k_seq on its LDS
+    // image: ~0.9 us per point; k_seq_r, rows in registers, d <= 4: ~0.6 us)
+    double seq_rate_guess() const { return (h->allow_seq_r && h->d >= 2 && h->d <= 4) ? 1500.0 : 700.0; }
     bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; }
 
     // lookahead (re)start: the current window is a fresh one (scanned in place), the lookahead scan enqueued next covers
@@ -1483,6 +1489,7 @@ struct OnlineRun {
         c.stat_trunc_unknown = 0;
         c.stat_table_rows = 0;
         c.stat_seq_points = 0;
+        c.stat_seq_r_points = 0;
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
         c.stat_missed = 0;
@@ -1548,7 +1555,19 @@ struct OnlineRun {
         const double t0 = now_ms();
         {
             const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
-#define CC_SEQ(F, P) hipLaunchKernelGGL((k_seq<F, P>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk)
+            // d <= 4: the register-resident kernel first; what it cannot hold (Ctl::seq_rest) is left to the LDS kernel
+            int follow = 0;
+#define CC_SEQR(D) do { \
+                if (p2) hipLaunchKernelGGL((k_seq_r<D, true>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk); \
+                else hipLaunchKernelGGL((k_seq_r<D, false>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk); \
+                follow = 1; } while (0)
+            if (h->allow_seq_r) {
+                if (h->d == 2) CC_SEQR(2);
+                else if (h->d == 3) CC_SEQR(3);
+                else if (h->d == 4) CC_SEQR(4);
+            }
+#undef CC_SEQR
+#define CC_SEQ(F, P) hipLaunchKernelGGL((k_seq<F, P>), dim3(1), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk, follow)
             if (f && p2) CC_SEQ(true, true);
             else if (f) CC_SEQ(true, false);
             else if (p2) CC_SEQ(false, true);
@@ -1879,7 +1898,7 @@ struct OnlineRun {
                         } else {
                             seq_stint_len = 32768;
                         }
-                    } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : 700.0)) {
+                    } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : seq_rate_guess())) {
                         // (700 points per millisecond: what k_seq delivers whatever the data, until it has been measured
                         // in this call; the short windows of a stream that is merely starting up run faster than that)
                         seq_on = true;
@@ -1910,6 +1929,7 @@ struct OnlineRun {
         h->stats.scan_pair_dims_pruned += pair_rows_pruned * (double)h->d;
         h->stats.sharded_windows += sharded_windows;
         h->stats.seq_points += h->hc.stat_seq_points;
+        h->stats.seq_r_points += h->hc.stat_seq_r_points;
         h->seq_sticky = seq_on;
         h->stats.table_rows_scanned += h->hc.stat_table_rows;
         h->stats.lookahead_windows += h->hc.stat_lookahead;

@@ -224,6 +224,9 @@ struct Ctl {
     // thresholds missed (k_missed / k_missed_g; not cut at the list's capacity).
     unsigned long long pstat[2][2];
     int n_missed_all[2];
+    int seq_rest;  // k_seq_r -> k_seq: points of the stint the register kernel left (its capacity was reached, or the table did not fit)
+    int pad3;
+    long long stat_seq_r_points;  // of stat_seq_points: taken by k_seq_r
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against

@@ -218,6 +218,7 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 // The kernels of the online phase, by stage (all of them see the helpers above):
 #include "cc_scan.h"      // snapshot scans and dirty scans
 #include "cc_validate.h"  // k_dseed, k_decide, k_claims, k_chain, k_chain_long, k_commit_a / b
-#include "cc_seq.h"       // the sequential kernel
+#include "cc_seq.h"       // the sequential kernel (table in LDS)
+#include "cc_seq_r.h"     // ... and with the table in registers, for d <= 4 and a few hundred rows
 #include "cc_relaxed.h"   // relaxed multi-GPU mode
 #include "cc_points.h"    // transposed copy, finiteness check, scaler

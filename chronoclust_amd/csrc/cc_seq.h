@@ -41,7 +41,8 @@ __device__ __forceinline__ double cc_wave_min_f64(double x)
 // FILTER: pi < d (the tentative-add pdim filter of the pcore stage is not vacuous); POW2: k is a power of two
 template <bool FILTER, bool POW2>
 __global__ __launch_bounds__(64) void k_seq(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
-                                            long long* __restrict__ lab_uid, int8_t* __restrict__ lab_path, int n_max)
+                                            long long* __restrict__ lab_uid, int8_t* __restrict__ lab_path, int n_max,
+                                            int follow)
 {
     const long long clk0 = clock64(), wall0 = wall_clock64();
     const Par par = cc_load_par(ctl);
@@ -52,6 +53,8 @@ __global__ __launch_bounds__(64) void k_seq(Ctl* __restrict__ ctl, const double*
     if (M > cap) return;  // (the host checks the same bound)
     const long long cursor0 = ctl->cursor;
     const long long left = ctl->n_points - cursor0;
+    // follow: launched behind k_seq_r (cc_seq_r.h) for what that kernel left of the stint - usually nothing
+    if (follow) n_max = ctl->seq_rest;
     const int n = (int)(left < (long long)n_max ? left : (long long)n_max);
     if (n <= 0) return;
     int n_pkeys = ctl->n_pkeys, n_okeys = ctl->n_okeys;

@@ -124,6 +124,7 @@ typedef struct cc_stats {
     int64_t scan_g_launches;       /* of scan_p_launches: with guessed thresholds (no seed pass over the window) */
     int64_t missed_points;         /* ... points those scans missed (the seeded chain ran for them alone)        */
     int64_t probe_launches;        /* plain scans that carried a probe of the pruned chain (128 points)          */
+    int64_t seq_r_points;          /* of seq_points: taken by the register-resident sequential kernel (d <= 4)    */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

@@ -79,3 +79,81 @@ def test_few_microclusters_long_stream_matches_oracle():
             h.online_microcluster_maintenance(X, t)
             _check_against_oracle(h, o)
     assert hs[0].stats()["seq_points"] > 0 and hs[2].stats()["seq_points"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# k_seq_r (round 4): the table in registers for d <= 4 - one pcore row and a few outlier rows per lane, the 2 d
+# divisions of a tentative add through one prepared reciprocal (cc_div.h)
+# ---------------------------------------------------------------------------------------------------------
+
+def _seq_r_case(seed):
+    """d in 2..4, every k / pi / delta regime of the general fuzz (pdim filter, k not a power of two), populations from a
+    handful to more than the kernel's 64 pcore / 256 (192 at d = 4) outlier slots hold, coarse grids (ties), coordinates
+    scaled by 2^-40 or 2^-420 in some cases (the latter leaves the range k_seq_r's fast division is proven for)."""
+    rng = np.random.default_rng(77_000 + seed)
+    d = int(rng.choice([2, 3, 4]))
+    n = int(rng.choice([40, 700, 3000, 7100]))
+    g = int(rng.choice([1, 3, 8, 30, 90, 400]))
+    sigma = float(rng.choice([0.0, 0.002, 0.02, 0.1]))
+    grid = bool(rng.random() < 0.25)
+    cfg = {
+        "beta": float(rng.choice([0.1, 0.2, 0.9])),
+        "delta": float(rng.choice([0.0, 0.01, 0.05, 1.0])),
+        "epsilon": float(rng.choice([0.003, 0.03, 0.2])),
+        "lambda": float(rng.choice([0.0, 2.0])),
+        "k": float(rng.choice([0.5, 3.0, 4.0, 16.0])),
+        "mu": float(rng.choice([0.0005, 0.01, 0.05])),
+        "pi": int(rng.choice([1, d - 1, d])),
+        "omicron": float(rng.choice([0.0, 4.35e-7, 1e-3])),
+        "upsilon": 6.5,
+    }
+    scale = float(rng.choice([1.0, 1.0, 1.0, 2.0 ** -40, 2.0 ** -420]))  # (2^-420: below what k_seq_r's division premise admits)
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    Xs = []
+    for t in range(3):
+        lab = rng.integers(0, g, n)
+        X = np.clip(centres[lab] + rng.normal(0.0, 1.0, (n, d)) * sigma, 0.0, 1.0)
+        if grid:
+            X = np.round(X * 16) / 16
+        Xs.append(np.ascontiguousarray(X * scale))
+        centres = np.clip(centres + rng.normal(0, 0.01, centres.shape), 0, 1)
+    if scale != 1.0:
+        cfg["epsilon"] *= scale
+        cfg["delta"] *= scale
+    return cfg, Xs
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_register_resident_sequential_kernel_fuzz(seed):
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    from oracle import oracle as O
+    cfg, Xs = _seq_r_case(seed)
+    h = HDDStream(cfg, tuning=dict(window=1024, sequential=2))
+    o = O.OracleHDDStream(cfg)
+    used = 0
+    for t, X in enumerate(Xs):
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+        used += h.stats()["seq_r_points"]
+    assert used > 0
+
+
+def test_register_kernel_takes_the_reference_data_and_the_knob_switches_it_off():
+    """The bundled d0-d4 files (7 100 x 3): every point through k_seq_r; CHRONOCLUST_HIP_SEQR=0: through k_seq, the same
+    results (the goldens of the Python reference both times)."""
+    dump = StateDump(os.path.join(GOLDEN, "c1", "hdd_state.npz"))
+    Xs = [dump.get(t, "X") for t in range(dump.n_timepoints)]
+    cfg = scenarios.params_to_config(scenarios.C1_PARAMS)
+    h = _replay_dump(dump, Xs, cfg, sequential=2)
+    assert h.stats()["seq_r_points"] == h.stats()["seq_points"] == len(Xs[-1])
+    old = os.environ.get("CHRONOCLUST_HIP_SEQR")
+    os.environ["CHRONOCLUST_HIP_SEQR"] = "0"
+    try:
+        h = _replay_dump(dump, Xs, cfg, sequential=2)
+    finally:
+        if old is None:
+            os.environ.pop("CHRONOCLUST_HIP_SEQR")
+        else:
+            os.environ["CHRONOCLUST_HIP_SEQR"] = old
+    assert h.stats()["seq_r_points"] == 0 and h.stats()["seq_points"] == len(Xs[-1])
