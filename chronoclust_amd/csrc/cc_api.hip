@@ -69,7 +69,7 @@ struct TableStore {
     DevBuf<int> kind, key;
     DevBuf<long long> id, uid;
     DevBuf<unsigned long long> touch, last, carry_of, cnt;
-    DevBuf<int> memb, clen;
+    DevBuf<int> memb, clen, heavy;
     size_t cap = 0;
     int d = 0;
     void alloc(size_t rows, int dim)
@@ -78,10 +78,11 @@ struct TableStore {
         scl.ensure(rows * dim);
         w.ensure(rows); kind.ensure(rows); key.ensure(rows); id.ensure(rows); uid.ensure(rows); touch.ensure(2 * rows); last.ensure(2 * rows);
         carry_of.ensure(rows); cnt.ensure(rows); memb.ensure(rows * CC_CHAIN_MEMB); clen.ensure(rows);
+        heavy.ensure(rows);
         cap = rows;
         d = dim;
     }
-    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, carry_of.p, cnt.p, memb.p, clen.p, cap}; }
+    Table view() const { return Table{cf1.p, cf2.p, cen.p, pref.p, scl.p, w.p, kind.p, key.p, id.p, uid.p, touch.p, last.p, carry_of.p, cnt.p, memb.p, clen.p, heavy.p, cap}; }
     void swap(TableStore& o)
     {
         std::swap(cf1.p, o.cf1.p); std::swap(cf1.n, o.cf1.n); std::swap(cf2.p, o.cf2.p); std::swap(cf2.n, o.cf2.n);
@@ -94,6 +95,7 @@ struct TableStore {
         std::swap(carry_of.p, o.carry_of.p); std::swap(carry_of.n, o.carry_of.n);
         std::swap(cnt.p, o.cnt.p); std::swap(cnt.n, o.cnt.n); std::swap(memb.p, o.memb.p); std::swap(memb.n, o.memb.n);
         std::swap(clen.p, o.clen.p); std::swap(clen.n, o.clen.n);
+        std::swap(heavy.p, o.heavy.p); std::swap(heavy.n, o.heavy.n);
         std::swap(cap, o.cap); std::swap(d, o.d);
     }
 };
@@ -152,6 +154,7 @@ struct cc_handle {
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
+    bool allow_heavy = true;    // CHRONOCLUST_HIP_HEAVY=0: k_decide's atomics also for rows that take a large share of a window
     bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
     int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
     DevBuf<int> sp_list;        // [window] the round's list of points for the sparse dirty scans
@@ -423,6 +426,9 @@ void ensure_table(cc_handle* h, size_t rows)
     if (m > 0) HIPCHK(hipMemcpyAsync(nt.carry_of.p, h->tab.carry_of.p, m * 8, hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(nt.cnt.p, 0, want * 8, h->stream));
     HIPCHK(hipMemsetAsync(nt.clen.p, 0, want * 4, h->stream));
+    // (heavy marks index rows like the list in the control block: they move with the table)
+    HIPCHK(hipMemsetAsync(nt.heavy.p, 0, want * 4, h->stream));
+    if (m > 0 && h->tab.heavy.p) HIPCHK(hipMemcpyAsync(nt.heavy.p, h->tab.heavy.p, m * 4, hipMemcpyDeviceToDevice, h->stream));
     sync_stream(h, h->stream);
     h->tab.swap(nt);
 }
@@ -805,6 +811,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* hv = getenv("CHRONOCLUST_HIP_HEAVY");
+        h->allow_heavy = !(hv && hv[0] == '0');
         const char* sr = getenv("CHRONOCLUST_HIP_SEQR");
         h->allow_seq_r = !(sr && sr[0] == '0');
         const char* pb = getenv("CHRONOCLUST_HIP_PROBE");
@@ -1490,6 +1498,8 @@ struct OnlineRun {
         c.stat_table_rows = 0;
         c.stat_seq_points = 0;
         c.stat_seq_r_points = 0;
+        c.n_heavy = c.n_heavy_new = 0;  // (rows are renumbered between calls: the marks of the last call are void)
+        HIPCHK(hipMemsetAsync(h->tab.heavy.p, 0, h->tab.cap * sizeof(int), h->stream));
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
         c.stat_missed = 0;
@@ -1657,6 +1667,10 @@ struct OnlineRun {
         // that takes a third of the events): k_chain_long is launched, over the list k_decide keeps, in the batches
         // that follow one in which such chains were seen (a function of device counters: every rank decides alike)
         const bool long_listed = h->allow_long && scan_rows == 0 && long_seen;
+        // heavy rows: their claims are gathered by k_claims_heavy instead of k_decide's atomics from the batch after the
+        // one that marked them (the marks change between windows, on the device; what the host saw at the last sync
+        // decides for the whole batch whether the gathering kernel is launched - k_decide is told the same)
+        const bool heavy_on = h->allow_heavy && scan_rows == 0 && h->hc.n_heavy > 0;
         int* const long_list = long_listed ? h->long_list.p : nullptr;
         // workgroups of its launches = entries k_decide may list per round: a few more than the previous batch's
         // average when that was small (a launch of hundreds of workgroups that return at once is not free)
@@ -1756,9 +1770,12 @@ struct OnlineRun {
             hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0);
+                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0);
             if (scan_rows > 0)
                 hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
+            if (heavy_on)
+                hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0,
+                                   long_list, long_cap);
             for (int r = 1; r <= Rcur; ++r) {
                 const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                 int* tnew = (r & 1) ? h->T1.p : h->T0.p;
@@ -1796,10 +1813,13 @@ struct OnlineRun {
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                    dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
                                    dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
-                                   r == Rcur ? 1 : 0);
+                                   r == Rcur ? 1 : 0, heavy_on ? 1 : 0);
                 // (the claims of the last round are not replayed: nothing to gather either)
                 if (scan_rows > 0 && r < Rcur)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
+                if (heavy_on && r < Rcur)
+                    hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r,
+                                       long_list, long_cap);
             }
             hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                h->rk.p, h->rec.p, (const Cand*)h->clean.p, (const int8_t*)h->dpath.p);

@@ -52,8 +52,18 @@ struct Table {
     unsigned long long* cnt;  // [cap]
     int* memb;                // [cap, CC_CHAIN_MEMB]
     int* clen;                // [cap] members of the MC's chain as k_chain walked it (valid while `touch` carries the round's stamp)
+    // Heavy rows (skewed populations: a MC that takes a large share of a window's points).  Per claimant k_decide issues
+    // three atomics on the MC's words (touch, last, cnt); thousands of claimants of one MC serialise there (~20 ns each).
+    // A row whose chain was long (> CC_CHAIN_MEMB claimants) is marked heavy at the end of that window (k_commit_a:
+    // Ctl::heavy_list, at most CC_HEAVY_CAP rows); from the next batch on its claimants skip the atomics and
+    // k_claims_heavy - one workgroup per heavy row, behind every k_decide whose claims are replayed - gathers first /
+    // last claimant, count and members from the claims, in the formats k_decide writes.  0: not heavy, 1: heavy,
+    // 2: heavy, to be dropped at the end of this window (its chain was short again).
+    int* heavy;               // [cap]
     size_t cap;                 // rows allocated (offset of the second copy)
 };
+#define CC_HEAVY_CAP 64   // heavy rows at a time (= workgroups of a k_claims_heavy launch)
+#define CC_HEAVY_NEW 32   // candidates a window may nominate
 
 // Candidate slots >= CC_CAR_BASE refer to carried rows (index = slot - CC_CAR_BASE), below to version rows.
 #define CC_CAR_BASE (1 << 24)
@@ -227,6 +237,11 @@ struct Ctl {
     int seq_rest;  // k_seq_r -> k_seq: points of the stint the register kernel left (its capacity was reached, or the table did not fit)
     int pad3;
     long long stat_seq_r_points;  // of stat_seq_points: taken by k_seq_r
+    // heavy rows (Table::heavy): the list k_claims_heavy works on, and this window's nominations (k_decide: the claimant
+    // that finds a chain's member list full); k_commit_a merges the nominations into the list and drops rows marked 2
+    int n_heavy, n_heavy_new;
+    int heavy_list[CC_HEAVY_CAP];
+    int heavy_new[CC_HEAVY_NEW];
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against

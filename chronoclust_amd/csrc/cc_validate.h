@@ -567,7 +567,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int8_t* __restrict__ dpath, int S, int Sd, int round, int nodirty,
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
-                                                int* __restrict__ long_list, int long_cap, int stat_tail, int last_round)
+                                                int* __restrict__ long_list, int long_cap, int stat_tail, int last_round,
+                                                int heavy_on)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -794,7 +795,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         // Nobody replays the claims of the last round the host enqueued for this window - no k_chain follows it, the
         // commit reads the claims themselves -, so they are not registered: three atomics per point saved, and the ones
         // that serialise when a population takes a large share of the events (one address per MC)
-        if (last_round == 0 && T >= 0 && !(T < M0 && T < scan_rows)) {
+        // (heavy_on: k_claims_heavy follows this launch and gathers the claims of the heavy rows - Table::heavy)
+        if (last_round == 0 && T >= 0 && !(T < M0 && T < scan_rows) && !(heavy_on != 0 && T < M0 && tab.heavy[T] != 0)) {
             // first / last point of this window that targets T, for the round that replays these claims
             // (provisional ids of new MCs index the free rows behind the table)
             const unsigned long long sn = (stamp + 1ull) << 20;
@@ -818,6 +820,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
             else if (pos == CC_CHAIN_MEMB && T < M0) {
                 // the one claimant that finds the list full: a long chain of an existing MC
                 atomicAdd((unsigned long long*)&ctl->stat_long, 1ull);
+                if (tab.heavy[T] == 0) {  // nominated as a heavy row (k_commit_a takes it from there)
+                    const int hn = atomicAdd(&ctl->n_heavy_new, 1);
+                    if (hn < CC_HEAVY_NEW) ctl->heavy_new[hn] = T;
+                }
                 if (long_list != nullptr) {
                     const int idx = atomicAdd(&ctl->n_long[round + 1], 1);
                     if (idx < long_cap) {  // (= the workgroups of the k_chain_long launch that follows)
@@ -876,6 +882,75 @@ __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Tab
         tab.last[wr] = sn | (unsigned long long)s_last;
         tab.cnt[m] = ((stamp + 1ull) << 24) | (unsigned long long)s_pos;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// k_claims_heavy: k_claims for the heavy rows of a large table (Table::heavy, Ctl::heavy_list): one workgroup per
+// heavy row reads the claims once and leaves first / last claimant, count and members as k_decide's atomics would have
+// - without the thousands of same-address atomics a MC that takes a tenth of the window's points costs there.  A chain
+// of more than CC_CHAIN_MEMB claimants goes on the round's list of long chains exactly as in k_decide.  Launched behind
+// every k_decide whose claims are replayed, while the previous batch ended with heavy rows (k_decide: heavy_on).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_claims_heavy(Ctl* __restrict__ ctl, Table tab, const int* __restrict__ T, int round,
+                                                      int* __restrict__ long_list, int long_cap)
+{
+    CC_LATENCY_KERNEL();
+    const int B = ctl->win_b;
+    if (B == 0) return;
+    if (round > 0 && ctl->fc[round - 1] >= B) return;  // k_decide of this round did not run either
+    if ((int)blockIdx.x >= ctl->n_heavy) return;
+    const int m = ctl->heavy_list[blockIdx.x];
+    if (m < 0 || m >= ctl->m_rows) return;
+    // (thousands of claimants: each thread counts its own, and only the first CC_CHAIN_MEMB of them - any of them, the
+    // list is unordered - take a slot of the member list through the LDS counter)
+    __shared__ int s_pos, s_cnt, s_first, s_last;
+    if (threadIdx.x == 0) { s_pos = 0; s_cnt = 0; s_first = CC_IDX_INF; s_last = -1; }
+    __syncthreads();
+    int lmin = CC_IDX_INF, lmax = -1, mine = 0;
+    volatile int* const pos_now = &s_pos;
+    const int4* T4 = reinterpret_cast<const int4*>(T);  // (the buffer is padded to whole 128-entry blocks)
+    for (int base = (int)threadIdx.x * 4; base < B; base += 256 * 4) {
+        const int4 v = T4[base >> 2];
+        const int e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int j = base + c;
+            if (j < B && e[c] == m) {
+                lmin = j < lmin ? j : lmin;
+                lmax = j > lmax ? j : lmax;
+                ++mine;
+                if (*pos_now < CC_CHAIN_MEMB) {
+                    const int pos = atomicAdd(&s_pos, 1);
+                    if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+                }
+            }
+        }
+    }
+    if (lmax >= 0) { atomicMin(&s_first, lmin); atomicMax(&s_last, lmax); atomicAdd(&s_cnt, mine); }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int n_claims = s_cnt;
+    if (n_claims > 0) {
+        const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+        const unsigned long long sn = (stamp + 1ull) << 20;
+        const size_t wr = (size_t)((round + 1) & 1) * tab.cap + (size_t)m;  // the copy the next round reads
+        tab.touch[wr] = sn | (unsigned long long)(0xFFFFF - s_first);
+        tab.last[wr] = sn | (unsigned long long)s_last;
+        unsigned long long cw = ((stamp + 1ull) << 24) | (unsigned long long)n_claims;
+        if (n_claims > CC_CHAIN_MEMB) {
+            atomicAdd((unsigned long long*)&ctl->stat_long, 1ull);
+            if (long_list != nullptr) {
+                const int idx = atomicAdd(&ctl->n_long[round + 1], 1);
+                if (idx < long_cap) {
+                    long_list[(size_t)((round + 1) & 1) * CC_LONG_CAP + idx] = m;
+                    cw |= CC_LONG_LISTED;
+                }
+            }
+        }
+        tab.cnt[m] = cw;
+    }
+    // the population has thinned out: back to k_decide's atomics from the next window on
+    if (round == 0 && n_claims <= CC_CHAIN_MEMB / 2) tab.heavy[m] = 2;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1128,7 +1203,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 // ---------------------------------------------------------------------------------
 
 #define CC_LONG_XY_DOUBLES 6144  // staged CF1 / CF2 prefixes of a batch: 2 * K * d doubles (48 KB)
-#define CC_LONG_QUEUE 2048       // pending chain members (ring buffer)
+#define CC_LONG_QUEUE 2048       // pending chain members (ring buffer); four times as many in the SPLIT workgroups
 #define CC_LONG_THREADS 1024      // threads of a k_chain_long workgroup
 
 // SPLIT: workgroups of CC_LONG_THREADS threads (four waves per SIMD) with the per-(step, dimension) work of the radius
@@ -1178,11 +1253,15 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     __shared__ double s_w[256], s_dq[256];
     __shared__ unsigned long long s_mask[256];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
     __shared__ int s_flag[256];                 // bit 0: radius test passed, bit 1: promotion condition holds
-    __shared__ int s_queue[CC_LONG_QUEUE];
+    // claims looked at per pass of the member collection: four per thread; the ring buffer holds two passes' worth
+    constexpr int PASS = (SPLIT ? CC_LONG_THREADS : 256) * 4;
+    constexpr int QUEUE = SPLIT ? 4 * CC_LONG_QUEUE : CC_LONG_QUEUE;
+    constexpr int SCAN_WAVES = PASS / 256;
+    __shared__ int s_queue[QUEUE];
     __shared__ double s_b1[64], s_b2[64], s_bcen[64], s_bpref[64], s_c0[64], s_w0[64];  // running state / snapshot metric
     __shared__ double s_bw, s_bdq;
     __shared__ unsigned long long s_m0, s_bmask;  // preferred dimensions in the snapshot / of the running state (bit i)
-    __shared__ int s_wsum[4];
+    __shared__ int s_wsum[SCAN_WAVES];
     __shared__ int s_first_fail, s_first_up;
     // per (step, dimension) of a batch: the term of the radius sum, the displacement term, "preferred after the step"
     __shared__ double s_term[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1], s_dqt[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
@@ -1236,19 +1315,25 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
 
     const int4* T4 = reinterpret_cast<const int4*>(T);  // (the claims buffer is padded to whole 128-entry blocks)
     int qhead = 0, qcount = 0;     // ring buffer of pending members (the same in every thread)
-    int scan_pos = head & ~1023;   // next block of 1 024 claims to look at
+    int scan_pos = head & ~(PASS - 1);  // next block of PASS claims to look at
     bool scan_done = false;
     int walked = 0;
     bool promoted_any = false;
+    // (every thread scans four claims per pass.  The claims of a pass are loaded one pass ahead: the latency of the load
+    // runs beside the batch in between, not in front of the pass.)
+    const bool scanner = true;
+    auto load_claims = [&](int pos) {
+        const int i0 = pos + (scanner ? tid : 0) * 4;
+        return (scanner && i0 <= last_j) ? T4[i0 >> 2] : make_int4(-1, -1, -1, -1);
+    };
+    int4 v_next = load_claims(scan_pos);
 
     for (;;) {
         // ---- 1. members in order: ordered compaction of the next claims into the queue ----
-        while (!scan_done && qcount < K + 1 && qcount + 1024 <= CC_LONG_QUEUE) {
-            // (the first 256 threads scan 1 024 claims per pass; the others only keep the barriers company)
-            const bool scanner = tid < 256;
+        while (!scan_done && qcount < K + 1 && qcount + PASS <= QUEUE) {
             const int i0 = scan_pos + (scanner ? tid : 0) * 4;
-            int4 v = make_int4(-1, -1, -1, -1);
-            if (scanner && i0 <= last_j) v = T4[i0 >> 2];
+            const int4 v = v_next;
+            v_next = load_claims(scan_pos + PASS);
             const int e[4] = {v.x, v.y, v.z, v.w};
             int f[4], cnt = 0;
 #pragma unroll
@@ -1264,20 +1349,20 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
                 if (lane >= off) incl += o;
             }
             __syncthreads();  // (s_wsum of the previous pass has been read)
-            if (lane == 63 && wv < 4) s_wsum[wv] = incl;
+            if (lane == 63) s_wsum[wv] = incl;
             __syncthreads();
             int base = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < SCAN_WAVES; ++w) {
                 if (w < wv) base += s_wsum[w];
                 total += s_wsum[w];
             }
             int pos = qcount + base + incl - cnt;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-                if (f[c]) { s_queue[(qhead + pos) & (CC_LONG_QUEUE - 1)] = i0 + c; ++pos; }
+                if (f[c]) { s_queue[(qhead + pos) & (QUEUE - 1)] = i0 + c; ++pos; }
             qcount += total;
-            scan_pos += 1024;
+            scan_pos += PASS;
             if (scan_pos > last_j) scan_done = true;
         }
         __syncthreads();
@@ -1287,7 +1372,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         // ---- 2. stage the points, then the sequential additions per dimension ----
         for (int e = tid; e < n * d; e += NT) {
             const int k = e / d, i = e - k * d;
-            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            const int m = s_queue[(qhead + k) & (QUEUE - 1)];
             const double x = X[(cursor + m) * d + i];
             xs[e] = x;
             ys[e] = x * x;  // (the square every step adds to CF2: formed here, by all threads, instead of inside the chain)
@@ -1297,19 +1382,31 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         // The three running sums are chains of dependent additions, a dozen instructions per step for ONE wave that has
         // its SIMD to itself: CF1 in the first wave, CF2 in the second, W in the third, side by side
         // (mc_functions.py:24-29 / microcluster.py:147: the additions k_chain makes, in its order).
+        // (eight steps at a time: the eight LDS reads go out together, then the eight additions in order, then the eight
+        // writes - read, add, write per step would wait out one LDS round trip per step)
+        auto prefix_chain = [&](double* a, int i, double c) {
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = a[(k + u) * d + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c = c + v[u];
+                    v[u] = c;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a[(k + u) * d + i] = v[u];
+            }
+            for (; k < n; ++k) {
+                c = c + a[k * d + i];
+                a[k * d + i] = c;
+            }
+        };
         if (tid < d) {
-            double c1 = s_b1[tid];
-            for (int k = 0; k < n; ++k) {
-                c1 = c1 + xs[k * d + tid];
-                xs[k * d + tid] = c1;
-            }
+            prefix_chain(xs, tid, s_b1[tid]);
         } else if (tid >= 64 && tid < 64 + d) {
-            const int i = tid - 64;
-            double c2 = s_b2[i];
-            for (int k = 0; k < n; ++k) {
-                c2 = c2 + ys[k * d + i];
-                ys[k * d + i] = c2;
-            }
+            prefix_chain(ys, tid - 64, s_b2[tid - 64]);
         } else if (tid == 128) {
             double w = s_bw;
             for (int k = 0; k < n; ++k) {
@@ -1380,12 +1477,12 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         // hddstream.py:416-430: the first accepted add to an outlier MC that fulfils the condition promotes it
         int u = -1;
         if (bkind == CC_KIND_OUTLIER && s_first_up < n_ok) u = s_first_up;
-        const int up_point = (u >= 0) ? s_queue[(qhead + u) & (CC_LONG_QUEUE - 1)] : -1;
+        const int up_point = (u >= 0) ? s_queue[(qhead + u) & (QUEUE - 1)] : -1;
 
         // ---- 4. version rows: vectors by (row, dimension), the rest by row ----
         for (int e = tid; e < n_rows * d; e += NT) {
             const int k = e / d, i = e - k * d;
-            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            const int m = s_queue[(qhead + k) & (QUEUE - 1)];
             const int src = (k < n_ok) ? k : k - 1;  // a rejected step leaves the state of the step before it
             double c1, c2, ce, pr;
             if (src >= 0) {
@@ -1401,7 +1498,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         }
         if (tid < n_rows) {
             const int k = tid;
-            const int m = s_queue[(qhead + k) & (CC_LONG_QUEUE - 1)];
+            const int m = s_queue[(qhead + k) & (QUEUE - 1)];
             const int src = (k < n_ok) ? k : k - 1;
             const bool promoted = u >= 0 && k >= u;
             const int kind = promoted ? CC_KIND_PCORE : bkind;
@@ -1410,7 +1507,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             const unsigned long long vmask = (src >= 0) ? s_mask[src] : s_bmask;
             const bool was_outlier = kind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER;  // promoted since the snapshot: class 2
             if ((kind != kind0 && !was_outlier) || !(dq >= 0.0) || vmask != s_m0) dq = CC_INF;
-            const int nx = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (CC_LONG_QUEUE - 1)] : CC_IDX_INF;
+            const int nx = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (QUEUE - 1)] : CC_IDX_INF;
             ver.w[m] = (src >= 0) ? s_w[src] : s_bw;
             ver.tgt[m] = t;
             ver.kind[m] = kind;
@@ -1438,7 +1535,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             bkind = CC_KIND_PCORE; bkey = pk_base + up_point; bupg = up_point;
             promoted_any = true;
         }
-        qhead = (qhead + n_rows) & (CC_LONG_QUEUE - 1);
+        qhead = (qhead + n_rows) & (QUEUE - 1);
         qcount -= n_rows;
         walked += n_rows;
         __syncthreads();
@@ -1469,6 +1566,33 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
     __shared__ unsigned wsum[16];
     __shared__ unsigned tot;
     __shared__ int dirty_tiles;
+    // heavy rows (Table::heavy): rows marked 2 leave the list, this window's nominations join it (the last wave; the
+    // list and the marks change nowhere else, so k_decide and k_claims_heavy of one window always agree on them)
+    if (threadIdx.x >= 960 && (ctl->n_heavy > 0 || ctl->n_heavy_new > 0)) {
+        const int lane = (int)threadIdx.x - 960;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const int n_h = min(ctl->n_heavy, CC_HEAVY_CAP);
+        const int row = lane < n_h ? ctl->heavy_list[lane] : -1;
+        const bool keep = row >= 0 && tab.heavy[row] == 1;
+        if (row >= 0 && !keep) tab.heavy[row] = 0;
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep);
+        const int n_keep = __builtin_popcountll(km);
+        const int n_new = min(ctl->n_heavy_new, CC_HEAVY_NEW);
+        const int nr = lane < n_new ? ctl->heavy_new[lane] : -1;
+        bool add = nr >= 0 && atomicExch(&tab.heavy[nr], 1) == 0;  // (a row nominated twice is taken once)
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(add);
+        const int apos = n_keep + __builtin_popcountll(am & below);
+        if (add && apos >= CC_HEAVY_CAP) {
+            tab.heavy[nr] = 0;  // no room
+            add = false;
+        }
+        if (keep) ctl->heavy_list[__builtin_popcountll(km & below)] = row;
+        if (add) ctl->heavy_list[apos] = nr;
+        if (lane == 0) {
+            ctl->n_heavy = min(n_keep + __builtin_popcountll(am), CC_HEAVY_CAP);
+            ctl->n_heavy_new = 0;
+        }
+    }
     const int r = ctl->last_round;
     const bool la_win = ctl->mode != 0;  // this window's snapshot scan ran ahead (read before thread 0 moves on)
     if (threadIdx.x == 0) dirty_tiles = 0;
