@@ -1773,7 +1773,7 @@ struct OnlineRun {
                                (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0);
             if (scan_rows > 0)
                 hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
-            if (heavy_on)
+            if (heavy_on && ++h->stats.heavy_launches > 0)
                 hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0,
                                    long_list, long_cap);
             for (int r = 1; r <= Rcur; ++r) {
@@ -1817,7 +1817,7 @@ struct OnlineRun {
                 // (the claims of the last round are not replayed: nothing to gather either)
                 if (scan_rows > 0 && r < Rcur)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
-                if (heavy_on && r < Rcur)
+                if (heavy_on && r < Rcur && ++h->stats.heavy_launches > 0)
                     hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r,
                                        long_list, long_cap);
             }

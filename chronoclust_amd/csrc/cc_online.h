@@ -42,6 +42,9 @@
 //                     dimension, radius tests of a batch of steps in parallel, resume after the first rejected one
 //   k_seq             no speculation: one wavefront walks the points in order on an LDS image of the table; the host
 //                     switches to it while windows keep being cut short and it measures faster
+//   k_seq_r           the same with the table in registers (d <= 4, a few hundred rows: the reference's own data)
+//   k_claims_heavy    the claims of a microcluster that takes a large share of a window, gathered by one workgroup
+//                     instead of three same-address atomics per claimant in k_decide (Table::heavy)
 //   k_merge_partials  exact multi-GPU path: a rank's partials per point -> the 64-byte record the ranks all-gather
 //                     (k_scan then scans only the rank's share of the table rows, k_decide merges the records)
 //   k_rel_*           relaxed multi-GPU mode (events sharded over the ranks): CF deltas, merge, promotions,

@@ -125,6 +125,7 @@ typedef struct cc_stats {
     int64_t missed_points;         /* ... points those scans missed (the seeded chain ran for them alone)        */
     int64_t probe_launches;        /* plain scans that carried a probe of the pruned chain (128 points)          */
     int64_t seq_r_points;          /* of seq_points: taken by the register-resident sequential kernel (d <= 4)    */
+    int64_t heavy_launches;        /* k_claims_heavy launches (claims of heavy rows gathered without k_decide's atomics) */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

@@ -456,3 +456,44 @@ def test_point_clusters_device_gather_equals_numpy_join_and_reference_labels():
             seen_none |= bool((got < 0).any())
             seen_cluster |= bool((got >= 0).any())
     assert seen_none and seen_cluster
+
+
+def test_heavy_rows_are_gathered_by_their_own_kernel():
+    """Round 4: a microcluster whose chain was long is marked heavy; from the next batch on its claimants skip k_decide's
+    three atomics and k_claims_heavy gathers first / last claimant, count and members.  (a) three populations take 30 %
+    of the events, then the stream turns uniform (the rows are dropped from the list again); (b) every one of 1 200
+    microclusters has a long chain (41 claimants per 49 152-point window): more nominations than the list of 64 holds.
+    The oracle's results, with the kernel really used; and the same with CHRONOCLUST_HIP_HEAVY=0."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(515)
+    for case in ("skewed then uniform", "all chains long"):
+        if case == "skewed then uniform":
+            n, d, g, window = 300_000, 6, 1500, 8192
+        else:
+            n, d, g, window = 400_000, 6, 1200, 49152
+        centres = rng.uniform(0.05, 0.95, (g, d))
+        lab = rng.integers(0, g, n)
+        if case == "skewed then uniform":
+            big = (rng.random(n) < 0.3) & (np.arange(n) < n // 2)
+            lab[big] = rng.integers(0, 3, int(big.sum()))
+        X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 0.003, (n, d)), 0.0, 1.0))
+        cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.05, promote_after=5))
+        o = O.OracleHDDStream(cfg)
+        o.online_microcluster_maintenance(X, 0)
+        for knob in (None, "0"):
+            old = os.environ.get("CHRONOCLUST_HIP_HEAVY")
+            if knob is not None:
+                os.environ["CHRONOCLUST_HIP_HEAVY"] = knob
+            try:
+                h = _hdd(cfg, window=window, lookahead=0)
+            finally:
+                if knob is not None:
+                    if old is None:
+                        os.environ.pop("CHRONOCLUST_HIP_HEAVY")
+                    else:
+                        os.environ["CHRONOCLUST_HIP_HEAVY"] = old
+            h.online_microcluster_maintenance(X, 0)
+            _check_against_oracle(h, o)
+            s = h.stats()
+            assert s["rows"] > 1024 and s["long_chains"] > 0
+            assert (s["heavy_launches"] > 0) == (knob is None), (case, knob, s)
