@@ -134,6 +134,8 @@ struct cc_handle {
     int prune_mode = 1;
     double prune_F = 16.0;
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
+    bool group_guess_now = false;     // ... and the missed points derived from the gathered records (k_missed_g), see timed_scan
+    bool group_guess_always = false;  // CHRONOCLUST_HIP_GROUP_GUESS=1: also in a group of one rank
     bool guess_now = false;   // ... with guessed thresholds (k_scan_p + k_missed + the seeded chain for the missed points)
     bool probe_now = false;   // the next plain scan also runs the pruned chain on 128 points (cc_policy_decision::probe)
     DevBuf<Cand> probe_part;  // ... into these scratch partials
@@ -565,7 +567,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 }
                 if (h->prune_now) {
                     ++h->stats.scan_p_launches;
-                    if (h->guess_now && shard_world > 1) {
+                    if (h->guess_now && h->group_guess_now) {
                         // (split over ranks: every rank scans its rows against the same guess; who was missed is only known
                         // once the records are gathered - phase 1, enqueued by the caller behind the all-gather)
                         ++h->stats.scan_g_launches;
@@ -811,6 +813,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* gg = getenv("CHRONOCLUST_HIP_GROUP_GUESS");
+        h->group_guess_always = gg && gg[0] == '1';
         const char* hv = getenv("CHRONOCLUST_HIP_HEAVY");
         h->allow_heavy = !(hv && hv[0] == '0');
         const char* sr = getenv("CHRONOCLUST_HIP_SEQR");
@@ -1391,7 +1395,8 @@ struct OnlineRun {
     }
     // points per ms the sequential kernel is assumed to manage before it has been measured in this call (k_seq on its LDS
     // image: ~0.9 us per point; k_seq_r, rows in registers, d <= 4: ~0.6 us)
-    double seq_rate_guess() const { return (h->allow_seq_r && h->d >= 2 && h->d <= 4) ? 1500.0 : 700.0; }
+    bool seq_r_applies() const { return h->allow_seq_r && h->d >= 2 && h->d <= 4; }
+    double seq_rate_guess() const { return seq_r_applies() ? 1500.0 : 700.0; }
     bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; }
 
     // lookahead (re)start: the current window is a fresh one (scanned in place), the lookahead scan enqueued next covers
@@ -1693,6 +1698,10 @@ struct OnlineRun {
                 h->probe_now = probe_left > 0 && !h->prune_now;  // (the batch's first scan carries the probe)
                 if (h->probe_now) --probe_left;
                 const int srank = shard_on ? myrank : 0, sworld = shard_on ? world : 1;
+                // guessed thresholds with the missed points agreed on from the gathered records: whenever the scan is split
+                // over more than one rank (a group of one rank takes the same steps on request, CHRONOCLUST_HIP_GROUP_GUESS=1:
+                // that is how the second all-gather is exercised over RCCL on one GPU)
+                h->group_guess_now = shard_on && (sworld > 1 || h->group_guess_always);
                 scan_end = nullptr;
                 if (timing) {
                     hipEvent_t a = get_event(h, ev_used), b = get_event(h, ev_used + 1);
@@ -1716,7 +1725,7 @@ struct OnlineRun {
                                        (const int*)nullptr);
                     h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
                                        ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
-                    if (h->prune_now && h->guess_now && sworld > 1) {
+                    if (h->prune_now && h->guess_now && h->group_guess_now) {
                         // guessed thresholds: the points no rank found a pcore MC for (a function of the gathered records:
                         // the same list everywhere) go through the seeded chain on every rank's rows, their new records
                         // are exchanged in a second, small all-gather of fixed size and take the place of the old ones
@@ -1918,9 +1927,12 @@ struct OnlineRun {
                         } else {
                             seq_stint_len = 32768;
                         }
-                    } else if (bad_batches >= 2 && win_rate < (seq_rate_last > 0.0 ? seq_rate_last : seq_rate_guess())) {
-                        // (700 points per millisecond: what k_seq delivers whatever the data, until it has been measured
-                        // in this call; the short windows of a stream that is merely starting up run faster than that)
+                    } else if (bad_batches >= (seq_r_applies() ? 1 : 2) &&
+                               win_rate < (seq_rate_last > 0.0 ? seq_rate_last : seq_rate_guess())) {
+                        // (seq_rate_guess(): what the sequential kernel delivers whatever the data, until it has been
+                        // measured in this call; the short windows of a stream that is merely starting up run faster than
+                        // that.  Where the register kernel applies one such batch is enough: a stint of it costs half of
+                        // what k_seq's costs, and the streams it is built for have a few thousand points per call.)
                         seq_on = true;
                     }
                     if (seq_on) seq_stint_left = seq_stint_len;

@@ -248,3 +248,41 @@ def test_guessed_thresholds_in_a_group_miss_a_loose_population(world):
     for r in off:
         P.same_results(r, single)
         assert all(s["stats"]["scan_g_launches"] == 0 for s in r)
+
+
+def test_rccl_transport_carries_the_second_gather_of_guessed_thresholds():
+    """The second, fixed-size all-gather of a split scan with guessed thresholds (the missed points' new records) over
+    ncclAllGather: a communicator of one rank that takes the group's steps on request (CHRONOCLUST_HIP_GROUP_GUESS=1) -
+    k_missed_g over the gathered records, the seeded chain for the listed points, compact records, gather, scatter - on
+    both streams.  The stream with loose populations (points are missed in every window), pruning forced."""
+    import os
+    from chronoclust_amd import _lib
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    rng = np.random.default_rng(31)
+    n, d, g = 60_000, 20, 300
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    sig = np.where(np.arange(g) < 240, 0.004, 0.03)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.25))
+    Xs = []
+    for _ in range(2):
+        lab = rng.integers(0, g, n)
+        Xs.append(np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 1.0, (n, d)) * sig[lab, None], 0.0, 1.0)))
+    single = P.run_pipeline(Xs, cfg)
+    env = dict(CHRONOCLUST_HIP_PRUNE="2", CHRONOCLUST_HIP_GROUP_GUESS="1")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        h = HDDStream(cfg, tuning=dict(window=8192))
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    h._h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)
+    h._h.set_shard_thresholds(0, 0)
+    res = P.run_pipeline(Xs, cfg, stream=h)
+    P.same_results(res, single)
+    assert sum(r["stats"]["scan_g_launches"] for r in res) > 0 and sum(r["stats"]["missed_points"] for r in res) > 0
+    assert all(r["stats"]["sharded_windows"] == r["stats"]["windows"] > 0 for r in res)
+    h._h.comm_destroy()

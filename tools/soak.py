@@ -1,5 +1,7 @@
 """Soak run of the fuzz parity cases beyond the seeds the test suite holds (tests/test_fuzz_parity.py: seeds 0-191;
-tests/test_pruned_scan.py::test_forced_pruning_fuzz: 0-95): the same case generators and checks, other seeds.
+tests/test_pruned_scan.py::test_forced_pruning_fuzz: 0-95; tests/test_sequential.py::test_register_resident_sequential_kernel_fuzz:
+0-95; tests/test_hip_parity.py::test_skewed_streams_fuzz: 0-11, here on every eighth seed): the same case generators and
+checks, other seeds.
 Usage: python tools/soak.py <first seed> <last seed> [log file]   (on the GPU box from the repo root; failures and a
 progress line every 25 seeds are printed and appended to the log file - default gpurun_out/soak.log -, exit status 1 if
 any case failed)"""
@@ -26,11 +28,17 @@ def main():
     import pytest  # noqa: F401  (the test modules import it)
     import test_fuzz_parity as F
     import test_pruned_scan as P
+    import test_sequential as S
+    import test_hip_parity as H
     bad, n, t0 = [], 0, time.time()
     for seed in range(a, b):
-        for name, fn in (("fuzz la=3", lambda s: F.test_fuzz_case(s, 3)),
-                         ("fuzz la=2", lambda s: F.test_fuzz_case(s, 2)),
-                         ("forced pruning", lambda s: P.test_forced_pruning_fuzz(s))):
+        cases = [("fuzz la=3", lambda s: F.test_fuzz_case(s, 3)),
+                 ("fuzz la=2", lambda s: F.test_fuzz_case(s, 2)),
+                 ("forced pruning", lambda s: P.test_forced_pruning_fuzz(s)),
+                 ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s))]
+        if seed % 8 == 0:  # (two timepoints of 40-60 k points against 1 100-2 600 microclusters: seconds per case)
+            cases.append(("skewed streams", lambda s: H.test_skewed_streams_fuzz(s)))
+        for name, fn in cases:
             try:
                 fn(seed)
                 n += 1
