@@ -156,6 +156,7 @@ struct cc_handle {
     bool allow_nodirty = true;  // CHRONOCLUST_HIP_NODIRTY=0: always launch the dirty scans
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
+    bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
     bool allow_heavy = true;    // CHRONOCLUST_HIP_HEAVY=0: k_decide's atomics also for rows that take a large share of a window
     bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
     int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
@@ -815,6 +816,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_long = !(lc && lc[0] == '0');
         const char* gg = getenv("CHRONOCLUST_HIP_GROUP_GUESS");
         h->group_guess_always = gg && gg[0] == '1';
+        const char* qt = getenv("CHRONOCLUST_HIP_QUIET");
+        h->allow_quiet = !(qt && qt[0] == '0');
         const char* hv = getenv("CHRONOCLUST_HIP_HEAVY");
         h->allow_heavy = !(hv && hv[0] == '0');
         const char* sr = getenv("CHRONOCLUST_HIP_SEQR");
@@ -1779,7 +1782,7 @@ struct OnlineRun {
             hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0);
+                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0, 0);
             if (scan_rows > 0)
                 hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
             if (heavy_on && ++h->stats.heavy_launches > 0)
@@ -1822,7 +1825,7 @@ struct OnlineRun {
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                    dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
                                    dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
-                                   r == Rcur ? 1 : 0, heavy_on ? 1 : 0);
+                                   r == Rcur ? 1 : 0, heavy_on ? 1 : 0, h->allow_quiet ? 1 : 0);
                 // (the claims of the last round are not replayed: nothing to gather either)
                 if (scan_rows > 0 && r < Rcur)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);

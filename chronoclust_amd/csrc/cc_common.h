@@ -239,6 +239,9 @@ struct Ctl {
     long long stat_seq_r_points;  // of stat_seq_points: taken by k_seq_r
     // heavy rows (Table::heavy): the list k_claims_heavy works on, and this window's nominations (k_decide: the claimant
     // that finds a chain's member list full); k_commit_a merges the nominations into the list and drops rows marked 2
+    // rdiff[r]: some decision of round r may differ from the claim it validates (k_dseed of round r; reset by k_chain of
+    // round r).  0 after k_dseed: k_decide of round r would repeat every claim - it returns at once (a "quiet" round).
+    int rdiff[CC_MAX_ROUNDS + 2];
     int n_heavy, n_heavy_new;
     int heavy_list[CC_HEAVY_CAP];
     int heavy_new[CC_HEAVY_NEW];

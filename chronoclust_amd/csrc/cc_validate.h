@@ -183,6 +183,7 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
             }
     }
     bool flag_unprov = false, flag_unsafe = false, flag_n1skip = false;
+    bool repeats = false;  // k_decide of this round would repeat this point's claim (see the end of the per-point block)
     int flag_word = 0;
     double tau_w[3] = {CC_INF, CC_INF, CC_INF};
     bool need_ver = false, need_car = false;  // this point's stages need rows only a dirty scan of the versions / the carry set covers
@@ -453,6 +454,30 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
     flag_word = flags;
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) tau_w[kd] = tau[kd];
+    // Would k_decide of this round repeat the claim?  In the steady state it does for every point of the window, and the
+    // launch (one 32-lane group per point re-reading what this thread holds) only confirms it.  The test below is
+    // k_decide's own evaluation of stage 0 for a point whose tile's dirty scans do not run (its live versions are then
+    // the seeds written above), restricted to the two ways it ends on the claimed MC with the radius test's verdict
+    // already known from the chain (ver.acc, see run_stage); anything else - another stage, a flag, a bound in the
+    // list, a verdict that has to be computed - leaves `repeats` false, and one such point makes k_decide run.
+    {
+        const int t = T[j];
+        const Cand c1 = cq[0], c2 = cq[1];
+        if (flags == 0 && t >= 0 && dpath[j] == 0 && c1.slot >= 0 && ver.tgt[j] == t && ver.acc[j] != 0) {
+            const int head0 = 0xFFFFF - (int)(tcq[0] & 0xFFFFFull);
+            const bool dirty0 = ((tcq[0] >> 20) == stamp && head0 < j) || (la_mode && (coq[0] >> 20) == wseq);
+            if (!dirty0) {
+                // the clean best stands for its MC: it wins unless the best live version beats it; it must be the claim
+                repeats = c1.slot == t && !(first0.slot >= 0 && cand_less(first0.dist, first0.key, c1.dist, c1.key));
+            } else if (first0.slot >= 0 && (c2.slot == -1 || cand_less(first0.dist, first0.key, c2.dist, c2.key))) {
+                // the clean best was changed before j: the best live version has to beat whatever the second place
+                // holds (an exact candidate, clean or not, or a bound), belong to the claimed MC and be the state
+                // the chain added j to (its predecessor's version row, or the carried row)
+                if (first0.slot >= CC_CAR_BASE) repeats = car.slot[first0.slot - CC_CAR_BASE] == t;
+                else repeats = ver.tgt[first0.slot] == t && ver.next[first0.slot] == j;
+            }
+        }
+    }
     }
     // Sparse dirty scans (sparse_cap > 0: the host launches them instead of the tiles' scans): the points that need rows
     // only a dirty scan covers go on the round's list, one atomic per wave that holds any; a point that finds the list
@@ -484,6 +509,9 @@ __global__ __launch_bounds__(64) void k_dseed(Ctl* __restrict__ ctl, const doubl
         for (int kd = 0; kd < 3; ++kd) ver.tau[(size_t)j * CC_TAU_STRIDE + kd] = tau_w[kd];
         ver.unsafe[j] = flag_word;
     }
+    // (a tile whose dirty scans run gives k_decide more than the seeds to merge: not covered by the test above)
+    if (__builtin_amdgcn_ballot_w64(j < B && !(repeats && any_v == 0ull && any_c == 0ull)) != 0ull && threadIdx.x == 0)
+        ctl->rdiff[round] = 1;
     {
         // statistics for the host's trace line (one atomic per wave and only when something is flagged)
         const unsigned long long b1 = __builtin_amdgcn_ballot_w64(flag_unprov), b2 = __builtin_amdgcn_ballot_w64(flag_unsafe);
@@ -568,7 +596,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
                                                 int* __restrict__ long_list, int long_cap, int stat_tail, int last_round,
-                                                int heavy_on)
+                                                int heavy_on, int quiet_ok)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -603,6 +631,10 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         ctl->n_missed_all[q] = 0;
     }
     if (round > 0 && ctl->fc[round - 1] >= B) return;
+    // a quiet round: k_dseed established that every point's decision repeats its claim (Ctl::rdiff).  Nothing to write:
+    // the claims stand, the frontier stays at the window's end (fc[round] was reset when the window was opened), later
+    // rounds and the commit see a converged window.
+    if (round > 0 && quiet_ok != 0 && ctl->rdiff[round] == 0) return;
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
     if (j >= B) return;
@@ -969,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctl->last_round = round;
         ctl->n_sparse = 0;  // (k_dseed of this round fills the list of points for the sparse dirty scans)
+        ctl->rdiff[round] = 0;  // (... and says whether any decision of this round may differ from its claim)
     }
     const int gl = threadIdx.x & 31;
     const int j = blockIdx.x * (blockDim.x >> 5) + (threadIdx.x >> 5);
