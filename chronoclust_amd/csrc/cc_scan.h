@@ -1464,11 +1464,12 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // A split scan's sample describes this rank's rows only, and the host policy that reads the counters has to decide
     // alike on every rank: the sample then goes to the window's own pair of counters, travels with the rank's candidate
     // records (k_merge_partials) and k_decide adds up what all ranks sent - the same sum everywhere.
-    // The chain over a list of missed points (guessed thresholds) does not add to the sample: those points are the ones
-    // far from every microcluster, their waves complete most rows, and one such tile would outweigh the window's own
-    // in the ratio the policy reads - what they cost is bounded by their number instead (the policy returns to seeded
-    // thresholds when more than one point in sixteen is missed).
-    if (lane == 0 && blockIdx.x == 0 && n_rows > 0 && plist == nullptr) {
+    // (The chain over a list of missed points adds to the sample too: those points are the ones far from every
+    // microcluster, their waves complete most rows, and a stream in which they are many - a table that is still filling -
+    // is one on which the pruned chain does not pay.  Leaving them out was tried: the C5-shaped stream, which is all
+    // start-up, lost a quarter of its rate.  Split over ranks the list's scan runs behind the gather that carried the
+    // sample, so it stays out there.)
+    if (lane == 0 && blockIdx.x == 0 && n_rows > 0 && !(plist != nullptr && shard_world > 1)) {
         atomicAdd(pstat + win.q * 2, (unsigned long long)n_rows);
         atomicAdd(pstat + win.q * 2 + 1, (unsigned long long)n_full);
     }
