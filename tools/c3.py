@@ -22,7 +22,7 @@ if __name__ == "__main__":
     t0 = time.perf_counter()
     Xs = scenarios.make_blob_timepoints(sc, raw=True)
     print("generated %d x %d x %d in %.1f s" % (len(Xs), n, 20, time.perf_counter() - t0), flush=True)
-    tuning = {k.lower(): int(v) for k, v in os.environ.items() if k in ("WINDOW", "LOOKAHEAD", "SEGMENTS", "ROUNDS")}
+    tuning = {k.lower(): int(v) for k, v in os.environ.items() if k in ("WINDOW", "LOOKAHEAD", "SEGMENTS", "ROUNDS", "EARLY_WINDOW", "WINDOWS_PER_SYNC")}
     h = HDDStream(cfg, tuning=tuning or None)
     lineage, assoc = TrackByLineage(), TrackByHistoricalAssociation(handle=h._h)
     prefetch = os.environ.get("PREFETCH", "1") != "0"
