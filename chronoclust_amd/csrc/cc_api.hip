@@ -1506,6 +1506,9 @@ struct OnlineRun {
         c.stat_table_rows = 0;
         c.stat_seq_points = 0;
         c.stat_seq_r_points = 0;
+#ifdef CC_LONG_TIMERS
+        for (int i = 0; i < 8; ++i) c.dbg_long[i] = 0;
+#endif
         c.n_heavy = c.n_heavy_new = 0;  // (rows are renumbered between calls: the marks of the last call are void)
         HIPCHK(hipMemsetAsync(h->tab.heavy.p, 0, h->tab.cap * sizeof(int), h->stream));
         c.stat_seq_clk = c.stat_seq_wall = 0;
@@ -1965,6 +1968,10 @@ struct OnlineRun {
         h->stats.sharded_windows += sharded_windows;
         h->stats.seq_points += h->hc.stat_seq_points;
         h->stats.seq_r_points += h->hc.stat_seq_r_points;
+#ifdef CC_LONG_TIMERS
+        fprintf(stderr, "[cc] k_chain_long, workgroup 0 (shader cycles): collect %llu stage %llu chains %llu step-dim %llu step %llu rows %llu state %llu | batches %llu\n",
+                h->hc.dbg_long[0], h->hc.dbg_long[1], h->hc.dbg_long[2], h->hc.dbg_long[3], h->hc.dbg_long[4], h->hc.dbg_long[5], h->hc.dbg_long[6], h->hc.dbg_long[7]);
+#endif
         h->seq_sticky = seq_on;
         h->stats.table_rows_scanned += h->hc.stat_table_rows;
         h->stats.lookahead_windows += h->hc.stat_lookahead;

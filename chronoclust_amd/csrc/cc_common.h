@@ -245,6 +245,9 @@ struct Ctl {
     int n_heavy, n_heavy_new;
     int heavy_list[CC_HEAVY_CAP];
     int heavy_new[CC_HEAVY_NEW];
+#ifdef CC_LONG_TIMERS
+    unsigned long long dbg_long[8];  // build variant: shader cycles per phase of k_chain_long (workgroup 0 of each launch)
+#endif
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     // steps per batch: the CF1 / CF2 prefixes of a batch have to fit the staging area
     const int K = min(256, (CC_LONG_XY_DOUBLES / (2 * d)) & ~7);  // (256 at d <= 12, 216 at 14, 152 at 20, 72 at 40, 48 at 64)
 
-    __shared__ __attribute__((aligned(16))) double s_xy[CC_LONG_XY_DOUBLES];
+    __shared__ __attribute__((aligned(16))) double s_xy[CC_LONG_XY_DOUBLES + 2 * CC_MAX_DIM];  // (+ one odd-length pad per dimension)
     __shared__ double s_w[256], s_dq[256];
     __shared__ unsigned long long s_mask[256];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
     __shared__ int s_flag[256];                 // bit 0: radius test passed, bit 1: promotion condition holds
@@ -1300,8 +1300,15 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     __shared__ double s_term[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1], s_dqt[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
     __shared__ unsigned char s_pf[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
     const int NT = (int)blockDim.x;  // CC_LONG_THREADS: four waves per SIMD - these phases are instruction chains, not bandwidth
+    // staged coordinates / CF prefixes of a batch, dimension-major: entry (step k, dimension i) at i * Kp + k.  The chains
+    // walk a dimension's steps - contiguous, so their LDS operands have immediate offsets: a lone wave issues one
+    // instruction every ~8 cycles, and the address arithmetic of a step-major layout was two thirds of a step's
+    // instructions (54 -> 24 cycles per step, timed).  Kp is odd: threads that walk a step's dimensions (lanes = consecutive
+    // dimensions) then hit 32 different LDS banks.
+    const int Kp = K | 1;
     double* const xs = s_xy;
-    double* const ys = s_xy + (size_t)K * d;
+    double* const ys = s_xy + (size_t)Kp * d;
+    auto at = [&](int k, int i) { return i * Kp + k; };
 
     // running state of the chain (same meaning as k_chain's registers)
     int bkind = tab.kind[t], bkey = tab.key[t], bupg = -1;
@@ -1360,6 +1367,18 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         return (scanner && i0 <= last_j) ? T4[i0 >> 2] : make_int4(-1, -1, -1, -1);
     };
     int4 v_next = load_claims(scan_pos);
+    // coordinates requested one batch ahead (see phase 2): element e = tid + q NT of the next batch's staging area
+    constexpr int PRE = (CC_LONG_XY_DOUBLES / 2 + (SPLIT ? CC_LONG_THREADS : 256) - 1) / (SPLIT ? CC_LONG_THREADS : 256);
+    double pre[PRE];
+    int pre_elems = 0, pre_next = 0;  // elements of `pre` that are valid for the batch at hand / requested for the one after
+#ifdef CC_LONG_TIMERS
+    // build variant (-DCC_LONG_TIMERS): shader cycles per phase, workgroup 0 of every launch, printed at the end of a call
+    long long tk_prev = clock64();
+    unsigned long long tk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CC_TICK(i) do { const long long now_ = clock64(); tk_acc[i] += (unsigned long long)(now_ - tk_prev); tk_prev = now_; } while (0)
+#else
+#define CC_TICK(i) do { } while (0)
+#endif
 
     for (;;) {
         // ---- 1. members in order: ordered compaction of the next claims into the queue ----
@@ -1399,41 +1418,64 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             if (scan_pos > last_j) scan_done = true;
         }
         __syncthreads();
+        CC_TICK(0);  // member collection
         if (qcount == 0) break;
         const int n = qcount < K ? qcount : K;  // steps of this batch (the member after it is known, or the chain ends)
 
         // ---- 2. stage the points, then the sequential additions per dimension ----
-        for (int e = tid; e < n * d; e += NT) {
-            const int k = e / d, i = e - k * d;
-            const int m = s_queue[(qhead + k) & (QUEUE - 1)];
-            const double x = X[(cursor + m) * d + i];
-            xs[e] = x;
-            ys[e] = x * x;  // (the square every step adds to CF2: formed here, by all threads, instead of inside the chain)
+        // (the coordinates of the members the queue already held behind the previous batch were requested while that batch
+        // was evaluated - `pre`, valid if that batch consumed exactly its n members: a memory round trip per batch less)
+#pragma unroll
+        for (int q = 0; q < PRE; ++q) {
+            const int e = tid + q * NT;
+            if (e < n * d) {
+                const int k = e / d, i = e - k * d;
+                double x;
+                if (e < pre_elems) x = pre[q];
+                else x = X[(cursor + s_queue[(qhead + k) & (QUEUE - 1)]) * d + i];
+                xs[at(k, i)] = x;
+                ys[at(k, i)] = x * x;  // (the square every step adds to CF2: formed here, by all threads, instead of inside the chain)
+            }
+        }
+        // the next batch's coordinates, as far as its members are known: in flight during this batch's phases
+        {
+            const int n_ahead = min(K, qcount - n);
+#pragma unroll
+            for (int q = 0; q < PRE; ++q) {
+                const int e = tid + q * NT;
+                if (e < n_ahead * d) {
+                    const int k = e / d, i = e - k * d;
+                    pre[q] = X[(cursor + s_queue[(qhead + n + k) & (QUEUE - 1)]) * d + i];
+                }
+            }
+            pre_next = n_ahead * d;
         }
         if (tid == 0) { s_first_fail = n; s_first_up = n; }
         __syncthreads();
+        CC_TICK(1);  // staging
         // The three running sums are chains of dependent additions, a dozen instructions per step for ONE wave that has
         // its SIMD to itself: CF1 in the first wave, CF2 in the second, W in the third, side by side
         // (mc_functions.py:24-29 / microcluster.py:147: the additions k_chain makes, in its order).
-        // (eight steps at a time: the eight LDS reads go out together, then the eight additions in order, then the eight
-        // writes - read, add, write per step would wait out one LDS round trip per step)
+        // (sixteen steps at a time: the sixteen LDS reads go out together, then the sixteen additions in order, then the
+        // sixteen writes - read, add, write per step would wait out one LDS round trip per step)
         auto prefix_chain = [&](double* a, int i, double c) {
+            double* const row = a + (size_t)i * Kp;
             int k = 0;
-            for (; k + 8 <= n; k += 8) {
-                double v[8];
+            for (; k + 16 <= n; k += 16) {
+                double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = a[(k + u) * d + i];
+                for (int u = 0; u < 16; ++u) v[u] = row[k + u];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < 16; ++u) {
                     c = c + v[u];
                     v[u] = c;
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) a[(k + u) * d + i] = v[u];
+                for (int u = 0; u < 16; ++u) row[k + u] = v[u];
             }
             for (; k < n; ++k) {
-                c = c + a[k * d + i];
-                a[k * d + i] = c;
+                c = c + row[k];
+                row[k] = c;
             }
         };
         if (tid < d) {
@@ -1441,13 +1483,27 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         } else if (tid >= 64 && tid < 64 + d) {
             prefix_chain(ys, tid - 64, s_b2[tid - 64]);
         } else if (tid == 128) {
+            // (unrolled like the two above: with a loop per step, this chain - one addition per step - was the slowest of
+            // the three once theirs had lost their address arithmetic)
             double w = s_bw;
-            for (int k = 0; k < n; ++k) {
+            int k = 0;
+            for (; k + 16 <= n; k += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    w = w + 1.0;
+                    v[u] = w;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s_w[k + u] = v[u];
+            }
+            for (; k < n; ++k) {
                 w = w + 1.0;
                 s_w[k] = w;
             }
         }
         __syncthreads();
+        CC_TICK(2);  // chains
 
         // ---- 3. every step evaluated on its own prefix ----
         // (a) per (step, dimension), all threads: the two quotients, the variance, the term of the radius sum - the
@@ -1456,8 +1512,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         for (int e = tid; e < n * d; e += NT) {
             const int k = e / d, i = e - k * d;
             const double w1 = s_w[k];
-            const double qa = ys[e] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
-            const double qb = xs[e] / w1;
+            const double qa = ys[at(k, i)] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
+            const double qb = xs[at(k, i)] / w1;
             const double var = qa - qb * qb;
             const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
             const double pr = prefd ? par.k : 1.0;
@@ -1467,8 +1523,10 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             s_dqt[e] = df * df * s_w0[i];
         }
         __syncthreads();
+        CC_TICK(3);  // per (step, dimension)
         }
         // (b) per step, one thread: the ordered sums over the dimensions (!SPLIT: the terms themselves as well)
+        // (dealing the steps round all sixteen waves instead of packing them into four was timed: 7.0 -> 10.5 M cycles)
         if (tid < n) {
             const int k = tid;
             const double w1 = s_w[k];
@@ -1483,8 +1541,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
                     gt1 += (prefd && par.k > 1.0) ? 1 : 0;    // count(pref' > 1): pref' = k where preferred
                     mask |= prefd ? (1ull << i) : 0ull;
                 } else {
-                    const double qa = ys[k * d + i] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
-                    const double qb = xs[k * d + i] / w1;
+                    const double qa = ys[at(k, i)] / w1;  // mc_functions.py:14-22 (cc_sqvar), keeping CF1 / W
+                    const double qb = xs[at(k, i)] / w1;
                     const double var = qa - qb * qb;
                     const bool prefd = var <= par.delta_sq;  // microcluster.py:109-114 (NaN -> 1.0)
                     const double pr = prefd ? par.k : 1.0;
@@ -1504,6 +1562,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             if (up) atomicMin(&s_first_up, k);
         }
         __syncthreads();
+        CC_TICK(4);  // per step
         const int f = s_first_fail;                 // first rejected step (n: none)
         const int n_ok = f < n ? f : n;             // accepted steps 0 .. n_ok - 1
         const int n_rows = f < n ? f + 1 : n;       // members consumed by this batch (the rejected one included)
@@ -1519,7 +1578,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             const int src = (k < n_ok) ? k : k - 1;  // a rejected step leaves the state of the step before it
             double c1, c2, ce, pr;
             if (src >= 0) {
-                c1 = xs[src * d + i]; c2 = ys[src * d + i];
+                c1 = xs[at(src, i)]; c2 = ys[at(src, i)];
                 ce = c1 / s_w[src];  // mc_functions.py:31-33: the quotient the variance was formed from
                 pr = ((s_mask[src] >> i) & 1ull) ? par.k : 1.0;
             } else {
@@ -1553,13 +1612,14 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             atomicMax(&ver.tile_dsq[(size_t)(m >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
         }
         __syncthreads();  // every read of the running state and of the queue slots is done
+        CC_TICK(5);  // version rows
 
         // ---- 5. the running state moves on to the last accepted step ----
         if (n_ok > 0) {
             const int l = n_ok - 1;
             if (tid < d) {
-                s_b1[tid] = xs[l * d + tid]; s_b2[tid] = ys[l * d + tid];
-                s_bcen[tid] = xs[l * d + tid] / s_w[l];
+                s_b1[tid] = xs[at(l, tid)]; s_b2[tid] = ys[at(l, tid)];
+                s_bcen[tid] = xs[at(l, tid)] / s_w[l];
                 s_bpref[tid] = ((s_mask[l] >> tid) & 1ull) ? par.k : 1.0;
             }
             if (tid == 64) { s_bw = s_w[l]; s_bdq = s_dq[l]; s_bmask = s_mask[l]; }
@@ -1571,8 +1631,17 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         qhead = (qhead + n_rows) & (QUEUE - 1);
         qcount -= n_rows;
         walked += n_rows;
+        pre_elems = (n_rows == n) ? pre_next : 0;  // (a rejected step ends the batch early: the next one starts elsewhere)
         __syncthreads();
+        CC_TICK(6);  // state moves on
+#ifdef CC_LONG_TIMERS
+        tk_acc[7] += 1ull;
+#endif
     }
+#ifdef CC_LONG_TIMERS
+    if (tid == 0 && blockIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&ctl->dbg_long[i], tk_acc[i]);
+#endif
     if (tid == 0) {
         tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it
         if (promoted_any) ctl->any_up[round] = 1;
