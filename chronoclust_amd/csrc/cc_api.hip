@@ -136,10 +136,12 @@ struct cc_handle {
     bool prune_now = false;   // this batch's snapshot scans are pruned ones (set per batch by online_range)
     bool group_guess_now = false;     // ... and the missed points derived from the gathered records (k_missed_g), see timed_scan
     bool group_guess_always = false;  // CHRONOCLUST_HIP_GROUP_GUESS=1: also in a group of one rank
+    bool lean_now = false;    // ... guessed thresholds without k_missed / the seeded chain for missed points (cc_policy_decision::prune == 3)
     bool guess_now = false;   // ... with guessed thresholds (k_scan_p + k_missed + the seeded chain for the missed points)
     bool probe_now = false;   // the next plain scan also runs the pruned chain on 128 points (cc_policy_decision::probe)
     DevBuf<Cand> probe_part;  // ... into these scratch partials
     bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
+    bool allow_lean = true;   // CHRONOCLUST_HIP_LEAN=0: guessed scans always list and rescan the points they missed
     bool allow_probe = true;  // CHRONOCLUST_HIP_PROBE=0: pruned scans are retried blindly after a stretch of points
     DevBuf<unsigned long long> found;  // [2][CC_MAX_WINDOW / 64] per point tile: the points a guessed-threshold scan found a pcore MC for
     DevBuf<int> missed;                // [2][CC_MISSED_CAP] the others, listed by k_missed (two window parities)
@@ -576,7 +578,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                            rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
                                            h->part_stride, shard_rank, shard_world, h->pstat_p(), (const int*)nullptr,
-                                           h->prune_F, h->found.p);
+                                           h->prune_F, h->lean_now ? (unsigned long long*)nullptr : h->found.p);
                         return;
                     }
                     if (h->guess_now) {
@@ -586,7 +588,12 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         int* const list = h->missed.p;  // (the kernels take the half of the window's parity)
                         hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                            rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           h->part_stride, 0, 1, h->pstat_p(), (const int*)nullptr, h->prune_F, h->found.p);
+                                           h->part_stride, 0, 1, h->pstat_p(), (const int*)nullptr, h->prune_F,
+                                           h->lean_now ? (unsigned long long*)nullptr : h->found.p);
+                        if (h->lean_now) {  // (nobody is expected to be missed: see cc_policy.h)
+                            ++h->stats.scan_lean_launches;
+                            return;
+                        }
                         hipLaunchKernelGGL(k_missed, dim3(1), dim3(1024), 0, st, h->ctl.p, h->found.p, list, CC_MISSED_CAP, round, mode);
                         seeded_chain(CC_MISSED_CAP, list, part, h->part_stride, S);
                         return;
@@ -826,6 +833,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_probe = !(pb && pb[0] == '0');
         const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
         h->allow_guess = !(gs && gs[0] == '0');
+        const char* ln = getenv("CHRONOCLUST_HIP_LEAN");
+        h->allow_lean = !(ln && ln[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
         if (sp && atoi(sp) >= 0) h->allow_sparse = atoi(sp);
         push_ctl(h);
@@ -1482,7 +1491,7 @@ struct OnlineRun {
         pcfg.d = h->d;
         pcfg.resume = resume ? 1 : 0;
         pcfg.allow_sparse = h->allow_sparse;
-        pcfg.allow_guess = h->allow_guess ? 1 : 0;
+        pcfg.allow_guess = h->allow_guess ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
         pcfg.allow_probe = h->allow_probe ? 1 : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.n_end = N;
@@ -1561,7 +1570,8 @@ struct OnlineRun {
         Rcur = dec.rounds;
         batch_windows = dec.batch_windows;
         h->prune_now = dec.prune != 0;
-        h->guess_now = dec.prune == 2;
+        h->guess_now = dec.prune >= 2;
+        h->lean_now = dec.prune == 3;
         nodirty = dec.nodirty != 0;
         sparse_now = dec.sparse != 0;
         cursor_prev = range_a;
@@ -1731,7 +1741,8 @@ struct OnlineRun {
                                        (const int*)nullptr);
                     h->comm.all_gather(h->gsend.p + (size_t)q * h->gsend_stride, h->gpart.p + (size_t)q * h->gpart_stride,
                                        ((size_t)gw * 4 + 4) * sizeof(Cand), st, st == h->stream2 ? 1 : 0);
-                    if (h->prune_now && h->guess_now && h->group_guess_now) {
+                    if (h->prune_now && h->guess_now && h->group_guess_now && h->lean_now) ++h->stats.scan_lean_launches;
+                    if (h->prune_now && h->guess_now && h->group_guess_now && !h->lean_now) {
                         // guessed thresholds: the points no rank found a pcore MC for (a function of the gathered records:
                         // the same list everywhere) go through the seeded chain on every rank's rows, their new records
                         // are exchanged in a second, small all-gather of fixed size and take the place of the old ones
@@ -1906,7 +1917,8 @@ struct OnlineRun {
             sparse_now = dec.sparse != 0;
             shard_on = dec.shard != 0;
             h->prune_now = dec.prune != 0;
-            h->guess_now = dec.prune == 2;
+            h->guess_now = dec.prune >= 2;
+        h->lean_now = dec.prune == 3;
             if (dec.restart) {
                 h->hc.win_cfg = dec.win_cfg;
                 h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);

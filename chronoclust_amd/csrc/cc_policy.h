@@ -51,6 +51,8 @@ public:
         prune_resume_at_ = 0;
         prune_backoff_ = 65536;
         guess_on_ = false;
+        lean_on_ = false;
+        clean_guess_batches_ = 0;
         guess_resume_at_ = 0;
         stalled_ = 0;
         first_batch_ = true;
@@ -201,7 +203,16 @@ public:
         // for 2^18 points.  (Split over ranks as well: the list of missed points is derived from the gathered records.)
         const long long missed = o.stat_missed - prev_.stat_missed;
         if (guess_on_ && pts > 0 && missed * 16 > pts) guess_resume_at_ = o.cursor + (1ll << 18);
+        const bool guess_was = guess_on_;
         guess_on_ = prune_on_ && c_.allow_guess != 0 && o.tg_ok != 0 && o.cursor >= guess_resume_at_;
+        // Lean guessed scans: in a settled stream no point is missed for hundreds of windows, yet every window pays for
+        // the machinery that would rescan one - k_missed, the seeded chain's three launches over an empty list, in a
+        // group the second all-gather: a fifth of the scan chain's time.  After a batch with guessed thresholds and not one
+        // missed point the scans run without it; a point that is missed then keeps its bound,
+        // k_decide refuses it (and counts it: stat_missed), the window commits up to it, the batch idles behind it, and the
+        // next batch - this rule seeing the count - brings the machinery back.  (allow_guess == 2: never lean.)
+        clean_guess_batches_ = (guess_was && guess_on_ && wins > 0 && missed == 0) ? clean_guess_batches_ + 1 : 0;
+        lean_on_ = guess_on_ && c_.allow_guess == 1 && clean_guess_batches_ >= 1;
         const bool more = done < c_.n_end;
         const int restart = ((want != win_cfg_ || want_la != la_on_ || o.stall_b > 0 || shard_flip || prune_flip) && more) ? 1 : 0;
         if (restart) {
@@ -243,7 +254,7 @@ private:
         // scans cannot pay yet, and on short windows even the probe's three small launches are a few per cent of a batch)
         d.probe = (c_.allow_probe != 0 && c_.prune_applicable != 0 && c_.prune_mode == 1 && !prune_on_ && probe_gate_ &&
                    prune_resume_at_ != std::numeric_limits<long long>::max()) ? 1 : 0;
-        d.prune = prune_on_ ? (guess_on_ ? 2 : 1) : 0;
+        d.prune = prune_on_ ? (guess_on_ ? (lean_on_ ? 3 : 2) : 1) : 0;
         d.shard = shard_on_ ? 1 : 0;
         d.restart = restart;
         d.bad = bad;
@@ -258,6 +269,8 @@ private:
     long long prune_resume_at_ = 0, prune_backoff_ = 65536;  // pruned scans are tried again from this point on / stretch after the next failed try
     long long guess_resume_at_ = 0;                          // guessed thresholds are tried again from this point on
     bool guess_on_ = false;
+    bool lean_on_ = false;         // guessed thresholds without the list of missed points and their seeded chain
+    int clean_guess_batches_ = 0;  // batches in a row with guessed thresholds and no missed point
     bool probe_ok_ = false;    // the last probe of the pruned chain completed few rows: pruned scans would pay
     bool prev_probe_ = false;  // the batch that just ran carried a probe
     bool probe_gate_ = false;  // the last batch's table did not grow and most of its tiles were clean: a probe is worth its cost

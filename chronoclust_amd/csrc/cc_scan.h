@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // bounded by it.  A point whose own MC lies beyond the guess ends with a bound in first place; the wave that does
     // find a pcore MC within the threshold marks its points in `found`, k_missed lists the unmarked ones and the seeded
     // chain runs for them alone (plist).  No mean for the kind yet: +inf, every row of the kind is evaluated.
-    const bool guessed = found != nullptr;
+    const bool guessed = guess_F > 0.0;  // (found may be null: a lean guessed scan - nobody lists the missed points)
     if (guessed) {
         double pm = 0.0;
 #pragma unroll
@@ -1454,7 +1454,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     // recorded of them
     if (dropped[0]) lb[0] = cc_vmin(lb[0], th[0]);
     if (dropped[1]) lb[1] = cc_vmin(lb[1], th[1]);
-    if (guessed) {
+    if (guessed && found != nullptr) {
         // the points for which this wave evaluated a pcore MC within the guessed threshold: their pcore list's best is exact
         const unsigned long long fm = __builtin_amdgcn_ballot_w64(valid && bs[0][0] >= 0 && bd[0][0] <= th[0]);
         if (lane == 0 && fm != 0ull) atomicOr(found + (size_t)win.q * (CC_MAX_WINDOW / 64) + blockIdx.x, fm);

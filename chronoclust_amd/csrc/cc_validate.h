@@ -627,7 +627,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         ctl->pstat[q][1] = 0ull;
         ctl->stat_prune_rows += rows;
         ctl->stat_prune_full += full;
-        ctl->stat_missed += ctl->n_missed_all[q];
+        // (atomic: the groups of this launch that refuse a point whose first place is a bound add to the same counter)
+        if (ctl->n_missed_all[q] != 0) atomicAdd((unsigned long long*)&ctl->stat_missed, (unsigned long long)ctl->n_missed_all[q]);
         ctl->n_missed_all[q] = 0;
     }
     if (round > 0 && ctl->fc[round - 1] >= B) return;
@@ -738,7 +739,13 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         int state;  // 0: no clean candidate, 1: cb is the exact clean best, 2: cb only bounds the clean best from below
         Cand cb = none;
         if (c1.slot == -1) state = 0;
-        else if (c1.slot == CC_SLOT_BOUND) { T = CC_T_UNKNOWN; return; }  // (a pruned scan never leaves this)
+        else if (c1.slot == CC_SLOT_BOUND) {
+            // a guessed threshold missed the point's own MC and nobody rescanned it (the list of missed points was full,
+            // or the scan ran lean - without that list, see cc_policy.h): refused; counted, so that the policy hears of it
+            if (gl == 0 && round == 0 && stage == 0) atomicAdd((unsigned long long*)&ctl->stat_missed, 1ull);
+            T = CC_T_UNKNOWN;
+            return;
+        }
         else if (!dirty(c1.slot)) { state = 1; cb = c1; }
         else if (c2.slot == -1) state = 0;
         else if (c2.slot == CC_SLOT_BOUND) { state = 2; cb = c2; }  // the clean rows are only known to be >= c2.dist

@@ -126,6 +126,7 @@ typedef struct cc_stats {
     int64_t probe_launches;        /* plain scans that carried a probe of the pruned chain (128 points)          */
     int64_t seq_r_points;          /* of seq_points: taken by the register-resident sequential kernel (d <= 4)    */
     int64_t heavy_launches;        /* k_claims_heavy launches (claims of heavy rows gathered without k_decide's atomics) */
+    int64_t scan_lean_launches;    /* of scan_g_launches: lean - no list of missed points, no seeded chain behind the scan */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -326,7 +327,8 @@ typedef struct cc_policy_config {
     int32_t d;
     int32_t resume;            /* the call continues a stream this handle was clustering a moment ago              */
     int32_t allow_sparse;      /* sparse dirty scans while at most one point in this many needs them (0: never)     */
-    int32_t allow_guess;       /* pruned scans may take table-wide guessed thresholds (CHRONOCLUST_HIP_GUESS != 0)    */
+    int32_t allow_guess;       /* pruned scans may take table-wide guessed thresholds (CHRONOCLUST_HIP_GUESS != 0); 1: and
+                                  run lean - without the list of missed points - after a batch without a miss, 2: never lean */
     int32_t allow_probe;       /* pruned scans come back on a probe's word (CHRONOCLUST_HIP_PROBE != 0), else after a
                                 * stretch of points that doubles with every failed try                               */
     int64_t shard_min_row_dims;

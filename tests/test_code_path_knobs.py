@@ -28,6 +28,7 @@ KNOBS = {
     "sparse dirty scans eager": dict(CHRONOCLUST_HIP_SPARSE=2),  # whenever at most every second point needs them
     "two communicators": dict(CHRONOCLUST_HIP_TWO_COMMS=1),
     "register sequential kernel off": dict(CHRONOCLUST_HIP_SEQR=0),  # k_seq (table in LDS) also for d <= 4
+    "lean guessed scans off": dict(CHRONOCLUST_HIP_LEAN=0),  # k_missed and the seeded chain behind every guessed scan
     "quiet rounds off": dict(CHRONOCLUST_HIP_QUIET=0),  # k_decide re-derives every decision of every validation round
     "heavy rows off": dict(CHRONOCLUST_HIP_HEAVY=0),  # k_decide's atomics also for rows with thousands of claimants
 }

@@ -243,3 +243,42 @@ def test_guessed_thresholds_miss_a_loose_population():
         assert seeded.stats()["scan_g_launches"] == 0
     assert guessed > 0 and missed > 0
     print("guessed-threshold launches %d, points missed %d" % (guessed, missed))
+
+
+def test_lean_guessed_scans_and_a_population_that_appears_late():
+    """Lean guessed scans (round 4): after a batch with guessed thresholds and no missed point the scans run without
+    k_missed and the seeded chain.  A population that appears in the middle of a settled stream is then missed by the
+    guess: its first point keeps a bound in first place, k_decide refuses it, the window commits up to it, the batch idles,
+    and the policy - hearing of the refusal through stat_missed - brings the chain back.  The oracle's results all the
+    same, with lean scans before and after; the same stream in a group of two ranks (no second all-gather while lean);
+    and with CHRONOCLUST_HIP_LEAN=0."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    n, d, g, late = 900_000, 20, 400, 12
+    centres = rng.uniform(0.1, 0.9, (g + late, d))
+    lab = rng.integers(0, g, n)
+    for s in range(late):  # twelve populations that start at different places of the last third
+        start = 2 * n // 3 + s * 20_000
+        idx = start + np.flatnonzero(rng.random(n - start) < 0.004)
+        lab[idx] = g + s
+    X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 0.006, (n, d)), 0.0, 1.0))
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    o = O.OracleHDDStream(cfg)
+    o.online_microcluster_maintenance(X, 0)
+    h = _hdd(cfg, 1, window=8192)  # (the library's own policy)
+    h.online_microcluster_maintenance(X, 0)
+    _against_oracle(h, o)
+    s = h.stats()
+    assert s["scan_lean_launches"] > 0 and s["scan_g_launches"] > s["scan_lean_launches"] and s["missed_points"] > 0, s
+    with _env(CHRONOCLUST_HIP_LEAN=0):
+        full = _hdd(cfg, 1, window=8192)
+    full.online_microcluster_maintenance(X, 0)
+    _same_state(h, full)
+    assert full.stats()["scan_lean_launches"] == 0 and full.stats()["scan_g_launches"] > 0
+    # split over two ranks (in-process group): the same results, lean windows without the second gather
+    import pipeline_util as PU
+    from test_sharded_local import run_group
+    single = PU.run_pipeline([X], cfg, tuning=dict(window=8192))
+    for r in run_group(2, [X], cfg, tuning=dict(window=8192)):
+        PU.same_results(r, single)
+        assert r[0]["stats"]["scan_lean_launches"] > 0 and r[0]["stats"]["sharded_windows"] > 0
