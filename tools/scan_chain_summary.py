@@ -1,8 +1,10 @@
 """The snapshot scan of a bench run as rocprofv3 saw it, beside the bench line's own HIP-event figure.
 
 A timed scan launch of bench.py is either one k_scan_u / k_scan launch or, when the scan is pruned, the chain
-k_seed -> k_seed_merge -> k_scan_p on one stream.  This sums the kernel-trace durations of all of them and divides by the
-number of chains (= k_scan_p + k_scan_u + clean k_scan dispatches), which is what `roofline.avg_launch_us` measures.
+k_seed -> k_seed_merge -> k_scan_p on one stream (seeded), k_scan_p -> k_missed -> the seeded chain over the missed points
+(guessed thresholds), or k_scan_p alone (lean).  This sums the kernel-trace durations of all of them and divides by the
+number of launches (window-level k_scan_p + k_scan_u + clean k_scan dispatches), which is what `roofline.avg_launch_us`
+measures.
 Usage: scan_chain_summary.py <rocprof dir> <bench json> [leg name]"""
 import glob
 import json
@@ -32,8 +34,10 @@ for k, m in parts.items():
 ks = df[parts["k_seed"]]
 probes = int((ks["Grid_Size_Y"] > 64).sum()) if len(ks) else 0
 out["probes"] = probes
-chains = out["kernels"].get("k_seed_merge", {}).get("calls", 0) - probes + \
-    sum(out["kernels"].get(k, {}).get("calls", 0) for k in ("k_scan_u", "k_scan (LDS-staged, clean)"))
+# Every pruned launch has exactly one window-level k_scan_p; a k_missed is followed by one more (over the list of missed
+# points, same launch), a probe has one of its own (inside a plain launch); lean guessed scans are a k_scan_p and nothing else.
+calls = {k: out["kernels"].get(k, {}).get("calls", 0) for k in parts}
+chains = calls["k_scan_p"] - calls["k_missed"] - probes + calls["k_scan_u"] + calls["k_scan (LDS-staged, clean)"]
 out["scan_chains"] = chains
 out["rocprof_avg_chain_us"] = total / chains if chains else None
 line = json.load(open(sys.argv[2]))
