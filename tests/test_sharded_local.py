@@ -286,3 +286,26 @@ def test_rccl_transport_carries_the_second_gather_of_guessed_thresholds():
     assert sum(r["stats"]["scan_g_launches"] for r in res) > 0 and sum(r["stats"]["missed_points"] for r in res) > 0
     assert all(r["stats"]["sharded_windows"] == r["stats"]["windows"] > 0 for r in res)
     h._h.comm_destroy()
+
+
+def test_skewed_stream_in_a_group():
+    """Heavy rows (three populations take 30 % of the events) with every scan split over two ranks: the marks and the list
+    of heavy rows are kept by the replicated validation kernels, the host's decision to launch k_claims_heavy rests on a
+    counter that is the same on every rank - the single-GPU results, and the kernel really used."""
+    rng = np.random.default_rng(99)
+    n, d, g = 300_000, 14, 1500
+    centres = rng.uniform(0.05, 0.95, (g, d))
+    Xs = []
+    for _ in range(2):
+        lab = rng.integers(3, g, n)
+        big = rng.random(n) < 0.3
+        lab[big] = rng.integers(0, 3, int(big.sum()))
+        Xs.append(np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 0.004, (n, d)), 0.0, 1.0)))
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    single = P.run_pipeline(Xs, cfg, tuning=dict(window=8192))
+    assert sum(r["stats"]["heavy_launches"] for r in single) > 0
+    res = run_group(2, Xs, cfg, tuning=dict(window=8192))
+    for r in res:
+        P.same_results(r, single)
+        assert sum(x["stats"]["heavy_launches"] for x in r) > 0 and all(x["stats"]["sharded_windows"] > 0 for x in r)
+    assert [x["stats"]["heavy_launches"] for x in res[0]] == [x["stats"]["heavy_launches"] for x in res[1]]
