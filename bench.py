@@ -605,7 +605,7 @@ def main():
     ap.add_argument("--stream-blobs", type=int, default=50_000)
     ap.add_argument("--stream-steps", type=int, default=2)
     ap.add_argument("--stream-warmup", type=int, default=1)
-    ap.add_argument("--stream-timeout", type=float, default=240.0,
+    ap.add_argument("--stream-timeout", type=float, default=120.0,
                     help="seconds after which a one-stream leg that has not finished is abandoned")
     ap.add_argument("--strict-legs", action="store_true",
                     help="exit with status 3 when a side leg fails or is abandoned (default: the headline line is printed, "
