@@ -32,8 +32,11 @@ ranks / the 128-byte RCCL id travel over chronoclust_amd.rendezvous (TCP on 127.
     python bench.py --gpus N --dry-launch
         the ranks only meet (rendezvous, barrier) and rank 0 prints who came: the launch path without a GPU
 
-Prints ONE JSON line on rank 0.  Exit status: 0 when every leg ran; 3 when a leg was abandoned (a collective that
-never completed) or failed - the line is still printed, with the error in that leg's object.
+Prints ONE JSON line (< 4 KB: compact_line) on rank 0 and writes the full record - per-kernel counters, notes, the legs'
+own objects - to bench_detail.json beside this file (CHRONOCLUST_BENCH_DETAIL overrides the path; the line names it).
+Exit status: 0 when the headline was measured and every leg returned (a leg that FAILED is named in `legs_failed`, its
+error in `leg_errors`; --strict-legs makes that status 3); 3 when a leg was abandoned (a collective that never
+completed) - the line is still printed.
 """
 import argparse
 import hashlib
@@ -51,21 +54,147 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-PMC_VALU_FILE = os.path.join(ROOT, "profiles", "r04_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
+PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")
+PMC_VALU_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
+SCAN_SOURCES = ("cc_scan.h", "cc_common.h", "cc_div.h")  # what defines the snapshot-scan kernels the PMC files describe
 REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
 EXIT_LEG_FAILED = 3
 
 
-def csrc_digest():
-    """SHA-256 over the kernel sources: a PMC traffic figure is only quoted for the kernels it was measured on."""
+def csrc_digest(names=None):
+    """SHA-256 over the kernel sources (all of csrc/, or the named files): a PMC figure is only quoted for the kernels it
+    was measured on."""
     m = hashlib.sha256()
     d = os.path.join(ROOT, "chronoclust_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".h", ".hip")):
+        if name.endswith((".h", ".hip")) and (names is None or name in names):
             with open(os.path.join(d, name), "rb") as f:
                 m.update(name.encode() + b"\0" + f.read())
     return m.hexdigest()
+
+
+def scan_digest():
+    """The sources of the snapshot-scan kernels alone: a change to the validation or offline kernels leaves the scan's
+    counters valid."""
+    return csrc_digest(SCAN_SOURCES)
+
+
+def pmc_matches(pm):
+    """A PMC summary counts for this build when it was measured on these scan sources (files of round 5 on carry
+    `scan_sha256`; earlier ones only the digest of all of csrc/)."""
+    if "scan_sha256" in pm:
+        return pm["scan_sha256"] == scan_digest()
+    return pm.get("csrc_sha256") == csrc_digest()
+
+
+def newest_pmc(pattern):
+    """(summary, file name) of the newest round's PMC file of this pattern that matches the build, else (None, why)."""
+    import glob
+    why = "no PMC file %s" % os.path.basename(pattern)
+    for path in sorted(glob.glob(pattern), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if pmc_matches(pm):
+            return pm, os.path.basename(path)
+        why = "profiles/%s was measured on other scan-kernel sources (digest differs)" % os.path.basename(path)
+    return None, why
+
+
+DETAIL_FILE = os.environ.get("CHRONOCLUST_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+LINE_LIMIT = 4096   # bytes of the ONE stdout line (tests/test_host_logic.py::test_bench_line_is_compact holds it)
+LEG_NAMES = ("one_stream_exact", "events_sharded_relaxed", "one_stream_exact_c2", "events_sharded_relaxed_c2")
+
+
+def _r(x, digits=6):
+    """Floats of the line with 6 significant digits (the detail file keeps them all)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _r(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, digits) for v in x]
+    return x
+
+
+def compact_line(full, detail_file=None):
+    """The ONE stdout line: the contract's keys, a flat `roofline` and `cpu_baseline`, one small object per strong-scaling
+    leg - below LINE_LIMIT bytes whatever the run did.  Everything else (per-kernel counters, notes, parts, the legs' own
+    objects and rooflines) is in the detail file this line names."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "points", "dim", "microclusters", "clusters", "streams") if k in cfg}
+    line["config"]["workload"] = str(cfg.get("workload", ""))[:160]
+    for k in ("online_only_points_per_s", "value_with_transfers"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    rf = full.get("roofline")
+    if rf:
+        ex = (rf.get("executed") or {}).get("kernels") or {}
+        dom = ex.get("k_scan_p") or ex.get("k_scan_u") or {}
+        hbm = rf.get("hbm") or {}
+        line["roofline"] = {
+            "bound": rf.get("bound"), "kernel": str(rf.get("kernel", ""))[:120], "achieved": rf.get("achieved"),
+            "peak": rf.get("peak"), "unit": str(rf.get("unit", ""))[:60], "frac": rf.get("frac"),
+            "valu_busy": dom.get("valu_busy_fraction"), "effective_frac": (rf.get("effective") or {}).get("frac"),
+            "hbm_frac": hbm.get("frac"), "hbm_achieved_gbs": hbm.get("achieved"), "hbm_peak_gbs": hbm.get("peak"),
+            "traffic": rf.get("traffic"), "algorithmic_bytes": hbm.get("algorithmic_bytes_per_launch"),
+            "launches": rf.get("launches"), "avg_launch_us": rf.get("avg_launch_us"),
+            "pmc_source": rf.get("pmc_source"), "derived": rf.get("derived")}
+    cb = full.get("cpu_baseline")
+    if cb:
+        ref = cb.get("reference_py") or {}
+        allc = cb.get("all_cores") or {}
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"),
+                                "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:140],
+                                "labels_match_gpu_prefix": cb.get("labels_match_gpu_prefix"),
+                                "all_cores_value": allc.get("value"), "all_cores": allc.get("cores"),
+                                "reference_py": ref.get("value")}
+    ss = full.get("strong_scaling")
+    if ss:
+        legs = {}
+        for name in LEG_NAMES:
+            leg = ss.get(name)
+            if leg:
+                legs[name] = {k: leg.get(k) for k in ("value", "ms_per_step", "n_gpus", "rccl_ranks_seen",
+                                                     "all_ranks_bit_identical", "semantics", "sharded_windows_per_step",
+                                                     "agreement_with_exact_by_cluster", "predicted_value") if leg.get(k) is not None}
+        line["strong_scaling"] = dict(legs, unit="points/s of ONE stream on all n_gpus ranks")
+    for name in LEG_NAMES:
+        if isinstance(full.get(name), dict) and "error" in full[name]:
+            line.setdefault("leg_errors", {})[name] = str(full[name]["error"])[:120]
+    line["legs_failed"] = list(full.get("legs_failed", []))
+    if full.get("incomplete"):
+        line["incomplete"] = str(full["incomplete"])[:100]
+    line["detail_file"] = detail_file
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:  # (cannot happen with the bounded fields above; the contract's keys survive whatever does)
+        for k in ("strong_scaling", "leg_errors", "cpu_baseline"):
+            if len(text) >= LINE_LIMIT and k in line:
+                line[k] = "see detail_file"
+                text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def write_detail(full, path=None):
+    """The full record beside the line (atomically: a reader never sees half a file).  Returns the path, or None when the
+    directory cannot be written (the line then says so by carrying no detail_file)."""
+    path = path or DETAIL_FILE
+    try:
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+        os.replace(tmp, path)
+        return os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+    except OSError as e:
+        sys.stderr.write("[bench] detail file %s not written: %s\n" % (path, e))
+        return None
 
 
 class LineGuard:
@@ -100,8 +229,13 @@ class LineGuard:
                     if kind != b"F":
                         obj = json.loads(payload)
                         obj["incomplete"] = "the process ended before the remaining legs of the run had finished"
-                        payload = json.dumps(obj).encode()
-                    os.write(out_fd, payload + b"\n")
+                        payload = json.dumps(obj, separators=(",", ":")).encode()
+                    data = payload + b"\n"
+                    while data:  # (a short write - a non-blocking or full pipe - must not cut the line)
+                        try:
+                            data = data[os.write(out_fd, data):]
+                        except BlockingIOError:
+                            time.sleep(0.01)
             except BaseException:  # noqa: BLE001 - nothing to report to
                 status = 1
             os._exit(status)
@@ -110,7 +244,8 @@ class LineGuard:
         self._w, self._pid = w, pid
 
     def _send(self, kind, obj):
-        data = kind + json.dumps(obj).encode() + b"\n"
+        """`obj`: the full record; the keeper gets the compact line, the detail file gets the rest."""
+        data = kind + compact_line(obj, write_detail(obj)).encode() + b"\n"
         while data:
             data = data[os.write(self._w, data):]
 
@@ -270,24 +405,22 @@ def digest_of(h):
 
 def load_pmc_valu(d):
     """The per-kernel PMC figures of the scan kernels at dimensionality d (pruned chain, plain scan) - only when they were
-    measured on these kernel sources (the files carry the SHA-256 of chronoclust_amd/csrc/)."""
-    out, why = {}, None
-    digest = csrc_digest()
+    measured on these kernel sources.  Returns (kernels, files, full_rows_frac_under_pmc) or (None, why, None)."""
+    out, why, files, full = {}, None, [], None
     for suffix in ("", "_plain"):
-        path = PMC_VALU_FILE % (d, suffix)
-        try:
-            with open(path) as f:
-                pm = json.load(f)
-        except (OSError, ValueError):
-            why = "no PMC passes on file for d = %d (%s)" % (d, os.path.basename(path))
+        pm, name = newest_pmc(PMC_VALU_GLOB % (d, suffix))
+        if pm is None:
+            why = name
             continue
-        if pm.get("csrc_sha256") != digest:
-            why = "profiles/%s was measured on other kernel sources (csrc digest differs)" % os.path.basename(path)
-            continue
-        for name, k in pm["kernels"].items():
-            out[name] = dict(k, source=os.path.basename(path))
-    need = ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p")
-    return (out, None) if all(n in out for n in need) else (None, why or "incomplete PMC files for d = %d" % d)
+        files.append(name)
+        if suffix == "" and pm.get("rows_evaluated_in_full_frac") is not None:
+            full = float(pm["rows_evaluated_in_full_frac"])
+        for kname, k in pm["kernels"].items():
+            out[kname] = dict(k, source=name)
+    need = ("k_scan_u", "k_scan_p")
+    if all(n in out for n in need):
+        return out, files, full
+    return None, why or "incomplete PMC files for d = %d" % d, None
 
 
 def scan_roofline(acc, d, kernel):
@@ -327,20 +460,23 @@ def scan_roofline(acc, d, kernel):
         parts["pruned"] = {"kernel": "k_seed + k_seed_merge + k_scan_p (steady state: rows abandoned on a prefix)", "launches": n_p,
                            "avg_launch_us": 1e3 * ms_p / n_p, "effective_frac": 3.0 * pd_p / (ms_p * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
     out["parts"] = parts
-    pm, why = load_pmc_valu(d)
+    pm, why, full_pmc = load_pmc_valu(d)
     if pm is None:
         out["executed"] = None
-        out["executed_note"] = "not quoted: %s; re-run tools/profile_round.sh (SECTIONS=valu).  `effective` is the " \
-                               "algorithmic figure, not what the hardware issued" % why
+        out["derived"] = "achieved / frac not quoted: %s; re-run tools/profile_round.sh (SECTIONS=valu)" % why
         return out
+    out["pmc_source"] = "profiles/" + " + ".join(why)
+    out["derived"] = "achieved = VALU instructions per (wave,row) of pmc_source x this run's (wave,row) pairs x 64 lanes / " \
+                     "this run's HIP-event scan time"
     # instruction-lanes: instructions per (wave, row) x (wave, row) pairs x 64 lanes = instructions per (wave, row) x pairs
     pairs_u, pairs_p = (pd_all - pd_p) / d, pd_p / d
     full = (acc["pruned_scan_full_rows"] / acc["pruned_scan_rows"]) if acc.get("pruned_scan_rows") else 0.0
     # a pruned launch of this run may complete more rows than the steady-state launches the counters were taken on (the
     # first pruned windows of a stream): every completed row beyond that share is charged the plain scan's row
-    full_pmc = 0.013 if d <= 20 else 0.0013
+    if full_pmc is None:  # (files of round 4 did not record their own share: the figures their runs printed)
+        full_pmc = 0.013 if d <= 20 else 0.0013
     extra = max(0.0, full - full_pmc) * pm["k_scan_u"]["valu_instructions_per_wave_row"]
-    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_p")) + extra
+    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_p") if k in pm) + extra
     lanes_u = pairs_u * pm["k_scan_u"]["valu_instructions_per_wave_row"]
     lanes_p = pairs_p * per_row_p
     executed = (lanes_u + lanes_p) / secs / 1e12
@@ -353,7 +489,7 @@ def scan_roofline(acc, d, kernel):
     keys = ("valu_instructions_per_wave_row", "salu_instructions_per_wave_row", "lds_instructions_per_wave_row",
             "valu_busy_fraction", "lds_busy_fraction", "lds_array_busy_fraction", "wave_time_parked_on_waitcnt",
             "co_limiter", "avg_us_under_pmc", "source")
-    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p")},
+    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p") if n in pm},
                        "instruction_lanes_per_launch": (lanes_u + lanes_p) / acc["scan_launches"],
                        "note": "counters of full windows running alone (tools/steady.py under rocprofv3 --pmc, three passes); "
                                "busy fractions are of the kernel's own run time, `frac` above is over this run's launches "
@@ -745,17 +881,12 @@ def main():
                                "few that go unused) and in-place scans (short windows of the start-up phase included)"})
             # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
             # separate runs); only quoted when it was measured on this workload shape AND on these kernel sources
-            try:
-                with open(PMC_TRAFFIC_FILE) as f:
-                    pmc = json.load(f)
-                if pmc.get("csrc_sha256") != csrc_digest():
-                    out["roofline"]["traffic_note"] = "profiles/%s was measured on other kernel sources (csrc digest " \
-                                                      "differs): not quoted" % os.path.basename(PMC_TRAFFIC_FILE)
-                elif (pmc["points"], pmc["dim"], pmc["window"]) == (n, d, out["config"]["window"]):
-                    out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = pmc["note"]
-            except (OSError, KeyError, ValueError):
-                pass
+            pmc, name = newest_pmc(PMC_TRAFFIC_GLOB)
+            if pmc is None:
+                out["roofline"]["traffic_note"] = "not quoted: %s" % name
+            elif (pmc.get("points"), pmc.get("dim"), pmc.get("window")) == (n, d, out["config"]["window"]):
+                out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "profiles/%s: %s" % (name, pmc["note"])
         if world == 1 and not args.no_cpu_baseline and not args.only_leg:
             # (the GPU box gives a one-GPU job 16 of the host's cores; os.cpu_count() reports the whole machine)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -800,7 +931,7 @@ def main():
             else:
                 sys.stderr.write("[bench rank %d] leg %s not finished after %.0f s, abandoned\n" % (
                     rank, name, 1.5 * args.stream_timeout))
-            os._exit(EXIT_LEG_FAILED if args.strict_legs else 0)
+            os._exit(EXIT_LEG_FAILED)  # (a hung collective is never a clean exit; the line is out)
 
         timer = threading.Timer(1.5 * args.stream_timeout, abandon)
         timer.daemon = True

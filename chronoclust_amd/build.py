@@ -4,8 +4,12 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchronoclust_hip.so")
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("cc_api.hip", "cc_common.h", "cc_online.h", "cc_scan.h", "cc_validate.h", "cc_seq.h",
-                                                   "cc_relaxed.h", "cc_points.h", "cc_offline.h", "cc_comm.h", "cc_csv.h", "cc_policy.h")]
+import glob
+import hashlib
+
+# the one translation unit first (it includes every header beside it); every file under csrc/ counts for staleness
+SOURCES = [os.path.join(_HERE, "csrc", "cc_api.hip")] + sorted(
+    p for p in glob.glob(os.path.join(_HERE, "csrc", "*")) if p.endswith((".h", ".hip")) and not p.endswith("cc_api.hip"))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "chronoclust_hip.h")
 
 
@@ -30,6 +34,28 @@ def build(force=False, verbose=False, out=None, defines=()):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return out or LIB_PATH
+
+
+DIV_TEST_SOURCE = os.path.join(os.path.dirname(_HERE), "tests", "hip", "div_exact.hip")
+DIV_TEST_PROGRAM = os.path.join(os.path.dirname(_HERE), "tests", "hip", "_build", "div_exact")
+
+
+def build_div_test(force=False):
+    """The device test program of csrc/cc_div.h (tests/hip/div_exact.hip; tests/test_div_exact.py runs it on the GPU box).
+    hipcc cross-compiles for gfx950 without a GPU; the binary travels with the tree (git-ignored).  Keyed to the sources'
+    content, not to file times: a copy of the tree need not keep those."""
+    header = os.path.join(_HERE, "csrc", "cc_div.h")
+    digest = hashlib.sha256(open(DIV_TEST_SOURCE, "rb").read() + open(header, "rb").read()).hexdigest()
+    stamp = DIV_TEST_PROGRAM + ".sha256"
+    if not force and os.path.exists(DIV_TEST_PROGRAM) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return DIV_TEST_PROGRAM
+    os.makedirs(os.path.dirname(DIV_TEST_PROGRAM), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+                           DIV_TEST_SOURCE, "-o", DIV_TEST_PROGRAM])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    return DIV_TEST_PROGRAM
 
 
 if __name__ == "__main__":

@@ -26,16 +26,16 @@ def stream_seed(base_seed, rank):
     return int(base_seed) + int(rank)
 
 
-def max_over_ranks(value, dist=None, device=None):
-    """The job's step time is the slowest rank's.  `dist`: a HostGroup, torch.distributed, or None for one process."""
+def max_over_ranks(value, dist=None):
+    """The job's step time is the slowest rank's.  `dist`: a HostGroup, any object with torch.distributed's
+    get_world_size / all_gather_object (the gloo tests pass that module; nothing here imports it), or None."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
     if hasattr(dist, "max_float"):
         return dist.max_float(value)
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    box = [None] * dist.get_world_size()
+    dist.all_gather_object(box, float(value))
+    return max(float(v) for v in box)
 
 
 def whole_job_rate(points_per_rank, steps, world, seconds):

@@ -34,15 +34,16 @@ def totals(d, counter):
 if __name__ == "__main__":
     # launches as bench.py counts (and times) them: the figure of the line each profiled run printed - a plain launch may
     # carry a probe of the pruned chain, a pruned launch is a chain of three or five kernels
-    line1 = json.loads(open(sys.argv[3]).read().strip().splitlines()[-1])
-    line2 = json.loads(open(sys.argv[4]).read().strip().splitlines()[-1])
+    # (the FULL records of the two runs - bench.py's detail files -, not the compact stdout lines)
+    line1 = json.load(open(sys.argv[3]))
+    line2 = json.load(open(sys.argv[4]))
     n1, n2 = int(line1["roofline"]["launches"]), int(line2["roofline"]["launches"])
     fetch, _ = totals(sys.argv[1], "FETCH_SIZE")
     write, _ = totals(sys.argv[2], "WRITE_SIZE")
     fetch_kb = sum(v["KB_total"] for v in fetch.values()) / max(n1, 1)
     write_kb = sum(v["KB_total"] for v in write.values()) / max(n2, 1)
     out = {"points": int(line1["config"]["points"]), "dim": int(line1["config"]["dim"]), "window": int(line1["config"]["window"]),
-           "csrc_sha256": bench.csrc_digest(),
+           "csrc_sha256": bench.csrc_digest(), "scan_sha256": bench.scan_digest(),
            "kernel": "snapshot scan: pruned chains (k_scan_p with guessed thresholds + k_missed + k_seed / k_seed_merge / k_scan_p for the missed points, or the seeded chain for the whole window) and k_scan_u launches", "launches": n1,
            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
            "k_scan_clean_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,

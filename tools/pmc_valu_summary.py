@@ -2,7 +2,7 @@
 Usage: pmc_valu_summary.py <dir of pass a: GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU>
                            <dir of pass b: GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES>
                            <dir of pass c: GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT, or ->
-                           <d> <rows> [window]
+                           <d> <rows> [window] [stdout of a steady.py run: its share of rows evaluated in full]
 The output carries the SHA-256 of chronoclust_amd/csrc/: bench.py quotes these figures (roofline.executed) only for the
 kernel sources they were measured on."""
 import glob
@@ -45,8 +45,15 @@ def full_launches(d, pat):
     return full.mean(), int(len(full))
 
 
+FULL = None
+if len(sys.argv) > 7 and os.path.exists(sys.argv[7]):
+    import re
+    hits = re.findall(r"([0-9.]+) % evaluated in full", open(sys.argv[7]).read())
+    if hits:
+        FULL = float(hits[-1]) / 100.0
+
 out = {"shape": "%d points x %d microclusters x %d dims per launch, running alone (tools/steady.py, LA=2)" % (WINDOW, ROWS, D),
-       "csrc_sha256": bench.csrc_digest(), "dim": D, "rows": ROWS, "window": WINDOW, "kernels": {}}
+       "csrc_sha256": bench.csrc_digest(), "scan_sha256": bench.scan_digest(), "rows_evaluated_in_full_frac": FULL, "dim": D, "rows": ROWS, "window": WINDOW, "kernels": {}}
 for pat in ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<"):
     a, na = full_launches(sys.argv[1], pat)
     b, nb = full_launches(sys.argv[2], pat)
@@ -58,7 +65,8 @@ for pat in ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<"):
     k = {
         "launches": [na, nb, nc],
         "avg_us_under_pmc": [float(a["us"]), float(b["us"])] + ([float(c["us"])] if c is not None else []),
-        "effective_clock_ghz": float(cycles / (a["us"] * 1e3)),
+        # (a launch that ends within a few tens of us is mostly dispatch: GRBM cycles / its duration is not a clock)
+        "effective_clock_ghz": float(cycles / (a["us"] * 1e3)) if a["us"] >= 50.0 else None,
         "valu_instructions_per_wave_row": float(a["SQ_INSTS_VALU"] / pairs),
         "salu_instructions_per_wave_row": float(a["SQ_INSTS_SALU"] / pairs),
         "valu_busy_fraction": float(a["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cycles),
