@@ -1523,6 +1523,7 @@ struct OnlineRun {
         c.stat_seq_clk = c.stat_seq_wall = 0;
         c.stat_prune_rows = c.stat_prune_full = 0;
         c.stat_missed = 0;
+        c.seed_at = -1;
         for (int q = 0; q < 2; ++q) {
             c.n_missed[q] = 0;
             for (int K = 0; K < 2; ++K) { c.tg[q][K] = 0.0; c.tg_ok[q][K] = 0; }

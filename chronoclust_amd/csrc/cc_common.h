@@ -237,6 +237,12 @@ struct Ctl {
     int seq_rest;  // k_seq_r -> k_seq: points of the stint the register kernel left (its capacity was reached, or the table did not fit)
     int pad3;
     long long stat_seq_r_points;  // of stat_seq_points: taken by k_seq_r
+    // seed_at: absolute index of the point a window was cut short at because it could not be decided (k_commit_a; -1
+    // otherwise).  The next window starts there; if its scan runs with guessed thresholds, k_missed / k_missed_g put that
+    // first point on the list of the seeded chain whatever its marks say: a point whose pcore list was resolved by the guess
+    // but whose OUTLIER list starts with a bound (its pcore stage fails, no outlier MC lies within the guess - the first
+    // point of a new population beside an existing one) would otherwise be refused again and again.
+    long long seed_at;
     // heavy rows (Table::heavy): the list k_claims_heavy works on, and this window's nominations (k_decide: the claimant
     // that finds a chain's member list full); k_commit_a merges the nominations into the list and drops rows marked 2
     // rdiff[r]: some decision of round r may differ from the claim it validates (k_dseed of round r; reset by k_chain of

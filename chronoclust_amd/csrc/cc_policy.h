@@ -98,9 +98,15 @@ public:
                 prune_backoff_ = std::min<long long>(1ll << 20, prune_backoff_ * 2);
                 probe_ok_ = false;
             } else if (pr > 0) prune_backoff_ = 65536;
-            // a window that commits nothing although its first point is always decidable: cannot happen with exact
-            // first candidates - should it, the plain scan takes over for good
-            if (done == done_before && !nodirty_) prune_resume_at_ = std::numeric_limits<long long>::max();
+            // A batch that commits nothing although dirty scans were launched.  With guessed thresholds that is legitimate:
+            // a lean scan missed the batch's first point, the list of missed points was cut there (CC_MISSED_CAP), or a
+            // point's outlier list started with a bound (k_decide, stage 1) - the seeded chain comes back for 2^18 points.
+            // With SEEDED thresholds first candidates are exact and the first point of a window is always decidable:
+            // should such a batch still commit nothing, the plain scan takes over for good.
+            if (done == done_before && !nodirty_) {
+                if (guess_on_) guess_resume_at_ = o.cursor + (1ll << 18);
+                else prune_resume_at_ = std::numeric_limits<long long>::max();
+            }
         }
         // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused for want
         // of the dirty scans idle the rest of their batch), not three times in a row

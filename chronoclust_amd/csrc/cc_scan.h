@@ -1533,6 +1533,7 @@ __global__ __launch_bounds__(1024) void k_missed(Ctl* __restrict__ ctl, unsigned
             const int left = win.B - t * 64;
             const unsigned long long all = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             miss[q] = ~found[t] & all;
+            if (t == 0 && ctl->seed_at == win.cursor) miss[q] |= 1ull;  // (the point the previous window was cut short at)
             found[t] = 0ull;
             mine += __builtin_popcountll(miss[q]);
         }
@@ -1667,13 +1668,14 @@ __global__ __launch_bounds__(1024) void k_missed_g(Ctl* __restrict__ ctl, const 
     // (the scan's own marks are not what decides here; cleared for a later unsplit use of them)
     for (int t = tid; t < (B + 63) / 64; t += 1024) found[(size_t)win.q * (CC_MAX_WINDOW / 64) + t] = 0ull;
     const int per = (B + 1023) >> 10;
+    const bool seed_first = ctl->seed_at == win.cursor;  // (the point the previous window was cut short at, Ctl::seed_at)
     auto missed = [&](int j) -> bool {
         Cand best = Cand{CC_INF, CC_IDX_INF, -1};
         for (int r = 0; r < world; ++r) {
             const Cand c = gpart[(size_t)r * outer + (size_t)j * 4];
             if (c.slot != -1 && (best.slot == -1 || cand_less(c.dist, c.key, best.dist, best.key))) best = c;
         }
-        return best.slot == CC_SLOT_BOUND;
+        return best.slot == CC_SLOT_BOUND || (j == 0 && seed_first);
     };
     int mine = 0;
     for (int k = 0; k < per; ++k) {

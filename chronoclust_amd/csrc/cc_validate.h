@@ -742,7 +742,9 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         else if (c1.slot == CC_SLOT_BOUND) {
             // a guessed threshold missed the point's own MC and nobody rescanned it (the list of missed points was full,
             // or the scan ran lean - without that list, see cc_policy.h): refused; counted, so that the policy hears of it
-            if (gl == 0 && round == 0 && stage == 0) atomicAdd((unsigned long long*)&ctl->stat_missed, 1ull);
+            // (stage 1 as well: the pcore list was resolved by the guess, the pcore stage failed and every outlier MC lies
+            // beyond the guess - the seeded chain has to look at the point, see Ctl::seed_at)
+            if (gl == 0 && round == 0) atomicAdd((unsigned long long*)&ctl->stat_missed, 1ull);
             T = CC_T_UNKNOWN;
             return;
         }
@@ -1842,6 +1844,7 @@ __global__ __launch_bounds__(1024) void k_commit_a(Ctl* __restrict__ ctl, Table 
         ctl->stat_tiles += n_tiles;
         ctl->stat_dirty_tiles += dirty_tiles;
         ctl->stat_trunc_unknown += (n < B && T[n] == CC_T_UNKNOWN) ? 1 : 0;
+        ctl->seed_at = (n < B && T[n] == CC_T_UNKNOWN) ? cursor + n : -1ll;
         ctl->stat_table_rows += M0;
         ctl->stat_pair_rows += (double)B * (double)M0;
         // next window
