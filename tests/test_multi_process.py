@@ -224,6 +224,7 @@ _GUARD_SCRIPT = """
 import os, signal, sys
 sys.path.insert(0, %r)
 import bench
+bench.DETAIL_FILE = sys.argv[2]
 fd = os.dup(1)
 os.dup2(2, 1)
 g = bench.LineGuard(fd)
@@ -231,7 +232,7 @@ print("noise on fd 1 from a native library")
 g.provisional({"metric": "m", "value": 1.0})
 mode = sys.argv[1]
 if mode == "final":
-    g.final({"metric": "m", "value": 1.0, "one_stream_exact": {"value": 2.0}})
+    g.final({"metric": "m", "value": 1.0, "strong_scaling": {"one_stream_exact": {"value": 2.0, "n_gpus": 1}}})
 elif mode == "killed":
     os.kill(os.getpid(), signal.SIGKILL)
 elif mode == "terminated":
@@ -239,7 +240,7 @@ elif mode == "terminated":
 """
 
 
-def test_bench_line_survives_the_death_of_the_process():
+def test_bench_line_survives_the_death_of_the_process(tmp_path):
     """bench.py's stdout line is held by a keeper process: one line in every case - the complete one after a normal
     end, the headline marked incomplete when the process is killed after the headline was measured."""
     import json
@@ -247,7 +248,7 @@ def test_bench_line_survives_the_death_of_the_process():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for mode in ("final", "killed", "terminated"):
-        p = subprocess.Popen([sys.executable, "-c", _GUARD_SCRIPT % root, mode], stdout=subprocess.PIPE,
+        p = subprocess.Popen([sys.executable, "-c", _GUARD_SCRIPT % root, mode, str(tmp_path / "detail.json")], stdout=subprocess.PIPE,
                              stderr=subprocess.PIPE, text=True, start_new_session=True)
         out, _ = p.communicate(timeout=60)
         lines = [x for x in out.splitlines() if x.strip()]
@@ -255,7 +256,7 @@ def test_bench_line_survives_the_death_of_the_process():
         obj = json.loads(lines[0])
         assert obj["value"] == 1.0
         assert ("incomplete" in obj) == (mode != "final")
-        assert ("one_stream_exact" in obj) == (mode == "final")
+        assert ("one_stream_exact" in obj.get("strong_scaling", {})) == (mode == "final")
 
 
 def _bench(*argv, env=None, timeout=120):
