@@ -285,22 +285,24 @@ def test_lean_guessed_scans_and_a_population_that_appears_late():
 
 
 def test_guessed_thresholds_and_points_whose_outlier_list_starts_with_a_bound():
-    """A settled stream of tight populations, then a dozen WIDE ones (radius just over epsilon) appear late.  Once such a
+    """A settled stream of 2 000 tight populations, then six WIDE ones (radius just over epsilon) appear late.  Once such a
     population's microcluster is promoted, many of its points find it within the guessed threshold (their pcore list is
     resolved: the point counts as found), fail its radius test - the MC is young and light - and go on to the outlier stage
-    with NO outlier MC within the guess: their outlier list starts with a bound, k_decide refuses them and the window is cut
-    short there.  The next window starts at that point; k_missed puts it on the seeded chain's list (Ctl::seed_at) and the
-    stream moves on with pruned scans.  Before round 5 such a point was refused again and again and the policy switched
-    the pruned scans off for the rest of the call.  Exact either way; the test asserts that pruned scans
-    stay in use to the end of the stream."""
+    with no outlier MC within the guess: their outlier list starts with a bound and k_decide refuses them.  The window is cut
+    short there, the next one starts at that point, and k_missed / k_missed_g put a window's first point on the seeded chain's
+    list when the previous window was cut short at an undecidable point (Ctl::seed_at, round 5; ADVICE r04 traced a stall
+    from the code: such a point refused again and again until the policy switched pruned scans off for the call).  On this
+    stream the policy's other rules - back to seeded thresholds when one point in sixteen is missed - act first, with or
+    without seed_at (profiles/r05_tool_late_wide.txt: identical traces), so what the test holds is exactness on a stream
+    of this kind and that it ends on pruned scans."""
     from oracle import oracle as O
     rng = np.random.default_rng(2025)
-    n, d, g, late = 300_000, 20, 150, 12
+    n, d, g, late = 600_000, 20, 2000, 6
     centres = rng.uniform(0.1, 0.9, (g + late, d))
     lab = rng.integers(0, g, n)
     for s in range(late):
-        start = 2 * n // 3 + s * 6000
-        idx = start + np.flatnonzero(rng.random(n - start) < 0.006)
+        start = 2 * n // 3 + s * 12000
+        idx = start + np.flatnonzero(rng.random(n - start) < 0.004)
         lab[idx] = g + s
     sig = np.where(lab >= g, 0.0225, 0.006)  # (d sigma^2 / k = 2.5e-3 = epsilon^2 for the late ones)
     X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, 1.0, (n, d)) * sig[:, None], 0.0, 1.0))
@@ -308,7 +310,7 @@ def test_guessed_thresholds_and_points_whose_outlier_list_starts_with_a_bound():
     o = O.OracleHDDStream(cfg)
     o.online_microcluster_maintenance(X, 0)
     paths = np.asarray(o.paths)
-    assert int((paths[2 * n // 3:] == 2).sum()) > 4 * late  # microclusters opened beside the late populations' own
+    assert int((paths[2 * n // 3:] == 2).sum()) > 3 * late  # microclusters opened beside the late populations' own
     h = _hdd(cfg, 1, window=8192)  # (the library's own policy)
     h.online_microcluster_maintenance(X, 0)
     _against_oracle(h, o)
