@@ -182,7 +182,12 @@ public:
         sparse_ = c_.allow_nodirty != 0 && few_flagged && flagged > 0 && tiles > 0 &&
                   (trunc_batch == 0 || (nodirty_ && trunc_batch * 4 < wins));
         nodirty_ = c_.allow_nodirty != 0 && tiles > 0 && ((dtiles == 0 && trunc_batch == 0) || sparse_);
-        const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned);
+        // (switched ON only once the stream is calm - at most one point tile in eight still needs its dirty scan: a window
+        // scanned ahead does not see the previous window's commit, and while microclusters are still being promoted that
+        // costs a truncated window and two more batches at the start-up window size, ~0.9 ms of a C2 step,
+        // profiles/r05_tool_startup_lookahead.txt -; once on it stays on until a window is cut short)
+        const bool calm = tiles > 0 && (dtiles * 8 <= tiles || few_flagged);
+        const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned && (la_on_ || calm));
         // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)
         const bool shard_next = policy_want_shard(c_, o.m_rows);
         const bool shard_flip = shard_next != shard_on_;

@@ -18,7 +18,9 @@ if __name__ == "__main__":
     cfg = bench.blob_config(n)
     h = _lib.Handle(0)
     h.set_tuning(window=int(os.environ.get("WIN", "0")), lookahead=int(os.environ.get("LA", "0")), time_kernels=0,
-                 early_window=int(os.environ.get("EARLY", "0")), windows_per_sync=int(os.environ.get("WPS", "0")))
+                 early_window=int(os.environ.get("EARLY", "0")), windows_per_sync=int(os.environ.get("WPS", "0")),
+                 dirty_segments=int(os.environ.get("DSEG", "0")), segments=int(os.environ.get("SEG", "0")),
+                 rounds=int(os.environ.get("ROUNDS", "0")))
     bench.set_params(h, cfg, n, d)
     h.points_upload(X)
     for rep in range(int(os.environ.get("REPS", "3"))):
