@@ -388,6 +388,41 @@ def cpu_baseline(cfg, X, sample, cores, gpu_uid):
     return out
 
 
+def with_transfers(h, X, steps, step):
+    """The same step with its transfers inside the timed region (the seam of app.py:170-178: a timepoint arrives as a host
+    array, its per-point labels go back to the host): per step the upload of the step's points - started one step earlier
+    through cc_points_prefetch (page-locked staging buffers, a stream of its own), so that it runs beside the previous
+    step's clustering -, reset + online + offline phases, and the download of the labels.  Two host arrays take turns (the
+    library recognises a prefetched array by its address)."""
+    Xs = [X, X.copy()]
+    h.points_upload(Xs[0])
+    h.points_prefetch(Xs[1])
+    step()  # (fills the pipeline: the first timed step's points are on their way while this one runs)
+    h.labels_download()
+    h.sync()
+    wait_s = lab_s = 0.0
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t1 = time.perf_counter()
+        h.points_upload(Xs[(i + 1) % 2])   # adopts the prefetched copy: waits for what is left of it
+        h.points_prefetch(Xs[i % 2])       # the next step's points, beside this step's kernels
+        t2 = time.perf_counter()
+        step()
+        t3 = time.perf_counter()
+        h.labels_download()
+        lab_s += time.perf_counter() - t3
+        wait_s += t2 - t1
+    h.sync()
+    elapsed = time.perf_counter() - t0
+    h.points_upload(Xs[steps % 2])  # (takes over the last prefetch: nothing left in flight)
+    n, d = X.shape
+    return {"value": n * steps / elapsed, "unit": "points/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "upload_mb_per_step": n * d * 8 / 1e6, "labels_mb_per_step": n * 9 / 1e6,
+            "waiting_for_upload_ms_per_step": 1e3 * wait_s / steps, "labels_download_ms_per_step": 1e3 * lab_s / steps,
+            "note": "host array in (pageable, 8 d bytes per point) through cc_points_prefetch one step ahead, labels out "
+                    "(uid int64 + path int8 per point); everything else as the headline step"}
+
+
 def digest_of(h):
     """Bytes that pin the state a run ended in: labels, both tables, id counters."""
     from chronoclust_amd import _lib
@@ -731,6 +766,7 @@ def main():
     ap.add_argument("--early-window", type=int, default=0, help="window while the table grows / is being promoted (0: 4096)")
     ap.add_argument("--windows-per-sync", type=int, default=0, help="windows enqueued between host read-backs (0: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-transfers", action="store_true", help="skip the transfer-inclusive measurement (upload + labels inside the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads of the all-cores CPU column (at most the usable cores)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -748,7 +784,8 @@ def main():
                          "the leg's object carries the error, `legs_failed` names it, exit status 0)")
     ap.add_argument("--no-relaxed", action="store_true", help="skip the event-sharded relaxed leg (C4-shaped)")
     ap.add_argument("--relaxed-points", type=int, default=5_000_000)
-    ap.add_argument("--relaxed-minibatch", type=int, default=65536, help="points per rank and super-step")
+    ap.add_argument("--relaxed-minibatch", type=int, default=262144,
+                    help="points per rank and super-step (eight windows: lookahead scans inside a super-step; 65 536 - two windows per call - measured half the rate on one rank)")
     ap.add_argument("--no-c2-legs", action="store_true", help="skip the two C2-shaped strong-scaling legs")
     ap.add_argument("--only-leg", default=None, help="profiling: only this leg, after a token headline (20 000 points, 100 microclusters, no CPU baseline)")
     ap.add_argument("--dry-launch", action="store_true", help="the ranks only rendezvous and rank 0 prints who came (no GPU is touched)")
@@ -887,6 +924,10 @@ def main():
             elif (pmc.get("points"), pmc.get("dim"), pmc.get("window")) == (n, d, out["config"]["window"]):
                 out["roofline"]["traffic"] = pmc["k_scan_clean_bytes_per_launch"]
                 out["roofline"]["traffic_note"] = "profiles/%s: %s" % (name, pmc["note"])
+        if world == 1 and not args.no_transfers and not args.only_leg:
+            wt = with_transfers(h, X, max(2, min(args.steps, 10)), step)
+            out["with_transfers"] = wt
+            out["value_with_transfers"] = wt["value"]
         if world == 1 and not args.no_cpu_baseline and not args.only_leg:
             # (the GPU box gives a one-GPU job 16 of the host's cores; os.cpu_count() reports the whole machine)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

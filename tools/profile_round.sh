@@ -10,7 +10,7 @@ want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}" || exit 1
-B="python bench.py --no-cpu-baseline --no-one-stream --no-relaxed --no-c2-legs"
+B="python bench.py --no-cpu-baseline --no-transfers --no-one-stream --no-relaxed --no-c2-legs"
 if want bench; then
 # the driver's literal command; the line on stdout, the full record in the detail file beside it
 CHRONOCLUST_BENCH_DETAIL=$OUT/bench_detail.json python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; tail -5 $OUT/bench.err; exit 1; }
