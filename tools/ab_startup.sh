@@ -3,4 +3,4 @@
 cd "${GRAFT_REPO_ROOT:?run on the GPU box}" || exit 1
 run() { echo -n "$* : "; env "$@" REPS=4 python tools/startup.py 2>&1 | tail -1; }
 run X=0
-run LA=2
+run CHRONOCLUST_HIP_DSCANU=0
