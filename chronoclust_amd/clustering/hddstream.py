@@ -34,6 +34,36 @@ def rounded_weights(w):
     return out
 
 
+class _TqdmToLogger(object):
+    """The reference's TqdmToLogger (hddstream.py:552-573): what tqdm writes goes to the log, one record per refresh."""
+
+    def __init__(self, logger, level=logging.INFO):
+        self.logger, self.level, self.buf = logger, level, ""
+
+    def write(self, buf):
+        self.buf = buf.strip("\r\n\t ")
+
+    def flush(self):
+        self.logger.log(self.level, self.buf)
+
+
+def _progress_lines(logger, n):
+    """The progress records of the reference's per-point loop (`tqdm(range(N), file=TqdmToLogger(logger), mininterval=1)`,
+    hddstream.py:218-220): the bar at 0 of N when the loop starts and at N of N when it ends, written by tqdm itself (the
+    refreshes in between - one per second of the reference's loop - have no counterpart: the online phase is one call).
+    Returns the function that closes the bar at `done` points.  Without tqdm installed nothing is logged."""
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        return lambda done: None
+    bar = tqdm(total=n, file=_TqdmToLogger(logger), mininterval=1)
+
+    def finish(done):
+        bar.update(done)
+        bar.close()
+    return finish
+
+
 class HDDStream(object):
     def __init__(self, config, logger=None, device=0, tuning=None):
         self.config = config
@@ -121,6 +151,7 @@ class HDDStream(object):
             self._h.decay_downgrade(2 ** (-self.lambbda * interval))  # hddstream.py:283
 
         log.info("Starting online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
+        progress = _progress_lines(log, X.shape[0])  # hddstream.py:218-220: tqdm's bar, written to the log
         self._X = X if device_scaling is None else None  # scaled values are fetched from the device on demand
         self._n_points = X.shape[0]
         if X.shape[0] > 0 and device_scaling is not None:
@@ -131,6 +162,7 @@ class HDDStream(object):
             self.labels_uid, self.labels_path = self._h.online(X)
         else:
             self.labels_uid, self.labels_path = np.empty(0, np.int64), np.empty(0, np.int8)
+        progress(X.shape[0])
         log.info("Finish online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
         log.info("Online maintenance yield {} pcores and {} outlier".format(
             self._h.count(_lib.PCORE), self._h.count(_lib.OUTLIER)))
