@@ -240,3 +240,46 @@ def test_reference_modules_without_counterpart_say_why(stmt):
     assert not isinstance(e.value, ModuleNotFoundError)
     with pytest.raises(ModuleNotFoundError):
         exec("import chronoclust.no_such_module", {})
+
+
+def test_mutable_microcluster_object_replays_the_reference_unit_tests():
+    """chronoclust.objects.microcluster.Microcluster (the reference's mutable object, objects/microcluster.py:18-257): the
+    scenarios and known answers of the reference's own tests/objects_test/unittest_microcluster.py."""
+    import numpy as np
+    from chronoclust.objects.microcluster import Microcluster
+    m = Microcluster(cf1=np.zeros(3), cf2=np.zeros(3), cluster_centroids=[0.1, 0.2, 0.03], preferred_dimension_vector=[1.0, 15.0, 15.0])
+    assert round(m.get_projected_dist_to_point([1.0, 0.5, 0.7]), 2) == 0.85
+    m = Microcluster(cf1=np.zeros(3), cf2=np.zeros(3), cluster_centroids=[-0.1, 0.2, -0.03], preferred_dimension_vector=[1.0, 15.0, 15.0])
+    assert round(m.get_projected_dist_to_point([1.0, 0.5, 0.7]), 2) == 1.25
+    points = [[0.17550518, 0.50150137, 0.0715026, 0.46715915, 0.11825116], [0.09084978, 0.33935363, 0.06932869, 0.78185322, 0.62759489],
+              [0.22507306, 0.02771729, 0.46630673, 0.75367467, 0.2201496], [0.26507548, 0.44774516, 0.28568398, 0.80777178, 0.12095075],
+              [0.43343372, 0.35738624, 0.4001447, 0.89195078, 0.29652304], [0.48627326, 0.52784397, 0.22927219, 0.801923, 0.07897944],
+              [0.31972963, 0.29667314, 0.20070554, 0.31300255, 0.4958211], [0.05191981, 0.76440696, 0.0478006, 0.0201296, 0.25368318],
+              [0.18290483, 0.65387882, 0.174167, 0.21822311, 0.2230557], [0.87574659, 0.77501901, 0.21127804, 0.15939672, 0.6381301]]
+    k = 15
+    for delta_sq, expected in ((0.01, [1, 1, 1, 1, 1]), (0.05, [1, k, k, 1, k]), (0.1, [k, k, k, k, k])):
+        mc = Microcluster(cf1=np.zeros(5), cf2=np.zeros(5))
+        for idx, p in enumerate(points):
+            mc.add_new_point(np.array(p), 0, idx)
+            mc.update_preferred_dimensions(delta_sq, k)
+        np.testing.assert_equal(mc.preferred_dimension_vector, np.array(expected))
+        assert list(mc.points.keys()) == list(range(10)) and mc.cumulative_weight == 10
+    cf1 = [0.68756544, 0.96853843, 0.41156436, 0.13236377, 0.12836222, 0.55662013, 0.9671396, 0.99469293, 0.86402299, 0.90838236,
+           0.52934492, 0.37423623, 0.02787237, 0.35216188, 0.96222637, 0.09291304, 0.08972414, 0.76429683, 0.78941125, 0.53722776]
+    cf2 = [4.72746229e-01, 9.38066699e-01, 1.69385220e-01, 1.75201686e-02, 1.64768583e-02, 3.09825969e-01, 9.35359004e-01,
+           9.89414034e-01, 7.46535721e-01, 8.25158518e-01, 2.80206042e-01, 1.40052759e-01, 7.76869185e-04, 1.24017991e-01,
+           9.25879595e-01, 8.63283346e-03, 8.05042136e-03, 5.84149644e-01, 6.23170114e-01, 2.88613669e-01]
+    pref = [1, 1, 16, 16, 1, 16, 16, 16, 16, 16, 1, 16, 1, 16, 16, 16, 1, 1, 1, 16]
+    mc = Microcluster(cf1=np.array(cf1), cf2=np.array(cf2), preferred_dimension_vector=np.array(pref), cumulative_weight=20)
+    assert abs(mc.calculate_projected_radius_squared() - 0.1551429607662637) < 1e-10
+    for args, expected in (((0.1, 1, 20), False), ((0.2, 30, 20), False), ((0.2, 1, 2), False), ((0.1, 30, 20), False),
+                           ((0.2, 30, 2), False), ((0.1, 1, 2), False), ((0.2, 1, 20), True), ((0.1552, 20, 12), True)):
+        assert mc.is_core(*args) is expected, args
+    one = Microcluster(cf1=np.zeros(len(cf1)), cf2=np.zeros(len(cf1)))
+    one.add_new_point(np.array(cf1), 0, 0)
+    clone = one.get_copy()
+    np.testing.assert_almost_equal(clone.CF1, cf1)
+    np.testing.assert_almost_equal(clone.CF2, cf2)
+    assert clone.cumulative_weight == 1 and clone.points == {}
+    more = one.get_copy_with_new_point(np.array(cf1), 0.05, 4)
+    assert more.cumulative_weight == 2 and one.cumulative_weight == 1 and list(more.preferred_dimension_vector) == [4] * len(cf1)
