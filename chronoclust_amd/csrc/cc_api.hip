@@ -37,10 +37,6 @@ struct HipErr {
         if (_e != hipSuccess) throw HipErr{_e, #call}; \
     } while (0)
 
-#ifndef CC_DEFAULT_VAL_CUS
-#define CC_DEFAULT_VAL_CUS 0
-#endif
-
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -114,10 +110,6 @@ struct cc_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // lookahead scans
-    // round 5: in lookahead batches the validation kernels and the lookahead scans run on DISJOINT sets of compute units
-    // (CHRONOCLUST_HIP_VAL_CUS = n: the first n CUs of the mask for the validation stream, the rest for the scans; 0: off)
-    hipStream_t stream_v = nullptr, stream_s = nullptr;
-    int val_cus = 0;
     std::string err;
     cc_params par{};
     bool have_par = false;
@@ -797,17 +789,6 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
-        {
-            const char* vc = getenv("CHRONOCLUST_HIP_VAL_CUS");
-            h->val_cus = vc ? atoi(vc) : CC_DEFAULT_VAL_CUS;
-            if (h->val_cus > 0 && h->val_cus < h->n_cus) {
-                const int words = (h->n_cus + 31) / 32;
-                std::vector<uint32_t> mv((size_t)words, 0u), ms((size_t)words, 0u);
-                for (int i = 0; i < h->n_cus; ++i) (i < h->val_cus ? mv : ms)[(size_t)i / 32] |= 1u << (i % 32);
-                HIPCHK(hipExtStreamCreateWithCUMask(&h->stream_v, (uint32_t)words, mv.data()));
-                HIPCHK(hipExtStreamCreateWithCUMask(&h->stream_s, (uint32_t)words, ms.data()));
-            } else h->val_cus = 0;
-        }
         h->ctl.ensure(1);
         h->badflag.ensure(4);
         memset(&h->hc, 0, sizeof(Ctl));
@@ -887,12 +868,6 @@ void cc_destroy(cc_handle* h)
     };
     drain(h->stream);
     drain(h->stream2);
-    for (hipStream_t* ps : {&h->stream_v, &h->stream_s})
-        if (*ps) {
-            (void)hipStreamSynchronize(*ps);
-            (void)hipStreamDestroy(*ps);
-            *ps = nullptr;
-        }
     h->comm.destroy();
     if (h->stream) {
         (void)hipStreamSynchronize(h->stream);
@@ -1579,7 +1554,7 @@ struct OnlineRun {
         // cross-stream hand-offs: a fresh event per hand-off (the pool is reused from batch to batch)
         evCommit = get_event(h, 2); evScan = nullptr;
         ev_sync = ev_base;
-        ev_used = ev_base + 3 * (batch_max + 2) + 4;  // (+ 4: the events that tie the CU-masked streams of a lookahead batch to the handle's own)
+        ev_used = ev_base + 3 * (batch_max + 2);
 
         done = range_a;
         m_known = c.m_rows;
@@ -1726,23 +1701,6 @@ struct OnlineRun {
         // a batch, then kept up commit by commit
         ScanCopy scopy[2] = {ScanCopy{}, ScanCopy{}};
         if (la_on) scan_copy_sync(h, scopy);
-        // Lookahead batches on split compute units: the validation kernels of window w (chains of dependent memory accesses,
-        // a few waves) and the snapshot scan of window w + 1 (fills every SIMD it is given) slowed each other to the sum of
-        // their run times on shared CUs - each validation workgroup waits for a scan workgroup to retire, and the waves it
-        // then holds are registers the scan cannot use.  On disjoint sets neither sees the other.  What the two streams of
-        // the handle hold so far (table, scan copies, control block) is ordered before the masked streams' first kernel,
-        // and what those enqueue is ordered before whatever follows on the handle's streams (the read-back of the batch).
-        const bool cu_split = la_on && h->stream_v != nullptr && !grouped;
-        hipStream_t const sA = cu_split ? h->stream_v : this->sA, sB = cu_split ? h->stream_s : this->sB;
-        if (cu_split) {
-            hipEvent_t e0 = get_sync_event(h, ev_sync++), e1 = get_sync_event(h, ev_sync++);
-            HIPCHK(hipEventRecord(e0, this->sA));
-            HIPCHK(hipEventRecord(e1, this->sB));
-            for (hipStream_t st : {sA, sB}) {
-                HIPCHK(hipStreamWaitEvent(st, e0, 0));
-                HIPCHK(hipStreamWaitEvent(st, e1, 0));
-            }
-        }
         Rows srows[2];
         for (int q = 0; q < 2; ++q)
             srows[q] = Rows{scopy[q].cen, scopy[q].scl, nullptr, scopy[q].cf1, scopy[q].cf2, scopy[q].w, scopy[q].kind,
@@ -1898,13 +1856,6 @@ struct OnlineRun {
                 evCommit = get_sync_event(h, ev_sync++);
                 HIPCHK(hipEventRecord(evCommit, sA));
             }
-        }
-        if (cu_split) {
-            hipEvent_t e0 = get_sync_event(h, ev_sync++), e1 = get_sync_event(h, ev_sync++);
-            HIPCHK(hipEventRecord(e0, sA));
-            HIPCHK(hipEventRecord(e1, sB));
-            HIPCHK(hipStreamWaitEvent(this->sA, e0, 0));
-            HIPCHK(hipStreamWaitEvent(this->sB, e1, 0));
         }
     }
 
