@@ -151,6 +151,13 @@ struct cc_handle {
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
+    DevBuf<unsigned> masks;   // [2][tiles of 128 points, sub-ranges, words per sub-range]  k_scan_a's survivor masks (two window parities)
+    size_t mask_stride = 0;
+    // CHRONOCLUST_HIP_SCANA: 0 phase A inside k_scan_p (one point per lane, the round-3 form), 2 always as a kernel of its own
+    // (k_scan_a: two points per lane), 1 (default) k_scan_a from 10 000 table rows on: at 5 000 rows the second launch and
+    // phase B's own prologue cost what the cheaper phase A saves, at 50 000 the scan launch is 21 % shorter
+    // (profiles/r05_tool_scan_a.txt)
+    int split_a_mode = 1;
     // a pruned scan's sample {rows visited, rows completed} per window parity: Ctl::pstat, as the kernels take it
     unsigned long long* pstat_p() const { return (unsigned long long*)((char*)ctl.p + offsetof(Ctl, pstat)); }
     size_t spart_stride = 0, thr_stride = 0;
@@ -545,6 +552,29 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
             if constexpr (DP > 8) {
                 // prefix scores -> thresholds -> the scan that abandons rows whose partial sums pass them; for the
                 // window's points (plist == nullptr) or for the ones a guessed threshold missed
+                // k_scan_p for the window's points: phase A as a kernel of its own (two points per lane, survivor masks), phase
+                // B behind it; lists of points (the ones a guessed threshold missed, probes) keep the one-kernel form
+                auto scan_p_window = [&](int srank, int sworld, double gF, unsigned long long* found_) {
+                    if (h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000)) {
+                        hipLaunchKernelGGL((k_scan_p<DP, NW, false>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
+                                           rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
+                                           h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)nullptr, (size_t)0, 0);
+                        return;
+                    }
+                    const int nsub = S * NW;
+                    const int tps = cc_mask_tiles_per_sub((int)std::min<size_t>(h->tab.cap, (size_t)INT_MAX - 64), nsub);
+                    const size_t need = (size_t)((win + 127) / 128) * (size_t)nsub * (size_t)tps;
+                    if (need > h->mask_stride) {
+                        h->masks.ensure(2 * need);
+                        h->mask_stride = need;
+                    }
+                    hipLaunchKernelGGL((k_scan_a<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, (const Ctl*)h->ctl.p,
+                                       (const double*)h->Xt.p, rows.cen, rows.kind, (const double*)h->thr.p, h->thr_stride,
+                                       h->masks.p, h->mask_stride, tps, round, mode, srank, sworld, gF);
+                    hipLaunchKernelGGL((k_scan_p<DP, NW, true>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
+                                       rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
+                                       h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)h->masks.p, h->mask_stride, tps);
+                };
                 auto seeded_chain = [&](int n_pts, const int* plist, Cand* part, size_t part_stride, int S) {
                         // (k_seed holds two points per lane: point tiles of 128)
                         hipLaunchKernelGGL((k_seed<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
@@ -554,10 +584,14 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                            h->prune_F, round, mode, h->cmax.p, h->pstat_p(), plist);
                         // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
                         // that every rank abandons against the same T -, phases A / B over the rank's own rows)
-                        hipLaunchKernelGGL((k_scan_p<DP, NW>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                        if (plist == nullptr && n_pts == win && part_stride == h->part_stride && S == (int)grid.y) {
+                            scan_p_window(shard_rank, shard_world, 0.0, (unsigned long long*)nullptr);
+                            return;
+                        }
+                        hipLaunchKernelGGL((k_scan_p<DP, NW, false>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                            rows.scl, rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
                                            part_stride, shard_rank, shard_world, h->pstat_p(), plist, 0.0,
-                                           (unsigned long long*)nullptr);
+                                           (unsigned long long*)nullptr, (const unsigned*)nullptr, (size_t)0, 0);
                 };
                 if (phase == 1) {
                     // guessed thresholds on the exact multi-GPU path, after the ranks' records were gathered: the points
@@ -575,10 +609,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         // once the records are gathered - phase 1, enqueued by the caller behind the all-gather)
                         ++h->stats.scan_g_launches;
                         hipLaunchKernelGGL(k_pstat_zero, dim3(1), dim3(2), 0, st, (const Ctl*)h->ctl.p, h->pstat_p(), round, mode);
-                        hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
-                                           rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           h->part_stride, shard_rank, shard_world, h->pstat_p(), (const int*)nullptr,
-                                           h->prune_F, h->lean_now ? (unsigned long long*)nullptr : h->found.p);
+                        scan_p_window(shard_rank, shard_world, h->prune_F, h->lean_now ? (unsigned long long*)nullptr : h->found.p);
                         return;
                     }
                     if (h->guess_now) {
@@ -586,10 +617,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         // (list of the window's parity: the lookahead scan of the next window fills the other one)
                         ++h->stats.scan_g_launches;
                         int* const list = h->missed.p;  // (the kernels take the half of the window's parity)
-                        hipLaunchKernelGGL((k_scan_p<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
-                                           rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
-                                           h->part_stride, 0, 1, h->pstat_p(), (const int*)nullptr, h->prune_F,
-                                           h->lean_now ? (unsigned long long*)nullptr : h->found.p);
+                        scan_p_window(0, 1, h->prune_F, h->lean_now ? (unsigned long long*)nullptr : h->found.p);
                         if (h->lean_now) {  // (nobody is expected to be missed: see cc_policy.h)
                             ++h->stats.scan_lean_launches;
                             return;
@@ -833,6 +861,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_probe = !(pb && pb[0] == '0');
         const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
         h->allow_guess = !(gs && gs[0] == '0');
+        const char* sa = getenv("CHRONOCLUST_HIP_SCANA");
+        if (sa) h->split_a_mode = std::max(0, std::min(2, atoi(sa)));
         const char* ln = getenv("CHRONOCLUST_HIP_LEAN");
         h->allow_lean = !(ln && ln[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");

@@ -1243,13 +1243,204 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
 #ifndef CC_SCANP_WGS20
 #define CC_SCANP_WGS20 4  // workgroups per CU k_scan_p is compiled for at d <= 20
 #endif
+
+// ---- phase A as a kernel of its own (round 5): k_scan_a -> k_scan_p<.., MASKED = true> ----------------------------------
+// k_scan_p's phase A is bound by the round trip of its wave-uniform LDS reads (two 16-byte broadcasts per row and wave of 64
+// points; neither the VALU nor the LDS array is busy half the time, profiles/r05_tool_scanp_variants.txt).  k_scan_a runs the
+// prefix test the way k_seed scores prefixes: TWO points per lane - a row's prefix is read from LDS once for 128 points -
+// and the EXPANDED form, everything centred on the prefix o of table row 0:
+//     |p' - c'|^2 = |p'|^2 - 2 (p'.c' - |c'|^2 / 2),   p' = p - o,  c' = c - o.
+// With the lane's constant folded into the accumulator's start the test "the row's exact partial sum over the first eight
+// dimensions exceeds the point's threshold" is
+//     t' = p^.c^ - tau  <  h^        (4 packed multiply-adds, 1 add, 1 compare per row and point),
+// p^ = fl32(p'), c^ = fl32(c'), h^ = |c^|^2 / 2 as the wave computes it.  It needs no coordinates beyond the prefix, so the
+// 2 x d doubles of the points stay out of the registers; what it leaves per (tile of 128 points, row sub-range, tile of 16
+// rows) is one word: the rows some lane of either 64-point half keeps (bits 0-15 / 16-31).  k_scan_p<MASKED> then runs
+// phase B alone over those rows (1.3 % at C2, 0.13 % at the C5 shape) - same thresholds, same exact abandon test, same
+// candidates and bounds: a row phase A keeps is evaluated exactly, so only "abandoned implies beyond T" matters.
+//
+// cc_tau32: tau for a point.  T = its exact threshold of the kind, s = |p^|^2 (double), pm = max |p^_i|, cm >= max |c^_i|.
+// Reals, u = 2^-24:  U = sum_{i<8} (p_i - c_i)^2; phase B's partial sum P >= smin U (smin = min(1, 1/k)).  The conversions
+// perturb every difference by at most u' (|p^_i| + |c^_i|), so sqrt(U) >= sqrt(U^) - A, U^ = |p^ - c^|^2, A = sqrt(8) u' (pm + cm).
+// U^ = s - 2 p^.c^ + 2 H, H = |c^|^2 / 2; the wave's h^ is within 2^-21 H <= 2^-19 cm^2 of H (eh); the five roundings on any
+// path of the multiply-adds and the final add give |t' - (p^.c^ - tau)| <= g (|tau| + 8 pm cm), g = 6 u.  So t' < h^ implies
+// U^ > s - 2 tau - 2 g (|tau| + 8 pm cm) - 2 eh, and with
+//     tau <= (s - L) / 2 - g (|tau0| + 8 pm cm) - eh,     L = (sqrt(T (1 + 2^-40) / smin) + A)^2
+// U^ > L, sqrt(U) > sqrt(T (1 + 2^-40) / smin), P >= smin U > T (the 2^-40 covers the roundings of the double-precision
+// partial sum).  Slack: s's own rounding (2^-48 s), flushed subnormals (2^-100), tau rounded DOWN to single precision.
+// Refused (-inf: never abandon) unless pm, cm < 2^60 and |tau| < 2^120: no overflow in the products or the sum.
+__device__ __forceinline__ float cc_tau32(double T, double s, double pm, double cm, double inv_k)
+{
+    const float never = -__builtin_inff();
+    if (!(T < CC_INF)) return never;
+    const double smin = inv_k < 1.0 ? inv_k : 1.0;
+    const double A = 2.8284271247461903 * 0x1p-24 * (1.0 + 0x1p-20) * (pm + cm) + 0x1p-120;
+    const double r = sqrt(T * (1.0 + 0x1p-40) / smin) * (1.0 + 0x1p-50) + A;
+    const double L = r * r * (1.0 + 0x1p-20);
+    const double tau0 = 0.5 * (s - L) - 0x1p-48 * s;
+    const double tau = tau0 - 6.0 * 0x1p-24 * (__builtin_fabs(tau0) + 8.0 * pm * cm) - 0x1p-19 * cm * cm - 0x1p-100;
+    if (!(pm < 0x1p60 && cm < 0x1p60 && __builtin_fabs(tau) < 0x1p120)) return never;
+    float t = (float)tau;
+    if ((double)t > tau) t = (t > 0.0f) ? __uint_as_float(__float_as_uint(t) - 1u)
+                                      : (t < 0.0f ? __uint_as_float(__float_as_uint(t) + 1u) : -0x1p-149f);
+    return t;
+}
+
+// words per (tile of 128 points, row sub-range): one word of "abandoned a row of the kind" flags, then one per 16-row tile
+__host__ __device__ inline int cc_mask_tiles_per_sub(int rows, int nsub) { return (((rows + nsub - 1) / nsub) + CC_SCAN_TM - 1) / CC_SCAN_TM + 1; }
+
 template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_scan_a(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                     const double* __restrict__ g_cen, const int* __restrict__ g_kind,
+                                                     const double* __restrict__ thr, size_t thr_stride,
+                                                     unsigned* __restrict__ masks, size_t mask_stride, int tps, int round,
+                                                     int mode, int shard_rank, int shard_world, double guess_F)
+{
+    static_assert(CC_PRE == 8 && CC_PRE <= DP, "prefix dimensions");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 128;
+    if (j0 >= B) return;
+    thr += (size_t)win.q * thr_stride;
+    masks += (size_t)win.q * mask_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    // (the same split of the rows as k_scan_p: the masks are addressed by sub-range and tile)
+    int row_lo = 0, row_hi = win.rows;
+    if (shard_world > 1) cc_shard_range(win.rows, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int per = (row_hi - row_lo + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    double org[CC_PRE];
+#pragma unroll
+    for (int i = 0; i < CC_PRE; ++i) org[i] = g_cen[i];  // (wave-uniform: scalar loads)
+    // |c - o| <= |c| + |o| <= 2 x the largest |coordinate| of the table's centroids (centroids are means of points)
+    const double cmd = 2.0 * __builtin_fmax(ctl->x_absmax, __longlong_as_double((long long)ctl->cen_absmax));
+    const double inv_k = ctl->inv_k;
+    const bool guessed = guess_F > 0.0;
+    cc_f2 p2[2][CC_PRE / 2];
+    cc_f2 ninit[2][2];  // [point of the lane][kind]: the accumulator's start {-tau, 0}; no point: -inf (every row "exceeds")
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int jj = j0 + u * 64 + lane;
+        const bool valid = jj < B;
+        const double* xp = Xt + win.cursor + (valid ? jj : 0);
+        double s2 = 0.0;
+        float pmf = 0.0f;
+        float ph[CC_PRE];
+#pragma unroll
+        for (int i = 0; i < CC_PRE; ++i) {
+            ph[i] = valid ? (float)(xp[(size_t)i * n_pts] - org[i]) : 0.0f;
+            s2 += (double)ph[i] * (double)ph[i];
+            const float a = __builtin_fabsf(ph[i]);
+            pmf = a > pmf ? a : pmf;
+        }
+#pragma unroll
+        for (int i = 0; i < CC_PRE / 2; ++i) p2[u][i] = cc_f2{ph[2 * i], ph[2 * i + 1]};
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            double T;
+            if (guessed) T = (ctl->tg_ok[win.q][K] != 0) ? guess_F * ctl->tg[win.q][K] : CC_INF;
+            else T = valid ? thr[(size_t)jj * 2 + K] : CC_INF;
+            const float tau = valid ? cc_tau32(T, s2, (double)pmf, cmd, inv_k) : __builtin_inff();
+            ninit[u][K] = cc_f2{-tau, 0.0f};
+        }
+    }
+    __shared__ __attribute__((aligned(16))) float s_pre[NW * CC_SCAN_TM * CC_PRE];
+    __shared__ float s_h[NW * CC_SCAN_TM];
+    float* const tile = s_pre + (size_t)wv * CC_SCAN_TM * CC_PRE;
+    float* const th = s_h + (size_t)wv * CC_SCAN_TM;
+    unsigned* const mrow = masks + ((size_t)blockIdx.x * nsub + sub) * (size_t)tps;
+    unsigned dflag = 0u;  // bit 2 u + K: a row of kind K was abandoned for the points of half u
+    double tc[2];
+    int kdl = CC_KIND_DEAD;
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
+    int tt = 0;
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM, ++tt) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v = (float)(tc[q] - org[lane & 7]);
+            tile[lane + q * 64] = v;
+            // h of the row: the eight lanes that hold it add their squares (every lane ends up with the sum)
+            float hsum = v * v;
+            hsum += __shfl_xor(hsum, 1);
+            hsum += __shfl_xor(hsum, 2);
+            hsum += __shfl_xor(hsum, 4);
+            // a prefix beyond single precision's range: never abandoned (t' < -inf is false)
+            if ((lane & 7) == 0) th[(lane >> 3) + q * 8] = (hsum < 0x1p120f) ? 0.5f * hsum : -__builtin_inff();
+        }
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
+        const unsigned full = (1u << tm) - 1u;
+        unsigned surv[2] = {0u, 0u};
+        auto rows_of = [&](auto KSELC) {
+            constexpr int KSEL = decltype(KSELC)::value;
+            auto two = [&](int m0, int n) {
+                cc_f4 c01[2], c23[2];
+                float h[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int m = (v < n) ? m0 + v : m0;
+                    c01[v] = t4[m * 2]; c23[v] = t4[m * 2 + 1]; h[v] = th[m];
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    if (v >= n) break;
+                    const int m = m0 + v;
+                    int K;
+                    if constexpr (KSEL == 0) K = 0;
+                    else if constexpr (KSEL == 1) K = 1;
+                    else K = ((pmask >> m) & 1u) ? 0 : 1;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        cc_f2 acc = __builtin_elementwise_fma(p2[u][0], cc_f2{c01[v].x, c01[v].y}, K == 0 ? ninit[u][0] : ninit[u][1]);
+                        acc = __builtin_elementwise_fma(p2[u][1], cc_f2{c01[v].z, c01[v].w}, acc);
+                        acc = __builtin_elementwise_fma(p2[u][2], cc_f2{c23[v].x, c23[v].y}, acc);
+                        acc = __builtin_elementwise_fma(p2[u][3], cc_f2{c23[v].z, c23[v].w}, acc);
+                        float t;  // (written out: the vectoriser pairs the adds of two rows into one packed add behind three moves)
+                        asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(acc.x), "v"(acc.y));
+                        // kept unless t' < h^ (a NaN - an overflow the guards did not see - keeps the row)
+                        surv[u] |= (__builtin_amdgcn_ballot_w64(!(t < h[v])) != 0ull) ? (1u << m) : 0u;
+                    }
+                }
+            };
+            int m = 0;
+            for (; m + 2 <= tm; m += 2) two(m, 2);
+            if (m < tm) two(m, 1);
+        };
+        if (pmask == full) rows_of(std::integral_constant<int, 0>{});
+        else if (omask == full) rows_of(std::integral_constant<int, 1>{});
+        else rows_of(std::integral_constant<int, -1>{});
+        // rows of neither list (dead) are never completed by phase B: dropped from the mask, not counted as abandoned
+        const unsigned listed = (pmask | omask) & full;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            surv[u] &= listed;
+            if ((~surv[u] & pmask & full) != 0u) dflag |= 1u << (2 * u);
+            if ((~surv[u] & omask & full) != 0u) dflag |= 2u << (2 * u);
+        }
+        if (lane == 0) mrow[1 + tt] = surv[0] | (surv[1] << 16);
+    }
+    if (lane == 0) mrow[0] = dflag;  // (the sub-range's first word: its flags)
+}
+
+template <int DP, int NW, bool MASKED>
 __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3 : 2))) void k_scan_p(
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
     const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride,
     int shard_rank, int shard_world, unsigned long long* __restrict__ pstat, const int* __restrict__ plist, double guess_F,
-    unsigned long long* __restrict__ found)
+    unsigned long long* __restrict__ found, const unsigned* __restrict__ masks, size_t mask_stride, int tps)
 {
     static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
     const ScanWin win = cc_scan_window(ctl, round, mode);
@@ -1337,22 +1528,123 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
 
     double tc[2];
     int kdl = CC_KIND_DEAD;
+    // ---- phase B: the rows of a tile that stayed (bit mask `surv`) ----
+    auto phase_b = [&](int rt, unsigned surv, unsigned pmask, unsigned omask) {
+            while (surv != 0u) {
+                const int m = __builtin_ctz(surv);
+                surv &= surv - 1u;
+                const int rowg = rt + m;
+                const bool is_p = ((pmask >> m) & 1u) != 0u;
+                if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
+                const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
+                const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
+                double acc = 0.0;
+                bool gone = false;
+                cc_static_for<(DP + 7) / 8>([&](auto CC) {
+                    constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
+                    if (gone) return;
+                    double c[hi - lo], sc[hi - lo];
+    #pragma unroll
+                    for (int i = 0; i < hi - lo; ++i) {
+                        c[i] = rc[lo + i];
+                        sc[i] = rs[lo + i];
+                    }
+    #pragma unroll
+                    for (int i = 0; i < hi - lo; ++i) {
+                        double x = p[lo + i] - c[i];          // mc_functions.py:37
+                        x = x * x;                             // :38
+                        x = x * sc[i];                         // :39 (the divisor is a power of two)
+                        acc = (lo + i == 0) ? x : acc + x;     // :41
+                    }
+                    if constexpr (hi < DP) {
+                        // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
+                        if (is_p) {
+                            if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
+                        } else {
+                            if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
+                        }
+                    }
+                });
+                if (gone) continue;
+                ++n_full;
+                auto update = [&](auto KC) {
+                    constexpr int K = decltype(KC)::value;
+                    const double a = acc;
+                    double& d0 = bd[K][0];
+                    double& d1 = bd[K][1];
+                    int& s0 = bs[K][0];
+                    int& s1 = bs[K][1];
+                    bool ins = a < d1;
+                    bool first = a < d0;
+                    // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+                    const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+                    const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+                    if ((e1 | e0) != 0ull) {
+                        if (a == d1 || a == d0) {
+                            const int key = g_key[rowg];
+                            if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                            if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                        }
+                    }
+                    d1 = cc_vmin(d1, cc_vmax(d0, a));
+                    d0 = cc_vmin(d0, a);
+                    s1 = first ? s0 : (ins ? rowg : s1);
+                    s0 = first ? rowg : s0;
+                };
+                if (is_p) update(std::integral_constant<int, 0>{});
+                else update(std::integral_constant<int, 1>{});
+            }
+    };
+    if constexpr (MASKED) {
+        // Phase A has run as a kernel of its own (k_scan_a): per (tile of 128 points, sub-range) one word of "abandoned a row
+        // of the kind" flags, then one word per 16-row tile with the rows some lane of either 64-point half keeps.  The
+        // words of up to 64 tiles are fetched with one vector load; almost all are zero (1.3 % of the rows stay at C2,
+        // 0.13 % at the C5 shape), so a ballot leaves the few tiles that have work.
+        const int half = (int)(blockIdx.x & 1u);
+        const unsigned* const mrow = masks + (size_t)win.q * mask_stride + ((size_t)(blockIdx.x >> 1) * nsub + sub) * (size_t)tps;
+        if (r0 < r1) {
+            const unsigned fl = __builtin_amdgcn_readfirstlane(mrow[0]) >> (2 * half);
+            dropped[0] = (fl & 1u) != 0u;
+            dropped[1] = (fl & 2u) != 0u;
+            n_rows += r1 - r0;
+        }
+        const int ntiles = (r1 > r0) ? (r1 - r0 + CC_SCAN_TM - 1) / CC_SCAN_TM : 0;
+        for (int tb = 0; tb < ntiles; tb += 64) {
+            unsigned mw = (tb + lane < ntiles) ? mrow[1 + tb + lane] : 0u;
+            mw = (mw >> (16 * half)) & 0xFFFFu;
+            unsigned long long nz = __builtin_amdgcn_ballot_w64(mw != 0u);
+            while (nz != 0ull) {
+                const int t = __builtin_ctzll(nz);
+                nz &= nz - 1ull;
+                const int rt = r0 + (tb + t) * CC_SCAN_TM;
+                const int tm = min(CC_SCAN_TM, r1 - rt);
+                const unsigned full = (1u << tm) - 1u;
+                const unsigned surv = (unsigned)__builtin_amdgcn_readlane((int)mw, t) & full;
+                if (surv == 0u) continue;
+                const int kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
+                const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
+                const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
+                phase_b(rt, surv, pmask, omask);
+            }
+        }
+    } else {
     if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
     for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
         const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        unsigned surv = 0u;
+        unsigned pmask, omask;
+        const unsigned full = (1u << tm) - 1u;
         CC_WAVE_SYNC();
 #pragma unroll
         for (int q = 0; q < 2; ++q) tile[lane + q * 64] = (float)tc[q];
-        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
-        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
         CC_WAVE_SYNC();
         if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
         n_rows += tm;
         const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
-        const unsigned full = (1u << tm) - 1u;
 
         // ---- phase A ----
-        unsigned surv = 0u;
         // straight-line: one compare per row, the wave's verdict as one bit (which kinds lost rows follows from the
         // bits at the end of the tile)
         auto verdict = [&](auto KSELC, int m, float q) {
@@ -1383,72 +1675,8 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
         else phase_a(std::integral_constant<int, -1>{});
         if ((~surv & pmask & full) != 0u) dropped[0] = true;
         if ((~surv & omask & full) != 0u) dropped[1] = true;
-
-        // ---- phase B: the rows that stayed ----
-        while (surv != 0u) {
-            const int m = __builtin_ctz(surv);
-            surv &= surv - 1u;
-            const int rowg = rt + m;
-            const bool is_p = ((pmask >> m) & 1u) != 0u;
-            if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
-            const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
-            const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
-            double acc = 0.0;
-            bool gone = false;
-            cc_static_for<(DP + 7) / 8>([&](auto CC) {
-                constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
-                if (gone) return;
-                double c[hi - lo], sc[hi - lo];
-#pragma unroll
-                for (int i = 0; i < hi - lo; ++i) {
-                    c[i] = rc[lo + i];
-                    sc[i] = rs[lo + i];
-                }
-#pragma unroll
-                for (int i = 0; i < hi - lo; ++i) {
-                    double x = p[lo + i] - c[i];          // mc_functions.py:37
-                    x = x * x;                             // :38
-                    x = x * sc[i];                         // :39 (the divisor is a power of two)
-                    acc = (lo + i == 0) ? x : acc + x;     // :41
-                }
-                if constexpr (hi < DP) {
-                    // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
-                    if (is_p) {
-                        if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
-                    } else {
-                        if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
-                    }
-                }
-            });
-            if (gone) continue;
-            ++n_full;
-            auto update = [&](auto KC) {
-                constexpr int K = decltype(KC)::value;
-                const double a = acc;
-                double& d0 = bd[K][0];
-                double& d1 = bd[K][1];
-                int& s0 = bs[K][0];
-                int& s1 = bs[K][1];
-                bool ins = a < d1;
-                bool first = a < d0;
-                // exact ties: list order decides (hddstream.py:326/373, strict `<`)
-                const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
-                const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
-                if ((e1 | e0) != 0ull) {
-                    if (a == d1 || a == d0) {
-                        const int key = g_key[rowg];
-                        if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
-                        if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
-                    }
-                }
-                d1 = cc_vmin(d1, cc_vmax(d0, a));
-                d0 = cc_vmin(d0, a);
-                s1 = first ? s0 : (ins ? rowg : s1);
-                s0 = first ? rowg : s0;
-            };
-            if (is_p) update(std::integral_constant<int, 0>{});
-            else update(std::integral_constant<int, 1>{});
-        }
+        phase_b(rt, surv, pmask, omask);
+    }
     }
     // rows abandoned in phase A: their exact partial sums exceed every lane's T (k_seed_merge), which is all that is
     // recorded of them
