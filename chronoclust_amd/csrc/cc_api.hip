@@ -558,7 +558,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                     if (h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000)) {
                         hipLaunchKernelGGL((k_scan_p<DP, NW, false>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                            rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
-                                           h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)nullptr, (size_t)0, 0);
+                                           h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)nullptr, (size_t)0, 0, 1);
                         return;
                     }
                     const int nsub = S * NW;
@@ -571,9 +571,24 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                     hipLaunchKernelGGL((k_scan_a<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, (const Ctl*)h->ctl.p,
                                        (const double*)h->Xt.p, rows.cen, rows.kind, (const double*)h->thr.p, h->thr_stride,
                                        h->masks.p, h->mask_stride, tps, round, mode, srank, sworld, gF);
-                    hipLaunchKernelGGL((k_scan_p<DP, NW, true>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
-                                       rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
-                                       h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)h->masks.p, h->mask_stride, tps);
+                    // phase B: about one and a half rounds of the resident workgroups, i.e. q of phase A's sub-ranges per wave
+                    // (its waves live on chains of memory round trips - prologue, masks, a few rows, merge -, not on arithmetic:
+                    // with phase A's own split - eight rounds at the C5 shape - the prologues dominate, with one round every
+                    // wave walks q times the rows; 2 M x 40, 50 000 rows: q = 1 / 2 / 3 / 4 / 6 / 12 -> 39.6 / 40.6 / 40.7 /
+                    // 41.2 / 39.9 / 39.8 M points/s.  CHRONOCLUST_HIP_SCANB_Q overrides.)
+                    int q = 1;
+                    {
+                        const int tiles = (win + 63) / 64;
+                        const int resident = h->n_cus * (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3 : 2));
+                        for (int c = 1; c <= S; ++c)
+                            if (S % c == 0 && 2 * tiles * (S / c) >= 3 * resident) q = c;
+                        static const int q_env = []() { const char* e = getenv("CHRONOCLUST_HIP_SCANB_Q"); return e ? atoi(e) : 0; }();
+                        if (q_env > 0 && S % q_env == 0) q = q_env;
+                    }
+                    hipLaunchKernelGGL((k_scan_p<DP, NW, true>), dim3(grid.x, S / q), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                       rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank,
+                                       sworld, h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)h->masks.p,
+                                       h->mask_stride, tps, q);
                 };
                 auto seeded_chain = [&](int n_pts, const int* plist, Cand* part, size_t part_stride, int S) {
                         // (k_seed holds two points per lane: point tiles of 128)
@@ -591,7 +606,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                         hipLaunchKernelGGL((k_scan_p<DP, NW, false>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                            rows.scl, rows.kind, rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode,
                                            part_stride, shard_rank, shard_world, h->pstat_p(), plist, 0.0,
-                                           (unsigned long long*)nullptr, (const unsigned*)nullptr, (size_t)0, 0);
+                                           (unsigned long long*)nullptr, (const unsigned*)nullptr, (size_t)0, 0, 1);
                 };
                 if (phase == 1) {
                     // guessed thresholds on the exact multi-GPU path, after the ranks' records were gathered: the points

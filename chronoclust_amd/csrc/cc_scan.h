@@ -1440,7 +1440,7 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr,
     const float* __restrict__ thr32, size_t thr_stride, Cand* __restrict__ part, int round, int mode, size_t part_stride,
     int shard_rank, int shard_world, unsigned long long* __restrict__ pstat, const int* __restrict__ plist, double guess_F,
-    unsigned long long* __restrict__ found, const unsigned* __restrict__ masks, size_t mask_stride, int tps)
+    unsigned long long* __restrict__ found, const unsigned* __restrict__ masks, size_t mask_stride, int tps, int q_sub)
 {
     static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64, "k_scan_p shapes");
     const ScanWin win = cc_scan_window(ctl, round, mode);
@@ -1529,102 +1529,161 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
     double tc[2];
     int kdl = CC_KIND_DEAD;
     // ---- phase B: the rows of a tile that stayed (bit mask `surv`) ----
-    auto phase_b = [&](int rt, unsigned surv, unsigned pmask, unsigned omask) {
-            while (surv != 0u) {
-                const int m = __builtin_ctz(surv);
-                surv &= surv - 1u;
-                const int rowg = rt + m;
-                const bool is_p = ((pmask >> m) & 1u) != 0u;
-                if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
-                const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
-                const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
-                double acc = 0.0;
-                bool gone = false;
-                cc_static_for<(DP + 7) / 8>([&](auto CC) {
-                    constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
-                    if (gone) return;
-                    double c[hi - lo], sc[hi - lo];
-    #pragma unroll
-                    for (int i = 0; i < hi - lo; ++i) {
-                        c[i] = rc[lo + i];
-                        sc[i] = rs[lo + i];
-                    }
-    #pragma unroll
-                    for (int i = 0; i < hi - lo; ++i) {
-                        double x = p[lo + i] - c[i];          // mc_functions.py:37
-                        x = x * x;                             // :38
-                        x = x * sc[i];                         // :39 (the divisor is a power of two)
-                        acc = (lo + i == 0) ? x : acc + x;     // :41
-                    }
-                    if constexpr (hi < DP) {
-                        // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
-                        if (is_p) {
-                            if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
-                        } else {
-                            if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
-                        }
-                    }
-                });
-                if (gone) continue;
-                ++n_full;
-                auto update = [&](auto KC) {
-                    constexpr int K = decltype(KC)::value;
-                    const double a = acc;
-                    double& d0 = bd[K][0];
-                    double& d1 = bd[K][1];
-                    int& s0 = bs[K][0];
-                    int& s1 = bs[K][1];
-                    bool ins = a < d1;
-                    bool first = a < d0;
-                    // exact ties: list order decides (hddstream.py:326/373, strict `<`)
-                    const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
-                    const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
-                    if ((e1 | e0) != 0ull) {
-                        if (a == d1 || a == d0) {
-                            const int key = g_key[rowg];
-                            if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
-                            if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
-                        }
-                    }
-                    d1 = cc_vmin(d1, cc_vmax(d0, a));
-                    d0 = cc_vmin(d0, a);
-                    s1 = first ? s0 : (ins ? rowg : s1);
-                    s0 = first ? rowg : s0;
-                };
-                if (is_p) update(std::integral_constant<int, 0>{});
-                else update(std::integral_constant<int, 1>{});
+    // ---- phase B: one surviving row, from its first dimension, with the exact abandon test every eight dimensions ----
+    // `cs(i)` / `ss(i)`: the row's centroid coordinate / distance operand of dimension i (wave-uniform).
+    auto complete_row = [&](int rowg, bool is_p, auto&& cs, auto&& ss) {
+        double acc = 0.0;
+        bool gone = false;
+        cc_static_for<(DP + 7) / 8>([&](auto CC) {
+            constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
+            if (gone) return;
+            double c[hi - lo], sc[hi - lo];
+#pragma unroll
+            for (int i = 0; i < hi - lo; ++i) {
+                c[i] = cs(lo + i);
+                sc[i] = ss(lo + i);
             }
+#pragma unroll
+            for (int i = 0; i < hi - lo; ++i) {
+                double x = p[lo + i] - c[i];          // mc_functions.py:37
+                x = x * x;                             // :38
+                x = x * sc[i];                         // :39 (the divisor is a power of two)
+                acc = (lo + i == 0) ? x : acc + x;     // :41
+            }
+            if constexpr (hi < DP) {
+                // all lanes over their thresholds: the row is abandoned; its partial sum bounds its distance from below
+                if (is_p) {
+                    if (__builtin_amdgcn_ballot_w64(acc <= th[0]) == 0ull) { lb[0] = cc_vmin(lb[0], acc); gone = true; }
+                } else {
+                    if (__builtin_amdgcn_ballot_w64(acc <= th[1]) == 0ull) { lb[1] = cc_vmin(lb[1], acc); gone = true; }
+                }
+            }
+        });
+        if (gone) return;
+        ++n_full;
+        auto update = [&](auto KC) {
+            constexpr int K = decltype(KC)::value;
+            const double a = acc;
+            double& d0 = bd[K][0];
+            double& d1 = bd[K][1];
+            int& s0 = bs[K][0];
+            int& s1 = bs[K][1];
+            bool ins = a < d1;
+            bool first = a < d0;
+            // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+            const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+            const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+            if ((e1 | e0) != 0ull) {
+                if (a == d1 || a == d0) {
+                    const int key = g_key[rowg];
+                    if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                    if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                }
+            }
+            d1 = cc_vmin(d1, cc_vmax(d0, a));
+            d0 = cc_vmin(d0, a);
+            s1 = first ? s0 : (ins ? rowg : s1);
+            s0 = first ? rowg : s0;
+        };
+        if (is_p) update(std::integral_constant<int, 0>{});
+        else update(std::integral_constant<int, 1>{});
+    };
+    // the one-kernel form: the rows of a tile that stayed (bit mask), centroid and operands as scalar loads
+    auto phase_b = [&](int rt, unsigned surv, unsigned pmask, unsigned omask) {
+        while (surv != 0u) {
+            const int m = __builtin_ctz(surv);
+            surv &= surv - 1u;
+            const int rowg = rt + m;
+            const bool is_p = ((pmask >> m) & 1u) != 0u;
+            if (!is_p && ((omask >> m) & 1u) == 0u) continue;  // (neither list)
+            const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
+            const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
+            complete_row(rowg, is_p, [&](int i) { return rc[i]; }, [&](int i) { return rs[i]; });
+        }
     };
     if constexpr (MASKED) {
         // Phase A has run as a kernel of its own (k_scan_a): per (tile of 128 points, sub-range) one word of "abandoned a row
-        // of the kind" flags, then one word per 16-row tile with the rows some lane of either 64-point half keeps.  The
-        // words of up to 64 tiles are fetched with one vector load; almost all are zero (1.3 % of the rows stay at C2,
-        // 0.13 % at the C5 shape), so a ballot leaves the few tiles that have work.
+        // of the kind" flags, then one word per 16-row tile with the rows some lane of either 64-point half keeps.  Most
+        // words are zero, but the rows that stay are several per wave (0.6 % of the rows pass an eight-dimension prefix
+        // test for SOME point of 64; a fifth of those are completed), each a chain of dependent memory round trips when
+        // taken one by one.  So: (1) the wave lists its rows - a vector load of up to 64 mask words, a prefix sum over the
+        // lanes' bit counts, every lane writes the rows of its word into the wave's LDS list; (2) it walks the list with
+        // the NEXT row's 2 d doubles (and kind) already requested - one pass of coalesced vector loads into the wave's LDS
+        // row, read back as broadcasts - while the current one is evaluated.
+        constexpr int LCAP = 64 * CC_SCAN_TM;  // one batch of 64 mask words can list this many rows
+        __shared__ int s_list[NW * LCAP];
+        __shared__ __attribute__((aligned(16))) double s_rowbuf[NW * 2 * DP];
+        int* const lst = s_list + (size_t)wv * LCAP;
+        double* const srow = s_rowbuf + (size_t)wv * 2 * DP;
+        constexpr int RL = (2 * DP + 63) / 64;  // loads per lane for one row
+        auto fetch_row = [&](int rowg, double (&rv)[RL], int& rk) {
+#pragma unroll
+            for (int q = 0; q < RL; ++q) {
+                const int e = lane + q * 64;
+                rv[q] = (e < DP) ? g_cen[(size_t)rowg * DP + e] : ((e < 2 * DP) ? g_scl[(size_t)rowg * DP + (e - DP)] : 0.0);
+            }
+            rk = g_kind[rowg];
+        };
+        auto walk = [&](int n) {
+            if (n <= 0) return;
+            double rv[RL];
+            int rk;
+            CC_WAVE_SYNC();  // (the list is written)
+            fetch_row(__builtin_amdgcn_readfirstlane(lst[0]), rv, rk);
+            for (int e = 0; e < n; ++e) {
+                const int rowg = __builtin_amdgcn_readfirstlane(lst[e]);
+                const int kind = __builtin_amdgcn_readfirstlane(rk);
+                CC_WAVE_SYNC();  // (the previous row's reads are done)
+#pragma unroll
+                for (int q = 0; q < RL; ++q) {
+                    const int x = lane + q * 64;
+                    if (x < 2 * DP) srow[x] = rv[q];
+                }
+                CC_WAVE_SYNC();
+                if (e + 1 < n) fetch_row(__builtin_amdgcn_readfirstlane(lst[e + 1]), rv, rk);
+                if (kind != CC_KIND_PCORE && kind != CC_KIND_OUTLIER) continue;
+                complete_row(rowg, kind == CC_KIND_PCORE, [&](int i) { return srow[i]; }, [&](int i) { return srow[DP + i]; });
+            }
+            CC_WAVE_SYNC();  // (the list may be rewritten)
+        };
         const int half = (int)(blockIdx.x & 1u);
-        const unsigned* const mrow = masks + (size_t)win.q * mask_stride + ((size_t)(blockIdx.x >> 1) * nsub + sub) * (size_t)tps;
-        if (r0 < r1) {
-            const unsigned fl = __builtin_amdgcn_readfirstlane(mrow[0]) >> (2 * half);
-            dropped[0] = (fl & 1u) != 0u;
-            dropped[1] = (fl & 2u) != 0u;
-            n_rows += r1 - r0;
-        }
-        const int ntiles = (r1 > r0) ? (r1 - r0 + CC_SCAN_TM - 1) / CC_SCAN_TM : 0;
-        for (int tb = 0; tb < ntiles; tb += 64) {
-            unsigned mw = (tb + lane < ntiles) ? mrow[1 + tb + lane] : 0u;
-            mw = (mw >> (16 * half)) & 0xFFFFu;
-            unsigned long long nz = __builtin_amdgcn_ballot_w64(mw != 0u);
-            while (nz != 0ull) {
-                const int t = __builtin_ctzll(nz);
-                nz &= nz - 1ull;
-                const int rt = r0 + (tb + t) * CC_SCAN_TM;
-                const int tm = min(CC_SCAN_TM, r1 - rt);
-                const unsigned full = (1u << tm) - 1u;
-                const unsigned surv = (unsigned)__builtin_amdgcn_readlane((int)mw, t) & full;
-                if (surv == 0u) continue;
-                const int kd = (lane < tm) ? g_kind[rt + lane] : CC_KIND_DEAD;
-                const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_PCORE);
-                const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kd == CC_KIND_OUTLIER);
-                phase_b(rt, surv, pmask, omask);
+        const int nsub_a = nsub * q_sub;
+        const int per_a = (row_hi - row_lo + nsub_a - 1) / nsub_a;
+        for (int k = 0; k < q_sub; ++k) {
+            const int sa = sub * q_sub + k;
+            const int ra0 = row_lo + sa * per_a;
+            const int ra1 = min(row_hi, ra0 + per_a);
+            if (ra0 >= ra1) break;
+            const unsigned* const mrow = masks + (size_t)win.q * mask_stride + ((size_t)(blockIdx.x >> 1) * nsub_a + sa) * (size_t)tps;
+            {
+                const unsigned fl = __builtin_amdgcn_readfirstlane(mrow[0]) >> (2 * half);
+                if ((fl & 1u) != 0u) dropped[0] = true;
+                if ((fl & 2u) != 0u) dropped[1] = true;
+                n_rows += ra1 - ra0;
+            }
+            const int ntiles = (ra1 - ra0 + CC_SCAN_TM - 1) / CC_SCAN_TM;
+            for (int tb = 0; tb < ntiles; tb += 64) {
+                unsigned mw = (tb + lane < ntiles) ? mrow[1 + tb + lane] : 0u;
+                const int rt = ra0 + (tb + lane) * CC_SCAN_TM;
+                const int tm = min(CC_SCAN_TM, ra1 - rt);  // (<= 0 beyond the sub-range: mw is 0 there)
+                mw = (mw >> (16 * half)) & 0xFFFFu & (tm >= CC_SCAN_TM ? 0xFFFFu : ((1u << (tm > 0 ? tm : 0)) - 1u));
+                if (__builtin_amdgcn_ballot_w64(mw != 0u) == 0ull) continue;
+                // exclusive prefix sum of the lanes' bit counts: where each lane's rows go in the list
+                const int cnt = __builtin_popcount(mw);
+                int incl = cnt;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_up(incl, off);
+                    if (lane >= off) incl += o;
+                }
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                int pos = incl - cnt;
+                unsigned m2 = mw;
+                while (m2 != 0u) {
+                    const int bbit = __builtin_ctz(m2);
+                    m2 &= m2 - 1u;
+                    lst[pos++] = rt + bbit;
+                }
+                walk(total);
             }
         }
     } else {
@@ -1731,8 +1790,18 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
         cc_top2_push(c2, c3, s_m_at(w, 2));
         cc_top2_push(c2, c3, s_m_at(w, 3));
     }
-    Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
-    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    if constexpr (MASKED) {
+        // (k_decide merges S x q_sub partials per point: this workgroup's go to the first of its slots, the rest stay empty)
+        Cand* o = part + ((size_t)jj * S * q_sub + (size_t)blockIdx.y * q_sub) * 4;
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+        const Cand none = Cand{CC_INF, CC_IDX_INF, -1};
+        for (int k = 1; k < q_sub; ++k) {
+            o[4 * k] = none; o[4 * k + 1] = none; o[4 * k + 2] = none; o[4 * k + 3] = none;
+        }
+    } else {
+        Cand* o = part + ((size_t)jj * S + blockIdx.y) * 4;
+        o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+    }
 }
 
 // ---------------------------------------------------------------------------------
