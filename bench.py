@@ -511,7 +511,7 @@ def scan_roofline(acc, d, kernel):
     if full_pmc is None:  # (files of round 4 did not record their own share: the figures their runs printed)
         full_pmc = 0.013 if d <= 20 else 0.0013
     extra = max(0.0, full - full_pmc) * pm["k_scan_u"]["valu_instructions_per_wave_row"]
-    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_p") if k in pm) + extra
+    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p") if k in pm) + extra
     lanes_u = pairs_u * pm["k_scan_u"]["valu_instructions_per_wave_row"]
     lanes_p = pairs_p * per_row_p
     executed = (lanes_u + lanes_p) / secs / 1e12
@@ -524,7 +524,7 @@ def scan_roofline(acc, d, kernel):
     keys = ("valu_instructions_per_wave_row", "salu_instructions_per_wave_row", "lds_instructions_per_wave_row",
             "valu_busy_fraction", "lds_busy_fraction", "lds_array_busy_fraction", "wave_time_parked_on_waitcnt",
             "co_limiter", "avg_us_under_pmc", "source")
-    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_p") if n in pm},
+    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_a", "k_scan_p") if n in pm},
                        "instruction_lanes_per_launch": (lanes_u + lanes_p) / acc["scan_launches"],
                        "note": "counters of full windows running alone (tools/steady.py under rocprofv3 --pmc, three passes); "
                                "busy fractions are of the kernel's own run time, `frac` above is over this run's launches "

@@ -54,7 +54,7 @@ if len(sys.argv) > 7 and os.path.exists(sys.argv[7]):
 
 out = {"shape": "%d points x %d microclusters x %d dims per launch, running alone (tools/steady.py, LA=2)" % (WINDOW, ROWS, D),
        "csrc_sha256": bench.csrc_digest(), "scan_sha256": bench.scan_digest(), "rows_evaluated_in_full_frac": FULL, "dim": D, "rows": ROWS, "window": WINDOW, "kernels": {}}
-for pat in ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_u<"):
+for pat in ("k_seed<", "k_seed_merge", "k_scan_a<", "k_scan_p<", "k_scan_u<"):
     a, na = full_launches(sys.argv[1], pat)
     b, nb = full_launches(sys.argv[2], pat)
     c, nc = full_launches(sys.argv[3], pat)
