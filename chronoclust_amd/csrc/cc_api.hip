@@ -1844,10 +1844,10 @@ struct OnlineRun {
                                h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
                                (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0, 0);
             if (scan_rows > 0)
-                hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows);
+                hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows, 0);
             if (heavy_on && ++h->stats.heavy_launches > 0)
                 hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0,
-                                   long_list, long_cap);
+                                   long_list, long_cap, 0);
             for (int r = 1; r <= Rcur; ++r) {
                 const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                 int* tnew = (r & 1) ? h->T1.p : h->T0.p;
@@ -1888,10 +1888,10 @@ struct OnlineRun {
                                    r == Rcur ? 1 : 0, heavy_on ? 1 : 0, h->allow_quiet ? 1 : 0);
                 // (the claims of the last round are not replayed: nothing to gather either)
                 if (scan_rows > 0 && r < Rcur)
-                    hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows);
+                    hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows, h->allow_quiet ? 1 : 0);
                 if (heavy_on && r < Rcur && ++h->stats.heavy_launches > 0)
                     hipLaunchKernelGGL(k_claims_heavy, dim3(CC_HEAVY_CAP), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r,
-                                       long_list, long_cap);
+                                       long_list, long_cap, h->allow_quiet ? 1 : 0);
             }
             hipLaunchKernelGGL(k_commit_a, dim3(1), dim3(1024), 0, sA, h->ctl.p, tab, ver, car, h->T0.p, h->T1.p,
                                h->rk.p, h->rec.p, (const Cand*)h->clean.p, (const int8_t*)h->dpath.p);

@@ -1624,25 +1624,35 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
             }
             rk = g_kind[rowg];
         };
+        // (four rows in flight: at 50 000 rows x 40 dims the table is eight times an XCD's L2, a row comes from the memory
+        // side in 1-2 us, and a wave has 25 of them to walk)
+        constexpr int PF = 4;
         auto walk = [&](int n) {
             if (n <= 0) return;
-            double rv[RL];
-            int rk;
+            double rv[PF][RL];
+            int rk[PF];
             CC_WAVE_SYNC();  // (the list is written)
-            fetch_row(__builtin_amdgcn_readfirstlane(lst[0]), rv, rk);
-            for (int e = 0; e < n; ++e) {
-                const int rowg = __builtin_amdgcn_readfirstlane(lst[e]);
-                const int kind = __builtin_amdgcn_readfirstlane(rk);
-                CC_WAVE_SYNC();  // (the previous row's reads are done)
 #pragma unroll
-                for (int q = 0; q < RL; ++q) {
-                    const int x = lane + q * 64;
-                    if (x < 2 * DP) srow[x] = rv[q];
+            for (int k = 0; k < PF; ++k)
+                if (k < n) fetch_row(__builtin_amdgcn_readfirstlane(lst[k]), rv[k], rk[k]);
+            for (int base = 0; base < n; base += PF) {
+#pragma unroll
+                for (int k = 0; k < PF; ++k) {
+                    const int e = base + k;
+                    if (e >= n) break;
+                    const int rowg = __builtin_amdgcn_readfirstlane(lst[e]);
+                    const int kind = __builtin_amdgcn_readfirstlane(rk[k]);
+                    CC_WAVE_SYNC();  // (the previous row's reads are done)
+#pragma unroll
+                    for (int q = 0; q < RL; ++q) {
+                        const int x = lane + q * 64;
+                        if (x < 2 * DP) srow[x] = rv[k][q];
+                    }
+                    CC_WAVE_SYNC();
+                    if (e + PF < n) fetch_row(__builtin_amdgcn_readfirstlane(lst[e + PF]), rv[k], rk[k]);
+                    if (kind != CC_KIND_PCORE && kind != CC_KIND_OUTLIER) continue;
+                    complete_row(rowg, kind == CC_KIND_PCORE, [&](int i) { return srow[i]; }, [&](int i) { return srow[DP + i]; });
                 }
-                CC_WAVE_SYNC();
-                if (e + 1 < n) fetch_row(__builtin_amdgcn_readfirstlane(lst[e + 1]), rv, rk);
-                if (kind != CC_KIND_PCORE && kind != CC_KIND_OUTLIER) continue;
-                complete_row(rowg, kind == CC_KIND_PCORE, [&](int i) { return srow[i]; }, [&](int i) { return srow[DP + i]; });
             }
             CC_WAVE_SYNC();  // (the list may be rewritten)
         };

@@ -885,12 +885,14 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
 // ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Table tab, const int* __restrict__ T,
-                                                int round, int scan_rows)
+                                                int round, int scan_rows, int quiet_ok)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (round > 0 && ctl->fc[round - 1] >= B) return;  // k_decide of this round did not run either
+    // (... nor in a quiet round: it left T unwritten - the claims of the round before stand -, nothing to gather)
+    if (round > 0 && quiet_ok != 0 && ctl->rdiff[round] == 0) return;
     const int M0 = ctl->m_rows;
     const int m = blockIdx.x;
     if (m >= M0 || m >= scan_rows) return;
@@ -933,12 +935,13 @@ __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Tab
 // every k_decide whose claims are replayed, while the previous batch ended with heavy rows (k_decide: heavy_on).
 // ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_claims_heavy(Ctl* __restrict__ ctl, Table tab, const int* __restrict__ T, int round,
-                                                      int* __restrict__ long_list, int long_cap)
+                                                      int* __restrict__ long_list, int long_cap, int quiet_ok)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
     if (B == 0) return;
     if (round > 0 && ctl->fc[round - 1] >= B) return;  // k_decide of this round did not run either
+    if (round > 0 && quiet_ok != 0 && ctl->rdiff[round] == 0) return;  // (a quiet round: see k_claims)
     if ((int)blockIdx.x >= ctl->n_heavy) return;
     const int m = ctl->heavy_list[blockIdx.x];
     if (m < 0 || m >= ctl->m_rows) return;

@@ -352,7 +352,8 @@ typedef struct cc_policy_decision {
     int32_t win_cfg;        /* window size of the next batch (changes only with `restart`)                         */
     int32_t want;           /* the size the policy is heading for                                                  */
     int32_t rounds, batch_windows, lookahead, nodirty;
-    int32_t prune;          /* 0: plain scans, 1: pruned with seeded thresholds, 2: pruned with guessed thresholds   */
+    int32_t prune;          /* 0: plain scans, 1: pruned with seeded thresholds, 2: pruned with guessed thresholds,
+                             * 3: guessed thresholds, lean (no list of missed points, no seeded chain behind the scan) */
     int32_t shard;
     int32_t restart;        /* the chain of windows restarts: pending lookahead scan dropped, control block pushed */
     int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
