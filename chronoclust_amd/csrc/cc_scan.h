@@ -1624,9 +1624,9 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
             }
             rk = g_kind[rowg];
         };
-        // (four rows in flight: at 50 000 rows x 40 dims the table is eight times an XCD's L2, a row comes from the memory
+        // (up to four rows in flight: at 50 000 rows x 40 dims the table is eight times an XCD's L2, a row comes from the memory
         // side in 1-2 us, and a wave has 25 of them to walk)
-        constexpr int PF = 4;
+        constexpr int PF = DP <= 20 ? 4 : 1;  // (d = 40: the points alone are 80 registers - deeper prefetch spills)
         auto walk = [&](int n) {
             if (n <= 0) return;
             double rv[PF][RL];
