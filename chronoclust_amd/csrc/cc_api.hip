@@ -1948,7 +1948,7 @@ struct OnlineRun {
             const cc_policy_carry& k = policy->carry();
             h->adapt_win = k.adapt_win; h->clean_batches = k.clean_batches; h->since_shrink = k.since_shrink;
             if (dec.stalled)
-                return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in three consecutive batches of windows");
+                return fail(h, CC_ERR_INTERNAL, "the online phase made no progress in five consecutive batches of windows");
             if (h->trace && dec.prune_rows > 0)
                 fprintf(stderr, "[cc] pruned scans of the batch%s (sample): %lld (wave, row) pairs, %.1f %% evaluated in full; points missed by guessed thresholds so far: %lld\n",
                         h->guess_now ? ", guessed thresholds" : "", (long long)dec.prune_rows,

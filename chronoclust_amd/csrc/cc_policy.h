@@ -103,13 +103,18 @@ public:
             // point's outlier list started with a bound (k_decide, stage 1) - the seeded chain comes back for 2^18 points.
             // With SEEDED thresholds first candidates are exact and the first point of a window is always decidable:
             // should such a batch still commit nothing, the plain scan takes over for good.
-            if (done == done_before && !nodirty_) {
+            // The SECOND batch in a row without progress - whatever the first one was put down to (guessed thresholds, dirty
+            // scans that were not launched) - ends the pruned scans for the call: plain scans, dirty scans launched and no
+            // lookahead always decide a window's first point.
+            if (done == done_before && stalled_ >= 1) prune_resume_at_ = std::numeric_limits<long long>::max();
+            else if (done == done_before && !nodirty_) {
                 if (guess_on_) guess_resume_at_ = o.cursor + (1ll << 18);
                 else prune_resume_at_ = std::numeric_limits<long long>::max();
             }
         }
-        // whatever the cause, a call must not spin: a batch without progress is legitimate once (points refused for want
-        // of the dirty scans idle the rest of their batch), not three times in a row
+        // whatever the cause, a call must not spin: a batch without progress is legitimate (a point refused for want of the
+        // dirty scans or of the seeded chain idles the rest of its batch; each cause once: guessed thresholds -> seeded ->
+        // plain scans, dirty scans not launched -> launched), not five times in a row
         stalled_ = (done == done_before) ? stalled_ + 1 : 0;
         // ---- validation rounds enqueued per window: what the last batch needed ----
         int used = 1;
@@ -269,7 +274,7 @@ private:
         d.shard = shard_on_ ? 1 : 0;
         d.restart = restart;
         d.bad = bad;
-        d.stalled = stalled_ >= 3 ? 1 : 0;
+        d.stalled = stalled_ >= 5 ? 1 : 0;
         return d;
     }
 

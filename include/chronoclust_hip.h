@@ -357,7 +357,7 @@ typedef struct cc_policy_decision {
     int32_t shard;
     int32_t restart;        /* the chain of windows restarts: pending lookahead scan dropped, control block pushed */
     int32_t bad;            /* short, truncated windows at a small window size (input of the sequential-kernel rule) */
-    int32_t stalled;        /* three batches without progress: the call fails with CC_ERR_INTERNAL                 */
+    int32_t stalled;        /* five batches without progress: the call fails with CC_ERR_INTERNAL                  */
     int32_t sparse;         /* with nodirty: the sparse dirty scans run for the points that need rows of their own  */
     int32_t probe;          /* plain scans, and the pruned chain runs beside the batch's first one on 128 points: its
                              * sample tells the policy whether pruned scans would pay, at 1 / 256 of a scan's cost    */

@@ -321,3 +321,12 @@ def test_guessed_thresholds_and_points_whose_outlier_list_starts_with_a_bound():
     assert s["scan_g_launches"] > 0 and s["missed_points"] > 0
     # the last third of the stream still runs on pruned scans (they would be ~0 there once switched off for the call)
     assert s["scan_p_launches"] >= s["scan_u_launches"] * 0.6, s
+
+
+def test_forced_pruning_seed_whose_first_window_point_was_refused_three_batches_in_a_row():
+    """Seed 9348 of the round-5 soak: with pruning forced on a table of eight microclusters a guessed threshold misses every
+    point of a window; the batch that ran without dirty scans, the one with guessed thresholds and the one with seeded ones
+    each commit nothing before the policy is down to plain scans - the call used to end with "no progress in three
+    consecutive batches" (a liveness failure, not a wrong result).  The policy now ends pruned scans at the second such
+    batch in a row and the limit is five."""
+    test_forced_pruning_fuzz(9348)
