@@ -15,8 +15,8 @@ python - $OUT <<'PY' | tee -a $OUT/n2_status.txt
 import json, sys
 o = sys.argv[1]
 a = json.loads(open(o + "/n2_headline.json").read().strip().splitlines()[-1])
-print("headline: n_gpus %d, %.1f M points/s, %s" % (a["n_gpus"], a["value"] / 1e6, a["harness"]))
+print("headline: n_gpus %d, %.1f M points/s, line of %d bytes, %s" % (a["n_gpus"], a["value"] / 1e6, len(json.dumps(a)), a["config"].get("streams")))
 b = json.loads(open(o + "/n2_leg.json").read().strip().splitlines()[-1])
-print("leg line: value %.1f M points/s, one_stream_exact -> %s" % (b["value"] / 1e6, json.dumps(b.get("one_stream_exact"))[:300]))
+print("leg line: value %.1f M points/s, legs_failed %s, leg_errors %s" % (b["value"] / 1e6, json.dumps(b.get("legs_failed")), json.dumps(b.get("leg_errors"))[:300]))
 PY
 grep "exitcode" $OUT/n2_leg.err | tee -a $OUT/n2_status.txt
