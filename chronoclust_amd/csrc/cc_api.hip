@@ -194,6 +194,9 @@ struct cc_handle {
     DevBuf<unsigned long long> c_tile_dsq;
     DevBuf<int> T0, T1, rk;
     DevBuf<int> long_list;    // [2][CC_LONG_CAP] MCs whose chain k_chain_long replays (tables beyond k_claims' reach)
+    DevBuf<unsigned long long> lstat, lprev;  // [2][CC_LSTAT_ROWS] / [CC_MAX_WINDOW]: long chains laid out ahead of k_chain (k_chain_long<.., true>)
+    bool prep_launched = false;  // (this call: the counters behind lstat are worth reading)
+    bool allow_prep = true;   // CHRONOCLUST_HIP_LONGPREP=0: long chains replayed by one workgroup each, as before round 5
     DevBuf<CommitRec> rec;
     // scan copy of the table for lookahead scans (see ScanCopy)
     DevBuf<double> sh_cen[2], sh_scl[2], sh_cf1[2], sh_cf2[2], sh_w[2];
@@ -483,6 +486,8 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->c_kind.ensure(w); h->c_key.ensure(w); h->c_slot.ensure(w); h->c_kind0.ensure(w); h->c_dsq.ensure(w); h->c_tile_dsq.ensure(CC_DSQ_STRIDE * (w / 16 + 2));
     h->T0.ensure(w + 128); h->T1.ensure(w + 128);  // k_chain reads the claims in 128-entry blocks
     h->long_list.ensure(2 * CC_LONG_CAP);
+    h->lstat.ensure(2 * CC_LSTAT_ROWS + 2);
+    h->lprev.ensure(CC_MAX_WINDOW);
     h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1); h->sp_list.ensure(w);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
@@ -864,6 +869,8 @@ int cc_create(int device, cc_handle** out)
         if (pf && atof(pf) >= 1.0) h->prune_F = atof(pf);
         const char* lc = getenv("CHRONOCLUST_HIP_LONGCHAINS");
         h->allow_long = !(lc && lc[0] == '0');
+        const char* lpp = getenv("CHRONOCLUST_HIP_LONGPREP");
+        h->allow_prep = !(lpp && lpp[0] == '0');
         const char* gg = getenv("CHRONOCLUST_HIP_GROUP_GUESS");
         h->group_guess_always = gg && gg[0] == '1';
         const char* qt = getenv("CHRONOCLUST_HIP_QUIET");
@@ -1584,6 +1591,9 @@ struct OnlineRun {
         HIPCHK(hipMemsetAsync(h->rec.p, 0, sizeof(CommitRec), h->stream));
         HIPCHK(hipMemsetAsync(h->cmax.p, 0, 2 * sizeof(unsigned long long), h->stream));  // (k_seed takes maxima into it)
         HIPCHK(hipMemsetAsync(h->found.p, 0, h->found.n * sizeof(unsigned long long), h->stream));
+        // (marks of long chains laid out in an earlier call - another table, perhaps another numbering of the windows)
+        HIPCHK(hipMemsetAsync(h->lstat.p, 0, h->lstat.n * sizeof(unsigned long long), h->stream));
+        HIPCHK(hipMemsetAsync(h->lprev.p, 0, h->lprev.n * sizeof(unsigned long long), h->stream));
         if (c.m_rows > 0)
             hipLaunchKernelGGL(k_rebuild_scl, dim3((c.m_rows * h->d + 255) / 256), dim3(256), 0, h->stream, h->ctl.p, h->tab.view(),
                                c.m_rows, h->d, c.pow2, c.inv_k);
@@ -1851,24 +1861,38 @@ struct OnlineRun {
             for (int r = 1; r <= Rcur; ++r) {
                 const int* told = ((r - 1) & 1) ? h->T1.p : h->T0.p;
                 int* tnew = (r & 1) ? h->T1.p : h->T0.p;
+                // long chains of pcore MCs: running sums first, by one workgroup per chain; the steps themselves inside k_chain,
+                // the fallback (rejected steps, outlier MCs) behind it
+                // (while the chains are few and long: with 200 table rows a chain is one batch of k_chain_long and the rows' 200
+                // workgroups are parallel enough - the extra launch cost 2 % there, measured)
+                const bool prep = h->allow_prep && ((long_rows > 0 && long_rows <= 64) || (long_listed && long_few));
+                unsigned long long* const lstat = prep ? h->lstat.p : nullptr;
+                unsigned long long* const lprev = prep ? h->lprev.p : nullptr;
+                if (prep) h->prep_launched = true;
+                if (prep && long_rows > 0)
+                    hipLaunchKernelGGL((k_chain_long<true, true>), dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
+                                       ver, car, told, r, long_rows, (const int*)nullptr, lstat, lprev);
+                else if (prep)
+                    hipLaunchKernelGGL((k_chain_long<true, true>), dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
+                                       tab, ver, car, told, r, 0, (const int*)long_list, lstat, lprev);
                 hipLaunchKernelGGL(k_chain, dim3(cblocks), dim3(chain_threads), 0, sA,
-                                   h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows);
+                                   h->ctl.p, h->X.p, tab, ver, car, told, r, long_rows, (const unsigned long long*)lprev, lstat);
                 // k_chain_long: one workgroup per table row while k_claims serves the table, else per entry of the
                 // round's list.  The large workgroups (SPLIT) while they are few - rows <= 256, or a short list, judged by
                 // the previous batch's count -, the small ones (two per CU) when hundreds of chains are long
                 if (long_rows > 0 && long_rows <= 256)
-                    hipLaunchKernelGGL(k_chain_long<true>, dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
-                                       ver, car, told, r, long_rows, (const int*)nullptr);
+                    hipLaunchKernelGGL((k_chain_long<true, false>), dim3(long_rows), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p, tab,
+                                       ver, car, told, r, long_rows, (const int*)nullptr, lstat, lprev);
                 else if (long_rows > 0)
-                    hipLaunchKernelGGL(k_chain_long<false>, dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
-                                       told, r, long_rows, (const int*)nullptr);
+                    hipLaunchKernelGGL((k_chain_long<false, false>), dim3(long_rows), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
+                                       told, r, long_rows, (const int*)nullptr, lstat, lprev);
                 else if (long_listed && ++long_launches > 0) {
                     if (long_few)
-                        hipLaunchKernelGGL(k_chain_long<true>, dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
-                                           tab, ver, car, told, r, 0, (const int*)long_list);
+                        hipLaunchKernelGGL((k_chain_long<true, false>), dim3(long_cap), dim3(CC_LONG_THREADS), 0, sA, h->ctl.p, h->X.p,
+                                           tab, ver, car, told, r, 0, (const int*)long_list, lstat, lprev);
                     else
-                        hipLaunchKernelGGL(k_chain_long<false>, dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
-                                           car, told, r, 0, (const int*)long_list);
+                        hipLaunchKernelGGL((k_chain_long<false, false>), dim3(long_cap), dim3(256), 0, sA, h->ctl.p, h->X.p, tab, ver,
+                                           car, told, r, 0, (const int*)long_list, lstat, lprev);
                 }
                 const bool sparse_r = nodirty && sparse_now;
                 hipLaunchKernelGGL(k_dseed, dim3((gw + 63) / 64), dim3(64), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
@@ -2037,6 +2061,13 @@ struct OnlineRun {
         h->stats.pruned_scan_full_rows += (int64_t)h->hc.stat_prune_full;
         h->stats.long_chains += (int64_t)h->hc.stat_long;
         h->stats.long_chain_launches += long_launches;
+        if (h->prep_launched) {
+            h->prep_launched = false;
+            unsigned long long lp[2] = {0ull, 0ull};
+            HIPCHK(hipMemcpy(lp, h->lstat.p + 2 * CC_LSTAT_ROWS, sizeof(lp), hipMemcpyDeviceToHost));
+            h->stats.long_prepared += (int64_t)lp[0];
+            h->stats.long_replayed += (int64_t)lp[1];
+        }
         h->stats.tiles += h->hc.stat_tiles;
         h->stats.dirty_tiles += h->hc.stat_dirty_tiles;
         h->stats.missed_points += h->hc.stat_missed;

@@ -6,6 +6,8 @@
 // (d <= 64); sums over dimensions stay strictly left to right through an ordered shuffle loop.
 // ---------------------------------------------------------------------------------
 
+#define CC_LSTAT_ROWS 1024  // words of `lstat` per round parity: one per workgroup of a k_chain_long launch (table rows <= 1 024, or list entries); two counters behind them
+
 __device__ __forceinline__ unsigned cc_group_ballot(bool p)
 {
     const unsigned long long b = __builtin_amdgcn_ballot_w64(p);
@@ -1004,7 +1006,8 @@ __global__ __launch_bounds__(256) void k_claims_heavy(Ctl* __restrict__ ctl, Tab
 
 __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                Versions ver, Carry car, const int* __restrict__ T, int round,
-                                               int long_rows)
+                                               int long_rows, const unsigned long long* __restrict__ lprev,
+                                               unsigned long long* __restrict__ lstat)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1026,6 +1029,72 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
         return;
     }
     const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
+    // a member of a long chain whose running sums k_chain_long<.., true> has laid out (see there): this group evaluates
+    // the member's own step - the body of the walk below for one step, from the sums before the member
+    if (lprev != nullptr) {
+        const unsigned long long lp = lprev[j];
+        if ((lp >> 27) == stamp) {
+            const int pv = (int)(lp & 0x1FFFFull) - 1;
+            const size_t lslot = (size_t)(round & 1) * CC_LSTAT_ROWS + (size_t)((lp >> 17) & 0x3FFull);
+            const Par par = cc_load_par(ctl);
+            const int d = par.d;
+            double bc1[2] = {0.0, 0.0}, bc2[2] = {0.0, 0.0}, px[2] = {0.0, 0.0}, c0[2] = {0.0, 0.0}, w0[2] = {1.0, 1.0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = gl + 32 * h;
+                if (i < d) {
+                    bc1[h] = (pv < 0) ? tab.cf1[(size_t)t * d + i] : ver.cf1[(size_t)pv * d + i];
+                    bc2[h] = (pv < 0) ? tab.cf2[(size_t)t * d + i] : ver.cf2[(size_t)pv * d + i];
+                    px[h] = X[(ctl->cursor + j) * d + i];
+                    c0[h] = tab.cen[(size_t)t * d + i];
+                    w0[h] = 1.0 / tab.pref[(size_t)t * d + i];
+                }
+            }
+            const double bw = (pv < 0) ? tab.w[t] : ver.w[pv];
+            const int bkind = tab.kind[t];  // (a pcore MC: nothing to promote)
+            int kind0 = bkind;
+            if (ctl->mode != 0) {
+                const unsigned long long co = tab.carry_of[t];
+                if ((co >> 20) == ctl->window_seq) {
+                    const size_t r = (size_t)(co & 0xFFFFFull);
+                    kind0 = car.kind0[r];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int i = gl + 32 * h;
+                        if (i < d) { c0[h] = car.c0[r * d + i]; w0[h] = car.w0[r * d + i]; }
+                    }
+                }
+            }
+            const GroupAdd g = cc_group_add_regs(bc1, bc2, bw, px, d, par);
+            if (!(g.r2 <= par.eps_sq)) {
+                if (gl == 0) atomicMin(&lstat[lslot], (stamp << 20) | (unsigned long long)j);  // (the FIRST rejected step is what counts)
+                return;
+            }
+            double dq = 0.0;
+            bool mv = false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = gl + 32 * h;
+                if (i < d) {
+                    ver.cen[(size_t)j * d + i] = g.cen[h]; ver.pref[(size_t)j * d + i] = g.pr[h];
+                    ver.scl[(size_t)j * d + i] = par.pow2 ? (g.pr[h] == 1.0 ? 1.0 : par.inv_k) : g.pr[h];
+                }
+                const double df = g.cen[h] - c0[h];
+                dq += df * df * w0[h];
+                mv = mv || (1.0 / g.pr[h] != w0[h]);
+            }
+            dq = cc_group_sum_any_order(dq);
+            const bool promoted = bkind == CC_KIND_PCORE && kind0 == CC_KIND_OUTLIER;
+            if ((bkind != kind0 && !promoted) || !(dq >= 0.0) || cc_group_ballot(mv) != 0u) dq = CC_INF;
+            if (gl == 0) {
+                ver.tgt[j] = t; ver.kind[j] = bkind; ver.key[j] = tab.key[t]; ver.upg[j] = -1; ver.acc[j] = 1;
+                int cls;
+                ver.dsq[j] = cc_dsq_store(dq, bkind, kind0, &cls);
+                atomicMax(&ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + cls], cc_dsq_code(dq));
+            }
+            return;
+        }
+    }
     // k_decide recorded the first and the last window point that target t: the first one heads the chain and
     // walks it; everybody else is walked over
     const size_t rd = (size_t)(round & 1) * tab.cap + (size_t)t;
@@ -1255,10 +1324,24 @@ __global__ __launch_bounds__(256) void k_chain(Ctl* __restrict__ ctl, const doub
 // tests spread over all of them - twice the LDS, so one workgroup per CU: for the few long chains of few-microcluster
 // streams and skewed populations.  !SPLIT: 256 threads, two workgroups per CU: tables of hundreds of rows, where every
 // row's chain is long-ish and the workgroups are many.
-template <bool SPLIT>
+//
+// PREP (round 5): the sequential part alone.  One workgroup's vector-memory pipeline and its per-(step, dimension) work
+// were most of a long chain's time (a chain of 3 277 members: 220 us, of which the running sums are 60) - and everything
+// but the running sums is a function of one step's sums.  k_chain_long<true, true>, launched BEFORE k_chain, walks the
+// chain of a pcore MC through phases 1 and 2 only and leaves, per member m: the sums after m (ver.cf1 / cf2 / w), the
+// member after it (ver.next) and `lprev[m]` = stamp, the chain's slot in `lstat`, the member before it.  k_chain's
+// 32-lane group of m then evaluates that one step from the sums before it - the same function of the same operands as a
+// step of its own walk, on all CUs instead of one - and if the radius test rejects the step takes the member into the
+// chain's word of `lstat` (atomic minimum: the first rejected step).  The sums behind a rejected step are not the chain's:
+// the launch of k_chain_long<.., false> that follows replays such a chain FROM that member on, starting from the version
+// row of the member before it (every step up to there was accepted and evaluated) - and, from the start, the chains that
+// were never prepared: outlier MCs, whose promotion is a sequential matter.
+#define CC_LPREV(stamp, slot, prev) (((unsigned long long)(stamp) << 27) | ((unsigned long long)(slot) << 17) | (unsigned long long)((prev) + 1))
+template <bool SPLIT, bool PREP>
 __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                     Versions ver, Carry car, const int* __restrict__ T, int round,
-                                                    int scan_rows, const int* __restrict__ long_list)
+                                                    int scan_rows, const int* __restrict__ long_list,
+                                                    unsigned long long* __restrict__ lstat, unsigned long long* __restrict__ lprev)
 {
     CC_LATENCY_KERNEL();
     const int B = ctl->win_b;
@@ -1283,8 +1366,32 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     const unsigned long long cw = tab.cnt[t];
     const int n_memb = ((cw >> 24) == stamp) ? (int)(cw & 0xFFFFFFull) : 0;
     if (n_memb <= CC_CHAIN_MEMB) return;  // a listed chain: k_chain walks it
-    const int head = 0xFFFFF - (int)(ft & 0xFFFFFull);
+    int head = 0xFFFFF - (int)(ft & 0xFFFFFull);
     const int last_j = ((lt >> 20) == stamp) ? (int)(lt & 0xFFFFFull) : head;
+    // the chain's word in lstat (per round parity; table row or list entry): stamp << 20 | first rejected member of a
+    // prepared chain (0xFFFFF: none)
+    const size_t lslot = (size_t)(round & 1) * CC_LSTAT_ROWS + (size_t)blockIdx.x;
+    int resume_prev = -1;   // the member before the one the replay starts at (-1: the table row is the state before it)
+    bool resumed = false;
+    if constexpr (PREP) {
+        if (tab.kind[t] != CC_KIND_PCORE) return;
+        if (threadIdx.x == 0) {
+            lstat[lslot] = (stamp << 20) | 0xFFFFFull;
+            atomicAdd(&lstat[2 * CC_LSTAT_ROWS], 1ull);
+        }
+    } else {
+        if (lstat != nullptr) {
+            const unsigned long long ls = lstat[lslot];
+            if ((ls >> 20) == stamp) {
+                const int f = (int)(ls & 0xFFFFFull);
+                if (f == 0xFFFFF) return;  // prepared, and k_chain accepted every step
+                if (threadIdx.x == 0) atomicAdd(&lstat[2 * CC_LSTAT_ROWS + 1], 1ull);
+                resumed = true;
+                head = f;
+                resume_prev = (int)(lprev[f] & 0x1FFFFull) - 1;
+            }
+        }
+    }
 
     const Par par = cc_load_par(ctl);
     const int d = par.d;
@@ -1309,8 +1416,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     __shared__ int s_wsum[SCAN_WAVES];
     __shared__ int s_first_fail, s_first_up;
     // per (step, dimension) of a batch: the term of the radius sum, the displacement term, "preferred after the step"
-    __shared__ double s_term[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1], s_dqt[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
-    __shared__ unsigned char s_pf[SPLIT ? CC_LONG_XY_DOUBLES / 2 : 1];
+    __shared__ double s_term[SPLIT && !PREP ? CC_LONG_XY_DOUBLES / 2 : 1], s_dqt[SPLIT && !PREP ? CC_LONG_XY_DOUBLES / 2 : 1];
+    __shared__ unsigned char s_pf[SPLIT && !PREP ? CC_LONG_XY_DOUBLES / 2 : 1];
     const int NT = (int)blockDim.x;  // CC_LONG_THREADS: four waves per SIMD - these phases are instruction chains, not bandwidth
     // staged coordinates / CF prefixes of a batch, dimension-major: entry (step k, dimension i) at i * Kp + k.  The chains
     // walk a dimension's steps - contiguous, so their LDS operands have immediate offsets: a lone wave issues one
@@ -1349,6 +1456,15 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         }
     }
     __syncthreads();
+    // a replay that starts inside the chain: the running state is the version row of the member before
+    if (resume_prev >= 0) {
+        if (tid < d) {
+            const size_t o = (size_t)resume_prev * d + tid;
+            s_b1[tid] = ver.cf1[o]; s_b2[tid] = ver.cf2[o]; s_bcen[tid] = ver.cen[o]; s_bpref[tid] = ver.pref[o];
+        }
+        if (tid == 0) s_bw = ver.w[resume_prev];
+        __syncthreads();
+    }
     if (tid == 0) {
         double dq = 0.0;
         for (int i = 0; i < d; ++i) {
@@ -1370,6 +1486,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     int scan_pos = head & ~(PASS - 1);  // next block of PASS claims to look at
     bool scan_done = false;
     int walked = 0;
+    int prev_last = -1;  // (PREP) the member before the batch at hand: none before the head
     bool promoted_any = false;
     // (every thread scans four claims per pass.  The claims of a pass are loaded one pass ahead: the latency of the load
     // runs beside the batch in between, not in front of the pass.)
@@ -1470,21 +1587,54 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         // (mc_functions.py:24-29 / microcluster.py:147: the additions k_chain makes, in its order).
         // (sixteen steps at a time: the sixteen LDS reads go out together, then the sixteen additions in order, then the
         // sixteen writes - read, add, write per step would wait out one LDS round trip per step)
+#ifndef CC_LONG_UNROLL
+#define CC_LONG_UNROLL 16
+#endif
+#ifndef CC_LONG_PREFETCH
+#define CC_LONG_PREFETCH 0
+#endif
         auto prefix_chain = [&](double* a, int i, double c) {
             double* const row = a + (size_t)i * Kp;
+            constexpr int U = CC_LONG_UNROLL;
             int k = 0;
-            for (; k + 16 <= n; k += 16) {
-                double v[16];
+#if CC_LONG_PREFETCH
+            double v[U], nx[U];
+            if (n >= U) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = row[k + u];
+                for (int u = 0; u < U; ++u) v[u] = row[u];
+            }
+            for (; k + U <= n; k += U) {
+                const bool more = k + 2 * U <= n;
+                if (more) {
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
+                    for (int u = 0; u < U; ++u) nx[u] = row[k + U + u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
                     c = c + v[u];
                     v[u] = c;
                 }
 #pragma unroll
-                for (int u = 0; u < 16; ++u) row[k + u] = v[u];
+                for (int u = 0; u < U; ++u) row[k + u] = v[u];
+                if (more) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) v[u] = nx[u];
+                }
             }
+#else
+            for (; k + U <= n; k += U) {
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = row[k + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    c = c + v[u];
+                    v[u] = c;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) row[k + u] = v[u];
+            }
+#endif
             for (; k < n; ++k) {
                 c = c + row[k];
                 row[k] = c;
@@ -1516,6 +1666,39 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         }
         __syncthreads();
         CC_TICK(2);  // chains
+
+        if constexpr (PREP) {
+            // the sums after every member, its neighbours in the chain: what k_chain's group of the member needs for its step
+            for (int e = tid; e < n * d; e += NT) {
+                const int k = e / d, i = e - k * d;
+                const size_t o = (size_t)s_queue[(qhead + k) & (QUEUE - 1)] * d + i;
+                ver.cf1[o] = xs[at(k, i)]; ver.cf2[o] = ys[at(k, i)];
+            }
+            if (tid < n) {
+                const int k = tid;
+                const int m = s_queue[(qhead + k) & (QUEUE - 1)];
+                const int pv = (k > 0) ? s_queue[(qhead + k - 1) & (QUEUE - 1)] : prev_last;
+                ver.w[m] = s_w[k];
+                ver.next[m] = (k + 1 < qcount) ? s_queue[(qhead + k + 1) & (QUEUE - 1)] : CC_IDX_INF;
+                lprev[m] = CC_LPREV(stamp, blockIdx.x, pv);
+            }
+            prev_last = s_queue[(qhead + n - 1) & (QUEUE - 1)];
+            __syncthreads();
+            CC_TICK(5);  // (version rows: the sums)
+            const int l = n - 1;
+            if (tid < d) { s_b1[tid] = xs[at(l, tid)]; s_b2[tid] = ys[at(l, tid)]; }
+            if (tid == 64) s_bw = s_w[l];
+            qhead = (qhead + n) & (QUEUE - 1);
+            qcount -= n;
+            walked += n;
+            pre_elems = pre_next;
+            __syncthreads();
+            CC_TICK(6);
+#ifdef CC_LONG_TIMERS
+            tk_acc[7] += 1ull;
+#endif
+            continue;
+        }
 
         // ---- 3. every step evaluated on its own prefix ----
         // (a) per (step, dimension), all threads: the two quotients, the variance, the term of the radius sum - the
@@ -1655,7 +1838,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         for (int i = 0; i < 8; ++i) atomicAdd(&ctl->dbg_long[i], tk_acc[i]);
 #endif
     if (tid == 0) {
-        tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it
+        if (!resumed) tab.clen[t] = walked;  // k_dseed chooses its way of finding live versions by it (a resumed replay: the whole chain's count is there already)
         if (promoted_any) ctl->any_up[round] = 1;
     }
 }

@@ -127,6 +127,9 @@ typedef struct cc_stats {
     int64_t seq_r_points;          /* of seq_points: taken by the register-resident sequential kernel (d <= 4)    */
     int64_t heavy_launches;        /* k_claims_heavy launches (claims of heavy rows gathered without k_decide's atomics) */
     int64_t scan_lean_launches;    /* of scan_g_launches: lean - no list of missed points, no seeded chain behind the scan */
+    int64_t long_prepared;         /* of long_chains: chains of pcore microclusters whose running sums were laid out ahead of
+                                    * k_chain, every step then evaluated by the step's own 32-lane group ...              */
+    int64_t long_replayed;         /* ... and of those, chains replayed from the start because the radius test rejected a step */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

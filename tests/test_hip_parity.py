@@ -316,6 +316,32 @@ def test_long_chains(g, window, lookahead):
         _check_against_oracle(h, o)
 
 
+@pytest.mark.parametrize("window,lookahead,sigma", [(16384, 0, 0.048), (16384, 2, 0.048), (32768, 3, 0.046), (8192, 0, 0.049)])
+def test_long_chains_with_rejected_steps(window, lookahead, sigma):
+    """Few microclusters whose spread sits at the preferred-dimension threshold (delta = 0.05): their dimensions flip
+    between preferred and not, so the radius test rejects steps all through the long chains of the pcore MCs.  Those
+    chains are laid out ahead of k_chain (k_chain_long<.., true>: running sums only), every step evaluated by its own
+    group, and a chain with a rejected step is replayed from that step on - both must have happened."""
+    from oracle import oracle as O
+    n, d, g = 70000, 6, 5
+    cfg = scenarios.params_to_config(scenarios.blob_params(n, param_epsilon=0.08))
+    h, o = _hdd(cfg, window=window, lookahead=lookahead, sequential=1), O.OracleHDDStream(cfg)  # (sequential = 1: never k_seq)
+    tot = dict(long_prepared=0, long_replayed=0)
+    for t in range(2):
+        X = scenarios.make_blobs(5100 + t, n, d, g, sigma)
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+        s = h.stats()
+        for k in tot:
+            tot[k] += s[k]
+    if os.environ.get("CHRONOCLUST_HIP_LONGPREP") == "0" or os.environ.get("CHRONOCLUST_HIP_LONGCHAINS") == "0":
+        assert tot["long_prepared"] == 0
+    else:
+        assert tot["long_prepared"] > 0 and 0 < tot["long_replayed"] < tot["long_prepared"], tot
+    assert int(np.sum((h.labels_path & 3) == 1)) > 60  # (outlier adds: rejected by the pcore stage)
+
+
 @pytest.mark.parametrize("window,lookahead,heavy", [(16384, 0, 0.3), (32768, 3, 0.5), (8192, 2, 0.1), (32768, 0, 0.02)])
 def test_long_chains_on_a_large_table(window, lookahead, heavy):
     """Skewed populations on a table k_claims does not serve (more than 1 024 microclusters): three of 2 000 blobs take
