@@ -1403,6 +1403,9 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
 
     __shared__ __attribute__((aligned(16))) double s_xy[CC_LONG_XY_DOUBLES + 2 * CC_MAX_DIM];  // (+ one odd-length pad per dimension)
     __shared__ double s_w[256], s_dq[256];
+    // (PREP: a second staging area - the running sums of one batch run beside the staging of the next, see the loop)
+    __shared__ __attribute__((aligned(16))) double s_xy2[PREP && SPLIT ? CC_LONG_XY_DOUBLES + 2 * CC_MAX_DIM : 1];
+    __shared__ double s_w2[PREP && SPLIT ? 256 : 1];
     __shared__ unsigned long long s_mask[256];  // bit i: dimension i is a preferred one after the step (var <= delta^2)
     __shared__ int s_flag[256];                 // bit 0: radius test passed, bit 1: promotion condition holds
     // claims looked at per pass of the member collection: four per thread; the ring buffer holds two passes' worth
@@ -1425,6 +1428,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     // instructions (54 -> 24 cycles per step, timed).  Kp is odd: threads that walk a step's dimensions (lanes = consecutive
     // dimensions) then hit 32 different LDS banks.
     const int Kp = K | 1;
+    const bool one_wave = d <= 31;  // the three running sums in one wave (see the chains)
     double* const xs = s_xy;
     double* const ys = s_xy + (size_t)Kp * d;
     auto at = [&](int k, int i) { return i * Kp + k; };
@@ -1509,9 +1513,10 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
 #define CC_TICK(i) do { } while (0)
 #endif
 
-    for (;;) {
-        // ---- 1. members in order: ordered compaction of the next claims into the queue ----
-        while (!scan_done && qcount < K + 1 && qcount + PASS <= QUEUE) {
+    // members in order: ordered compaction of the next claims into the queue, until it holds `want` of them (or the claims
+    // are through).  K slots behind the head stay untouched: the batch before the one at hand is still read there (PREP).
+    auto collect = [&](const int want) {
+        while (!scan_done && qcount < want && qcount + PASS + K <= QUEUE) {
             const int i0 = scan_pos + (scanner ? tid : 0) * 4;
             const int4 v = v_next;
             v_next = load_claims(scan_pos + PASS);
@@ -1546,6 +1551,126 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             scan_pos += PASS;
             if (scan_pos > last_j) scan_done = true;
         }
+    };
+
+    // the running sums of a batch of n steps over one staged row (see phase 2 of the loop).  Sixteen steps at a time: the
+    // sixteen LDS reads go out together, then the sixteen additions in order, then the sixteen writes.  (What a step costs is
+    // the LDS's time per instruction, not the round trip: a dependent v_add_f64 takes 7 cycles, a step 28 with its half a
+    // ds_read2_b64 and half a ds_write2_b64, whatever the number of active lanes; issuing the next sixteen reads ahead of
+    // these additions gave 27, storing the sums straight to HBM instead of the LDS 35-40 - tools/micro/dep_add.hip.)
+#ifndef CC_LONG_UNROLL
+#define CC_LONG_UNROLL 16
+#endif
+    auto prefix_chain = [&](double* const row, double c, const int n) {
+        constexpr int U = CC_LONG_UNROLL;
+        int k = 0;
+        for (; k + U <= n; k += U) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = row[k + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                c = c + v[u];
+                v[u] = c;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) row[k + u] = v[u];
+        }
+        for (; k < n; ++k) {
+            c = c + row[k];
+            row[k] = c;
+        }
+        return c;
+    };
+
+    if constexpr (PREP && SPLIT) {
+        if (one_wave) {
+            // The pipelined form (d <= 31: the running sums fit one wave).  The first wave adds up batch b in one staging area
+            // while the other fifteen write out batch b - 1 from the second one - sums, neighbours, stamps - and stage batch
+            // b + 1 into it: every thread of theirs stores the sums of a slot and then overwrites that same slot, so the
+            // two steps need no barrier between them, and the running sums themselves stay in the first wave's registers
+            // from batch to batch.  One barrier per batch; the member collection (all waves) runs between batches and keeps
+            // two batches' worth of members queued, so that the batch after the one at hand is known in full.
+            auto bxq = [&](const int q) -> double* { return q ? s_xy2 : s_xy; };
+            auto bwq = [&](const int q) -> double* { return q ? s_w2 : s_w; };
+            const int st = tid - 64, NS = NT - 64;  // the staging threads
+            const size_t ys_off = (size_t)Kp * d;
+            auto stage = [&](double* const xb, double* const wb, const int first, const int n_) {
+                for (int e = st; e < n_ * d; e += NS) {
+                    const int k = e / d, i = e - k * d;
+                    const double x = X[(cursor + s_queue[(first + k) & (QUEUE - 1)]) * d + i];
+                    xb[at(k, i)] = x;
+                    xb[ys_off + at(k, i)] = x * x;
+                }
+                for (int k = st; k < n_; k += NS) wb[k] = 1.0;  // (what the W chain adds per step)
+            };
+            // (n_after: members the queue holds behind this batch's first one; before: the member before it)
+            auto write_out = [&](const double* const xb, const double* const wb, const int first, const int n_, const int n_after,
+                                 const int before) {
+                for (int e = st; e < n_ * d; e += NS) {
+                    const int k = e / d, i = e - k * d;
+                    const size_t o = (size_t)s_queue[(first + k) & (QUEUE - 1)] * d + i;
+                    ver.cf1[o] = xb[at(k, i)]; ver.cf2[o] = xb[ys_off + at(k, i)];
+                }
+                for (int k = st; k < n_; k += NS) {
+                    const int m = s_queue[(first + k) & (QUEUE - 1)];
+                    const int pv = (k > 0) ? s_queue[(first + k - 1) & (QUEUE - 1)] : before;
+                    ver.w[m] = wb[k];
+                    ver.next[m] = (k + 1 < n_after) ? s_queue[(first + k + 1) & (QUEUE - 1)] : CC_IDX_INF;
+                    lprev[m] = CC_LPREV(stamp, blockIdx.x, pv);
+                }
+            };
+            collect(2 * K + 1);
+            __syncthreads();
+            CC_TICK(0);
+            int n = qcount < K ? qcount : K;
+            if (tid >= 64) stage(bxq(0), bwq(0), qhead, n);
+            __syncthreads();
+            CC_TICK(1);
+            const bool c1 = tid < d, c2 = tid >= 32 && tid < 32 + d, cw = tid == 63;
+            double run = c1 ? s_b1[tid] : c2 ? s_b2[tid - 32] : s_bw;  // this lane's running sum (first wave)
+            int cur = 0, n_prev = 0, first_prev = 0, before_prev = -1;
+            while (n > 0) {
+                const int n_next = min(K, qcount - n);  // (exact: either the claims are through or the queue holds 2 K + 1)
+                if (tid < 64) {
+                    if (c1 || c2 || cw)
+                        run = prefix_chain(c1 ? bxq(cur) + (size_t)tid * Kp : c2 ? bxq(cur) + ys_off + (size_t)(tid - 32) * Kp : bwq(cur), run, n);
+                } else {
+                    if (n_prev > 0) write_out(bxq(cur ^ 1), bwq(cur ^ 1), first_prev, n_prev, n_prev + 1, before_prev);
+                    if (n_next > 0) stage(bxq(cur ^ 1), bwq(cur ^ 1), qhead + n, n_next);
+                }
+                __syncthreads();
+                CC_TICK(2);
+                before_prev = (n_prev > 0) ? s_queue[(first_prev + n_prev - 1) & (QUEUE - 1)] : -1;
+                first_prev = qhead; n_prev = n;
+                qhead = (qhead + n) & (QUEUE - 1);
+                qcount -= n;
+                walked += n;
+                cur ^= 1;
+                n = n_next;
+                if (n == 0) break;
+                collect(2 * K + 1);
+                __syncthreads();
+                CC_TICK(0);
+#ifdef CC_LONG_TIMERS
+                tk_acc[7] += 1ull;
+#endif
+            }
+            // the last batch's sums (nothing behind it: the chain ends there)
+            if (tid >= 64 && n_prev > 0) write_out(bxq(cur ^ 1), bwq(cur ^ 1), first_prev, n_prev, n_prev, before_prev);
+            CC_TICK(5);
+#ifdef CC_LONG_TIMERS
+            tk_acc[7] += 1ull;
+            if (tid == 0 && blockIdx.x == 0)
+                for (int i = 0; i < 8; ++i) atomicAdd(&ctl->dbg_long[i], tk_acc[i]);
+#endif
+            if (tid == 0) tab.clen[t] = walked;
+            return;
+        }
+    }
+    for (;;) {
+        // ---- 1. members in order ----
+        collect(K + 1);
         __syncthreads();
         CC_TICK(0);  // member collection
         if (qcount == 0) break;
@@ -1580,6 +1705,8 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             pre_next = n_ahead * d;
         }
         if (tid == 0) { s_first_fail = n; s_first_up = n; }
+        if (one_wave)
+            for (int k = tid; k < n; k += NT) s_w[k] = 1.0;  // (what the W chain adds per step)
         __syncthreads();
         CC_TICK(1);  // staging
         // The three running sums are chains of dependent additions, a dozen instructions per step for ONE wave that has
@@ -1587,63 +1714,21 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
         // (mc_functions.py:24-29 / microcluster.py:147: the additions k_chain makes, in its order).
         // (sixteen steps at a time: the sixteen LDS reads go out together, then the sixteen additions in order, then the
         // sixteen writes - read, add, write per step would wait out one LDS round trip per step)
-#ifndef CC_LONG_UNROLL
-#define CC_LONG_UNROLL 16
-#endif
-#ifndef CC_LONG_PREFETCH
-#define CC_LONG_PREFETCH 0
-#endif
-        auto prefix_chain = [&](double* a, int i, double c) {
-            double* const row = a + (size_t)i * Kp;
-            constexpr int U = CC_LONG_UNROLL;
-            int k = 0;
-#if CC_LONG_PREFETCH
-            double v[U], nx[U];
-            if (n >= U) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = row[u];
+        if (one_wave) {
+            // (round 5) d <= 31: all three in ONE wave - CF1 in lanes 0 .., CF2 in lanes 32 .., W (a row of ones, see the
+            // staging) in lane 63.  The LDS serves a read or write of a wave in the same time whatever the number of
+            // active lanes (16 cycles per 16-byte-per-lane instruction, tools/micro/dep_add.hip), and three waves' requests
+            // queue up behind one another: 43 cycles per step side by side, 29 in one wave.
+            if (tid < 64) {
+                const bool c1 = tid < d, c2 = tid >= 32 && tid < 32 + d, cw = tid == 63;
+                if (c1 || c2 || cw)
+                    prefix_chain(c1 ? xs + (size_t)tid * Kp : c2 ? ys + (size_t)(tid - 32) * Kp : s_w,
+                                 c1 ? s_b1[tid] : c2 ? s_b2[tid - 32] : s_bw, n);
             }
-            for (; k + U <= n; k += U) {
-                const bool more = k + 2 * U <= n;
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) nx[u] = row[k + U + u];
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    c = c + v[u];
-                    v[u] = c;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) row[k + u] = v[u];
-                if (more) {
-#pragma unroll
-                    for (int u = 0; u < U; ++u) v[u] = nx[u];
-                }
-            }
-#else
-            for (; k + U <= n; k += U) {
-                double v[U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) v[u] = row[k + u];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    c = c + v[u];
-                    v[u] = c;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) row[k + u] = v[u];
-            }
-#endif
-            for (; k < n; ++k) {
-                c = c + row[k];
-                row[k] = c;
-            }
-        };
-        if (tid < d) {
-            prefix_chain(xs, tid, s_b1[tid]);
+        } else if (tid < d) {
+            prefix_chain(xs + (size_t)tid * Kp, s_b1[tid], n);
         } else if (tid >= 64 && tid < 64 + d) {
-            prefix_chain(ys, tid - 64, s_b2[tid - 64]);
+            prefix_chain(ys + (size_t)(tid - 64) * Kp, s_b2[tid - 64], n);
         } else if (tid == 128) {
             // (unrolled like the two above: with a loop per step, this chain - one addition per step - was the slowest of
             // the three once theirs had lost their address arithmetic)

@@ -398,6 +398,40 @@ def test_skewed_streams_fuzz(seed):
         centres = np.clip(centres + rng.normal(0.0, 0.001, centres.shape), 0.0, 1.0)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_long_chains_fuzz(seed):
+    """Random streams of few microclusters (2 - 60 populations, every chain of a window hundreds to thousands of members
+    long) at any compiled width - d <= 31: the pipelined layout of the running sums, one wave for all three; d >= 32: three
+    waves, one batch after the other -, spreads from tight to the preferred-dimension threshold (rejected steps all through
+    the chains: replays that start inside a chain), any window size, lookahead off / default / forced, two timepoints with
+    drift and decay.  The sequential kernel is kept out of it (sequential = 1): it would take these streams over."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(9900 + seed)
+    d = int(rng.choice([3, 6, 14, 20, 31, 32, 40, 64]))
+    g = int(rng.integers(2, 60))
+    n = int(rng.choice([30_000, 50_000]))
+    sigma = float(rng.choice([0.004, 0.015, 0.03, 0.046, 0.049]))
+    window = int(rng.choice([4096, 16384, 32768, 49152]))
+    lookahead = int(rng.choice([0, 2, 3]))
+    k = float(rng.choice([1.0, 2.0, 3.0, 4.0]))
+    # the radius threshold a little or well above the populations' own radius (d sigma^2 / k while every dimension is a
+    # preferred one - below delta = 0.05 -, up to d sigma^2 when dimensions flip): absorbed, with rejections at the margin
+    eps = float(np.sqrt(float(rng.choice([1.5, 4.0])) * d * sigma * sigma / k))
+    cfg = scenarios.params_to_config(scenarios.blob_params(
+        n, param_epsilon=eps, param_k=k, param_pi=int(rng.choice([0, max(1, d - 2)])),
+        param_lambda=float(rng.choice([0.0, 0.5])), promote_after=int(rng.choice([3, 10]))))
+    h, o = _hdd(cfg, window=window, lookahead=lookahead, sequential=1), O.OracleHDDStream(cfg)
+    centres = rng.uniform(0.1, 0.9, (g, d))
+    share = rng.dirichlet(np.full(g, 0.7))  # (uneven populations: a few take most of the events)
+    for t in range(2):
+        lab = rng.choice(g, n, p=share)
+        X = np.ascontiguousarray(np.clip(centres[lab] + rng.normal(0.0, sigma, (n, d)), 0.0, 1.0))
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+        centres = np.clip(centres + rng.normal(0.0, 0.002, centres.shape), 0.0, 1.0)
+
+
 def test_windows_with_more_than_32767_creations():
     """k_commit_a ranks a window's creations and promotions in two 16-bit counts packed into one word: a window at
     the largest size (49 152 points) in which EVERY point creates a microcluster (uniform points, a radius threshold

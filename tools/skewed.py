@@ -30,6 +30,6 @@ if __name__ == "__main__":
         h.points_upload(X)
         h.online_run()
         s = h.stats()
-        print("run %d: %.1f ms = %.1f M points/s; rows %d windows %d rounds %d truncated %d; long chains %d, k_chain_long launches %d" % (
-            t, s["run_ms"], n / s["run_ms"] / 1e3, s["rows"], s["windows"], s["rounds"], s["truncated"], s["long_chains"],
-            s["long_chain_launches"]), flush=True)
+        print("run %d: %.1f ms = %.1f M points/s; rows %d windows %d (lookahead %d) rounds %d truncated %d; long chains %d (laid out %d, replayed %d), k_chain_long launches %d" % (
+            t, s["run_ms"], n / s["run_ms"] / 1e3, s["rows"], s["windows"], s["lookahead_windows"], s["rounds"], s["truncated"], s["long_chains"],
+            s["long_prepared"], s["long_replayed"], s["long_chain_launches"]), flush=True)

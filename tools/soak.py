@@ -1,6 +1,7 @@
 """Soak run of the fuzz parity cases beyond the seeds the test suite holds (tests/test_fuzz_parity.py: seeds 0-191;
 tests/test_pruned_scan.py::test_forced_pruning_fuzz: 0-95; tests/test_sequential.py::test_register_resident_sequential_kernel_fuzz:
-0-95; tests/test_hip_parity.py::test_skewed_streams_fuzz: 0-11, here on every eighth seed): the same case generators and
+0-95; tests/test_hip_parity.py::test_skewed_streams_fuzz: 0-11, here on every eighth seed; ::test_long_chains_fuzz: 0-15, here on
+every second seed): the same case generators and
 checks, other seeds.
 Usage: python tools/soak.py <first seed> <last seed> [log file]   (on the GPU box from the repo root; failures and a
 progress line every 25 seeds are printed and appended to the log file - default gpurun_out/soak.log -, exit status 1 if
@@ -36,6 +37,8 @@ def main():
                  ("fuzz la=2", lambda s: F.test_fuzz_case(s, 2)),
                  ("forced pruning", lambda s: P.test_forced_pruning_fuzz(s)),
                  ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s))]
+        if seed % 2 == 0:  # (few microclusters, long chains at every compiled width: tests/test_hip_parity.py holds seeds 0-15)
+            cases.append(("long chains", lambda s: H.test_long_chains_fuzz(s)))
         if seed % 8 == 0:  # (two timepoints of 40-60 k points against 1 100-2 600 microclusters: seconds per case)
             cases.append(("skewed streams", lambda s: H.test_skewed_streams_fuzz(s)))
         for name, fn in cases:
