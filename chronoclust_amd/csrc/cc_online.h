@@ -40,6 +40,8 @@
 // Beside the window pipeline:
 //   k_chain_long      long chains on small tables (few MCs absorb every point): sequential CF additions per
 //                     dimension, radius tests of a batch of steps in parallel, resume after the first rejected one
+//                     <.., PREP>: ahead of k_chain, the running sums of a pcore MC's long chain alone; k_chain's group
+//                     of every member then evaluates that member's step (few long chains: one CU is not enough)
 //   k_seq             no speculation: one wavefront walks the points in order on an LDS image of the table; the host
 //                     switches to it while windows keep being cut short and it measures faster
 //   k_seq_r           the same with the table in registers (d <= 4, a few hundred rows: the reference's own data)
