@@ -898,34 +898,50 @@ __global__ __launch_bounds__(256) void k_claims(const Ctl* __restrict__ ctl, Tab
     const int M0 = ctl->m_rows;
     const int m = blockIdx.x;
     if (m >= M0 || m >= scan_rows) return;
-    __shared__ int s_pos, s_first, s_last;
-    if (threadIdx.x == 0) { s_pos = 0; s_first = CC_IDX_INF; s_last = -1; }
+    // (as in k_claims_heavy below: every thread counts its own claimants, only the first CC_CHAIN_MEMB of them go through
+    // the LDS counter - with a dozen MCs a workgroup finds thousands -, and eight 16-byte loads are in flight per thread)
+    __shared__ int s_pos, s_cnt, s_first, s_last;
+    if (threadIdx.x == 0) { s_pos = 0; s_cnt = 0; s_first = CC_IDX_INF; s_last = -1; }
     __syncthreads();
-    int lmin = CC_IDX_INF, lmax = -1;
+    int lmin = CC_IDX_INF, lmax = -1, mine = 0;
+    volatile int* const pos_now = &s_pos;
     const int4* T4 = reinterpret_cast<const int4*>(T);  // (the buffer is padded to whole 128-entry blocks)
-    for (int base = (int)threadIdx.x * 4; base < B; base += 256 * 4) {
-        const int4 v = T4[base >> 2];
-        const int e[4] = {v.x, v.y, v.z, v.w};
+    constexpr int AHEAD = 8;
+    for (int base0 = (int)threadIdx.x * 4; base0 < B; base0 += 256 * 4 * AHEAD) {
+        int4 v[AHEAD];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = base + c;
-            if (j < B && e[c] == m) {
-                lmin = j < lmin ? j : lmin;
-                lmax = j > lmax ? j : lmax;
-                const int pos = atomicAdd(&s_pos, 1);
-                if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+        for (int q = 0; q < AHEAD; ++q) {
+            const int base = base0 + q * 256 * 4;
+            v[q] = T4[(base < B ? base : 0) >> 2];  // (no branch around the load: claims beyond B are ignored by index below)
+        }
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) {
+            const int base = base0 + q * 256 * 4;
+            const int e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = base + c;
+                if (j < B && e[c] == m) {
+                    lmin = j < lmin ? j : lmin;
+                    lmax = j > lmax ? j : lmax;
+                    ++mine;
+                    if (*pos_now < CC_CHAIN_MEMB) {
+                        const int pos = atomicAdd(&s_pos, 1);
+                        if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+                    }
+                }
             }
         }
     }
-    if (lmax >= 0) { atomicMin(&s_first, lmin); atomicMax(&s_last, lmax); }
+    if (lmax >= 0) { atomicMin(&s_first, lmin); atomicMax(&s_last, lmax); atomicAdd(&s_cnt, mine); }
     __syncthreads();
-    if (threadIdx.x == 0 && s_pos > 0) {
+    if (threadIdx.x == 0 && s_cnt > 0) {
         const unsigned long long stamp = ctl->window_seq * 16ull + (unsigned long long)round;
         const unsigned long long sn = (stamp + 1ull) << 20;
         const size_t wr = (size_t)((round + 1) & 1) * tab.cap + (size_t)m;  // the copy the next round reads
         tab.touch[wr] = sn | (unsigned long long)(0xFFFFF - s_first);
         tab.last[wr] = sn | (unsigned long long)s_last;
-        tab.cnt[m] = ((stamp + 1ull) << 24) | (unsigned long long)s_pos;
+        tab.cnt[m] = ((stamp + 1ull) << 24) | (unsigned long long)s_cnt;
     }
 }
 
@@ -955,19 +971,31 @@ __global__ __launch_bounds__(256) void k_claims_heavy(Ctl* __restrict__ ctl, Tab
     int lmin = CC_IDX_INF, lmax = -1, mine = 0;
     volatile int* const pos_now = &s_pos;
     const int4* T4 = reinterpret_cast<const int4*>(T);  // (the buffer is padded to whole 128-entry blocks)
-    for (int base = (int)threadIdx.x * 4; base < B; base += 256 * 4) {
-        const int4 v = T4[base >> 2];
-        const int e[4] = {v.x, v.y, v.z, v.w};
+    // (eight 16-byte loads in flight per thread: with one load per pass of the loop - the matches' LDS traffic keeps the
+    // compiler from moving the next load up - a window of 32 768 claims was 32 dependent round trips, 29 us per launch)
+    constexpr int AHEAD = 8;
+    for (int base0 = (int)threadIdx.x * 4; base0 < B; base0 += 256 * 4 * AHEAD) {
+        int4 v[AHEAD];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int j = base + c;
-            if (j < B && e[c] == m) {
-                lmin = j < lmin ? j : lmin;
-                lmax = j > lmax ? j : lmax;
-                ++mine;
-                if (*pos_now < CC_CHAIN_MEMB) {
-                    const int pos = atomicAdd(&s_pos, 1);
-                    if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+        for (int q = 0; q < AHEAD; ++q) {
+            const int base = base0 + q * 256 * 4;
+            v[q] = T4[(base < B ? base : 0) >> 2];  // (no branch around the load: claims beyond B are ignored by index below)
+        }
+#pragma unroll
+        for (int q = 0; q < AHEAD; ++q) {
+            const int base = base0 + q * 256 * 4;
+            const int e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = base + c;
+                if (j < B && e[c] == m) {
+                    lmin = j < lmin ? j : lmin;
+                    lmax = j > lmax ? j : lmax;
+                    ++mine;
+                    if (*pos_now < CC_CHAIN_MEMB) {
+                        const int pos = atomicAdd(&s_pos, 1);
+                        if (pos < CC_CHAIN_MEMB) tab.memb[(size_t)m * CC_CHAIN_MEMB + pos] = j;
+                    }
                 }
             }
         }
