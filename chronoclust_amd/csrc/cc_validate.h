@@ -1525,7 +1525,7 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
     const bool scanner = true;
     auto load_claims = [&](int pos) {
         const int i0 = pos + (scanner ? tid : 0) * 4;
-        return (scanner && i0 <= last_j) ? T4[i0 >> 2] : make_int4(-1, -1, -1, -1);
+        return T4[((scanner && i0 <= last_j) ? i0 : 0) >> 2];  // (no branch around the load - it would wait for it -: claims beyond last_j are dropped by index)
     };
     int4 v_next = load_claims(scan_pos);
     // coordinates requested one batch ahead (see phase 2): element e = tid + q NT of the next batch's staging area
@@ -1623,13 +1623,26 @@ __global__ __launch_bounds__(SPLIT ? CC_LONG_THREADS : 256) void k_chain_long(Ct
             auto bwq = [&](const int q) -> double* { return q ? s_w2 : s_w; };
             const int st = tid - 64, NS = NT - 64;  // the staging threads
             const size_t ys_off = (size_t)Kp * d;
+            // (a thread's coordinates - up to four - are requested together, no branch around a load: one round trip per
+            // batch, not one per coordinate; the staging waves are the longer side of a batch otherwise)
+            constexpr int SE = (CC_LONG_XY_DOUBLES / 2 + (CC_LONG_THREADS - 64) - 1) / (CC_LONG_THREADS - 64);
             auto stage = [&](double* const xb, double* const wb, const int first, const int n_) {
-                for (int e = st; e < n_ * d; e += NS) {
-                    const int k = e / d, i = e - k * d;
-                    const double x = X[(cursor + s_queue[(first + k) & (QUEUE - 1)]) * d + i];
-                    xb[at(k, i)] = x;
-                    xb[ys_off + at(k, i)] = x * x;
+                double x[SE];
+                int slot[SE];
+#pragma unroll
+                for (int q = 0; q < SE; ++q) {
+                    const int e = st + q * NS;
+                    const bool valid = e < n_ * d;
+                    const int k = valid ? e / d : 0, i = valid ? e - k * d : 0;
+                    slot[q] = valid ? at(k, i) : -1;
+                    x[q] = X[(cursor + s_queue[(first + k) & (QUEUE - 1)]) * d + i];
                 }
+#pragma unroll
+                for (int q = 0; q < SE; ++q)
+                    if (slot[q] >= 0) {
+                        xb[slot[q]] = x[q];
+                        xb[ys_off + slot[q]] = x[q] * x[q];
+                    }
                 for (int k = st; k < n_; k += NS) wb[k] = 1.0;  // (what the W chain adds per step)
             };
             // (n_after: members the queue holds behind this batch's first one; before: the member before it)
