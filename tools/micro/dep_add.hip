@@ -1,5 +1,6 @@
 // Micro-benchmark: cycles per dependent v_add_f64 of a lone wave, with and without LDS traffic beside it (the running
-// sums of k_chain_long).  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/micro/dep_add.hip -o /tmp/dep_add
+// sums of k_chain_long).  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off tools/micro/dep_add.hip -o build_variants/dep_add   (build_variants/ is
+// git-ignored and travels to the GPU box; gpurun_out/ does not)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
