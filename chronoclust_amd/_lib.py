@@ -42,7 +42,8 @@ class CcStats(C.Structure):
                 ("scan_launches_pruned", C.c_int64), ("scan_ms_pruned", C.c_double), ("scan_pair_dims_pruned", C.c_double),
                 ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64), ("probe_launches", C.c_int64),
                 ("seq_r_points", C.c_int64), ("heavy_launches", C.c_int64),
-                ("scan_lean_launches", C.c_int64), ("long_prepared", C.c_int64), ("long_replayed", C.c_int64)]
+                ("scan_lean_launches", C.c_int64), ("long_prepared", C.c_int64), ("long_replayed", C.c_int64),
+                ("seq_g_points", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8

@@ -168,6 +168,8 @@ struct cc_handle {
     bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
     bool allow_heavy = true;    // CHRONOCLUST_HIP_HEAVY=0: k_decide's atomics also for rows that take a large share of a window
     bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
+    bool allow_seq_g = true;    // CHRONOCLUST_HIP_SEQG=0: no sequential kernel beyond the LDS image (k_seq_g, the table in HBM)
+    DevBuf<int> seq_lists;      // [2][table capacity] k_seq_g: rows of the pcore MCs / of the outlier MCs
     int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
     DevBuf<int> sp_list;        // [window] the round's list of points for the sparse dirty scans
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
@@ -879,6 +881,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_heavy = !(hv && hv[0] == '0');
         const char* sr = getenv("CHRONOCLUST_HIP_SEQR");
         h->allow_seq_r = !(sr && sr[0] == '0');
+        const char* sg = getenv("CHRONOCLUST_HIP_SEQG");
+        h->allow_seq_g = !(sg && sg[0] == '0');
         const char* pb = getenv("CHRONOCLUST_HIP_PROBE");
         h->allow_probe = !(pb && pb[0] == '0');
         const char* gs = getenv("CHRONOCLUST_HIP_GUESS");
@@ -1460,8 +1464,10 @@ struct OnlineRun {
     // points per ms the sequential kernel is assumed to manage before it has been measured in this call (k_seq on its LDS
     // image: ~0.9 us per point; k_seq_r, rows in registers, d <= 4: ~0.6 us)
     bool seq_r_applies() const { return h->allow_seq_r && h->d >= 2 && h->d <= 4; }
-    double seq_rate_guess() const { return seq_r_applies() ? 1500.0 : 700.0; }
-    bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && h->hc.m_rows < seq_cap; }
+    // (k_seq_g, beyond the LDS image: 3-5 us per point at a few hundred rows)
+    bool seq_g_applies() const { return h->allow_seq_g && h->hc.m_rows >= seq_cap; }
+    double seq_rate_guess() const { return seq_g_applies() ? 150.0 : seq_r_applies() ? 1500.0 : 700.0; }
+    bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && (h->hc.m_rows < seq_cap || h->allow_seq_g); }
 
     // lookahead (re)start: the current window is a fresh one (scanned in place), the lookahead scan enqueued next covers
     // the one after it
@@ -1640,7 +1646,19 @@ struct OnlineRun {
     {
         const int chunk = 8192;
         const double t0 = now_ms();
-        {
+        const bool use_g = seq_g_applies();
+        if (use_g) {
+            // the table has outgrown the LDS image: the same loop on the table where it lies, one workgroup
+            const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
+            const int list_cap = (int)std::min<size_t>(h->tab.cap, (size_t)INT_MAX / 2);
+            h->seq_lists.ensure(2 * (size_t)list_cap);
+#define CC_SEQG(F, P) hipLaunchKernelGGL((k_seq_g<F, P>), dim3(1), dim3(CC_SEQG_THREADS), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk, h->seq_lists.p, list_cap)
+            if (f && p2) CC_SEQG(true, true);
+            else if (f) CC_SEQG(true, false);
+            else if (p2) CC_SEQG(false, true);
+            else CC_SEQG(false, false);
+#undef CC_SEQG
+        } else {
             const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
             // d <= 4: the register-resident kernel first; what it cannot hold (Ctl::seq_rest) is left to the LDS kernel
             int follow = 0;
@@ -1675,7 +1693,10 @@ struct OnlineRun {
                     done, h->hc.m_rows, got, dt, (long long)h->hc.stat_seq_clk, (double)h->hc.stat_seq_wall / 1e5);
         if (got >= 1024) seq_rate_last = seq_rate;
         seq_stint_left -= got;
-        const bool full = !seq_possible() || (got < chunk && done < N);
+        if (use_g) h->stats.seq_g_points += got;
+        // (k_seq hands back early when its image is full: k_seq_g continues the stint; k_seq_g itself only when the table's
+        // capacity is used up - the windows' loop makes room)
+        const bool full = !seq_possible() || (got < chunk && done < N && (use_g || !h->allow_seq_g));
         const bool stint_over = seq_mode != 2 && seq_stint_left <= 0;
         if ((full || stint_over) && done < N) {
             // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
@@ -2100,7 +2121,7 @@ struct OnlineRun {
     {
         prepare();
         while (done < N) {
-            ensure_table(h, (size_t)m_known + (size_t)win * batch_max + 1);
+            ensure_table(h, (size_t)m_known + std::max<size_t>((size_t)win * batch_max, seq_on ? 8192 : 0) + 1);
             const Table tab = h->tab.view();
             if (seq_on) {
                 sequential_stint(tab);

@@ -45,6 +45,7 @@
 //   k_seq             no speculation: one wavefront walks the points in order on an LDS image of the table; the host
 //                     switches to it while windows keep being cut short and it measures faster
 //   k_seq_r           the same with the table in registers (d <= 4, a few hundred rows: the reference's own data)
+//   k_seq_g           the same on the table in HBM, one workgroup of 1 024 threads: tables beyond k_seq's LDS image
 //   k_claims_heavy    the claims of a microcluster that takes a large share of a window, gathered by one workgroup
 //                     instead of three same-address atomics per claimant in k_decide (Table::heavy)
 //   k_merge_partials  exact multi-GPU path: a rank's partials per point -> the 64-byte record the ranks all-gather
@@ -225,5 +226,6 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 #include "cc_validate.h"  // k_dseed, k_decide, k_claims, k_chain, k_chain_long, k_commit_a / b
 #include "cc_seq.h"       // the sequential kernel (table in LDS)
 #include "cc_seq_r.h"     // ... and with the table in registers, for d <= 4 and a few hundred rows
+#include "cc_seq_g.h"     // ... and on the table in HBM, one workgroup: tables beyond the LDS image
 #include "cc_relaxed.h"   // relaxed multi-GPU mode
 #include "cc_points.h"    // transposed copy, finiteness check, scaler

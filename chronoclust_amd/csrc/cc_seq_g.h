@@ -1,0 +1,272 @@
+// chronoclust_amd/csrc: k_seq_g, the sequential kernel on the table in HBM.  (included by cc_online.h; one translation unit, cc_api.hip)
+#pragma once
+
+// ---------------------------------------------------------------------------------
+// k_seq_g: the reference's loop taken literally (hddstream.py:220-237) like k_seq, for the streams k_seq is made for -
+// overlapping microclusters, decisions that keep moving, windows cut short after a handful of points - once the table has
+// outgrown k_seq's LDS image (77 rows at d = 20, 25 at d = 64).  There the windowed path commits ~10 points per
+// millisecond whatever is done to its kernels; this kernel takes 3-5 us per point at any table size.
+// One workgroup of 1 024 threads works on the table where it lies:
+//   per point and stage (pcore rows, then outlier rows: hddstream.py:288-343 / 345-395) every thread takes the rows
+//   q = tid, tid + 1 024, ... of the stage's list (row indices in HBM scratch) - projected distance over the dimensions
+//   left to right (mc_functions.py:35-43), with the tentative-add pdim filter when pi < d -, the workgroup's minimum by
+//   (distance, list-order key) goes through DPP row operations and one LDS exchange, the first wave makes the tentative
+//   add of the winner with lane = dimension (microcluster.py:213-233), the ordered radius sum and the test, and commits
+//   the row (and a promotion, hddstream.py:416-430) in place; a point nobody absorbs opens a new row (:434-462).
+// Two barriers per stage: the waves of one workgroup share their CU's vector L1, a barrier orders the first wave's stores
+// before everybody's loads of the next point.  Same arithmetic, same order of operations as k_seq / the oracle.
+// ---------------------------------------------------------------------------------
+
+#define CC_SEQG_THREADS 1024
+#define CC_SEQG_CHUNK_DOUBLES 512  // points staged per chunk: 512 / d of them, at most 64
+
+template <bool FILTER, bool POW2>
+__global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
+                                                            long long* __restrict__ lab_uid, int8_t* __restrict__ lab_path,
+                                                            int n_max, int* __restrict__ lists, int list_cap)
+{
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+    const Par par = cc_load_par(ctl);
+    const int d = par.d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = CC_SEQG_THREADS, NW = CC_SEQG_THREADS / 64;
+    int M = ctl->m_rows;
+    const long long cursor0 = ctl->cursor;
+    const long long left = ctl->n_points - cursor0;
+    const int n = (int)(left < (long long)n_max ? left : (long long)n_max);
+    if (n <= 0) return;
+    int n_pkeys = ctl->n_pkeys, n_okeys = ctl->n_okeys;
+    long long pcore_last_id = ctl->pcore_last_id, outlier_last_id = ctl->outlier_last_id;
+    constexpr bool pow2 = POW2;
+    auto op_of = [&](double pr) { return pow2 ? (pr == 1.0 ? 1.0 : par.inv_k) : pr; };
+    // x / pref through the operand (mc_functions.py:39)
+    auto scaled = [&](double x, double op) { return pow2 ? x * op : (op == 1.0 ? x : x / op); };
+
+    __shared__ __attribute__((aligned(16))) double s_pts[CC_SEQG_CHUNK_DOUBLES];
+    __shared__ double s_term[64];
+    __shared__ double s_cd[NW];          // per wave: best distance, key, row, list position
+    __shared__ int s_ck[NW], s_cr[NW], s_cq[NW];
+    __shared__ int s_np, s_no;
+    __shared__ int s_verdict;            // the first wave's word on the winner: 0 rejected, 1 accepted, 3 accepted and promoted
+    __shared__ int s_tgt[64], s_lpath[64];
+    int* const plist = lists;            // rows of the pcore MCs / of the outlier MCs, any order
+    int* const olist = lists + list_cap;
+
+    if (tid == 0) { s_np = 0; s_no = 0; }
+    __syncthreads();
+    for (int r = tid; r < M; r += NT) {
+        if (tab.kind[r] == CC_KIND_PCORE) plist[atomicAdd(&s_np, 1)] = r;
+        else olist[atomicAdd(&s_no, 1)] = r;
+    }
+    __syncthreads();
+    int n_p = s_np, n_o = s_no;
+
+    const int C = (CC_SEQG_CHUNK_DOUBLES / d) < 64 ? (CC_SEQG_CHUNK_DOUBLES / d) : 64;
+    int done = 0;
+    bool full = false;
+    for (int c0 = 0; c0 < n && !full; c0 += C) {
+        const int cnt = (n - c0) < C ? (n - c0) : C;
+        __syncthreads();  // (the previous chunk's points and targets have been consumed)
+        for (int e = tid; e < cnt * d; e += NT) s_pts[e] = X[(cursor0 + c0) * d + e];
+        __syncthreads();
+        int cdone = 0;
+        for (int jj = 0; jj < cnt; ++jj) {
+            const double* sp = s_pts + jj * d;
+            const double myp = (tid < d) ? sp[tid] : 0.0;  // (first wave) this lane's dimension of the point
+            int target = -1, path = 2;
+            bool promoted = false;
+            // stage 0: _add_to_pcore (hddstream.py:288-343), stage 1: _add_to_outlier (:345-395)
+            for (int stage = 0; stage < 2 && target < 0; ++stage) {
+                const int* list = stage == 0 ? plist : olist;
+                const int n_list = stage == 0 ? n_p : n_o;
+                if (n_list == 0) continue;
+                double bd = CC_INF;
+                int bk = CC_IDX_INF, br = -1, bq = -1;
+#pragma nounroll
+                for (int q = tid; q < n_list; q += NT) {
+                    const int r = list[q];
+                    const double* const rcen = tab.cen + (size_t)r * d;
+                    const double* const rscl = tab.scl + (size_t)r * d;
+                    if (stage == 0 && FILTER) {
+                        // hddstream.py:317-321: pdim of the MC with the point added must be <= pi
+                        const double w1 = tab.w[r] + 1.0;
+                        const double* const rc1 = tab.cf1 + (size_t)r * d;
+                        const double* const rc2 = tab.cf2 + (size_t)r * d;
+                        int ne1 = 0;
+#pragma unroll 4
+                        for (int i = 0; i < d; ++i) {
+                            const double x = sp[i];
+                            const double c1 = rc1[i] + x, c2 = rc2[i] + x * x;
+                            const double var = cc_sqvar(c1, c2, w1);
+                            ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                        }
+                        if (ne1 > par.pi) continue;
+                    }
+                    double acc = 0.0;
+                    int i = 0;
+#pragma nounroll
+                    for (; i + 8 <= d; i += 8) {  // the loads of eight dimensions together, sums left to right
+                        double e[8], o[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { e[u] = rcen[i + u]; o[u] = rscl[i + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            double x = sp[i + u] - e[u];       // mc_functions.py:37
+                            x = x * x;                          // :38
+                            acc = acc + scaled(x, o[u]);        // :39 + :41
+                        }
+                    }
+#pragma nounroll
+                    for (; i < d; ++i) {
+                        double x = sp[i] - rcen[i];
+                        x = x * x;
+                        acc = acc + scaled(x, rscl[i]);
+                    }
+                    const int key = tab.key[r];
+                    if (cand_less(acc, key, bd, bk)) { bd = acc; bk = key; br = r; bq = q; }  // strict <, first in list order wins (:326/:373)
+                }
+                // the wave's minimum by (distance, key) ...
+                {
+                    const double D = cc_wave_min_f64(bd);
+                    const unsigned long long tied = __builtin_amdgcn_ballot_w64(br >= 0 && bd == D);
+                    int wl = 0;
+                    if (tied != 0ull) {
+                        wl = __builtin_ctzll(tied);
+                        if (tied & (tied - 1ull)) {
+                            int best_key = CC_IDX_INF;
+                            for (unsigned long long m = tied; m; m &= m - 1ull) {
+                                const int l = __builtin_ctzll(m);
+                                const int k2 = __builtin_amdgcn_readlane(bk, l);
+                                if (k2 < best_key) { best_key = k2; wl = l; }
+                            }
+                        }
+                    }
+                    const int wr = __builtin_amdgcn_readlane(br, wl), wk = __builtin_amdgcn_readlane(bk, wl);
+                    const int wq = __builtin_amdgcn_readlane(bq, wl);
+                    if (lane == 0) {
+                        s_cd[wave] = (tied != 0ull) ? D : CC_INF;
+                        s_ck[wave] = (tied != 0ull) ? wk : CC_IDX_INF;
+                        s_cr[wave] = (tied != 0ull) ? wr : -1;
+                        s_cq[wave] = wq;
+                    }
+                }
+                __syncthreads();
+                // ... and the workgroup's (every thread looks at the sixteen entries: the same winner everywhere)
+                double D = CC_INF;
+                int K = CC_IDX_INF, R = -1, Q = -1;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) {
+                    const double wd = s_cd[w];
+                    const int wk = s_ck[w], wr = s_cr[w];
+                    if (wr >= 0 && cand_less(wd, wk, D, K)) { D = wd; K = wk; R = wr; Q = s_cq[w]; }
+                }
+                if (R < 0) {  // no (admissible) MC of this kind
+                    __syncthreads();  // (the entries are rewritten by the next stage)
+                    continue;
+                }
+                // tentative add (microcluster.py:213-233) with lane = dimension, then the radius test (:334-337 / :378-381)
+                if (wave == 0) {
+                    const double w1 = tab.w[R] + 1.0;
+                    double c1 = 0.0, c2 = 0.0, qb = 0.0, pr = 1.0, term = 0.0;
+                    if (lane < d) {
+                        c1 = tab.cf1[(size_t)R * d + lane] + myp;
+                        c2 = tab.cf2[(size_t)R * d + lane] + myp * myp;
+                        const double qa = c2 / w1;
+                        qb = c1 / w1;
+                        const double var = qa - qb * qb;
+                        pr = (var <= par.delta_sq) ? par.k : 1.0;
+                        term = scaled(var, op_of(pr));  // mc_functions.py:52: var / pref'
+                    }
+                    double r2 = 0.0;
+#pragma nounroll
+                    for (int i = 0; i < d; ++i) r2 = r2 + cc_readlane_f64(term, i);  // mc_functions.py:54, left to right
+                    int verdict = 0;
+                    if (r2 <= par.eps_sq) {
+                        verdict = 1;
+                        if (lane < d) {
+                            const size_t o = (size_t)R * d + lane;
+                            tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
+                        }
+                        if (lane == 0) tab.w[R] = w1;
+                        if (stage == 1) {
+                            // hddstream.py:416-430
+                            const int gt1 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < d && pr > 1.0));
+                            if (w1 >= par.beta_mu && gt1 <= par.pi) {
+                                verdict = 3;
+                                // out of the outlier list (the last entry takes its place), onto the pcore list
+                                if (lane == 0) {
+                                    tab.kind[R] = CC_KIND_PCORE; tab.key[R] = n_pkeys; tab.id[R] = pcore_last_id;
+                                    olist[Q] = olist[n_o - 1];
+                                    plist[n_p] = R;
+                                }
+                            }
+                        }
+                    }
+                    if (lane == 0) s_verdict = verdict;
+                }
+                __syncthreads();  // the row as committed is what the next point sees
+                const int verdict = s_verdict;
+                if (verdict == 0) continue;
+                target = R;
+                path = stage;
+                if (verdict == 3) {
+                    promoted = true;
+                    n_o -= 1;
+                    n_p += 1;
+                    n_pkeys += 1;
+                    pcore_last_id += 1;
+                }
+            }
+            if (target < 0) {
+                // hddstream.py:434-462: a new outlier MC holding this point (an add to an empty MC)
+                if (M >= (int)tab.cap || n_o >= list_cap) { full = true; break; }  // (the host makes room and comes back)
+                const int R = M;
+                if (wave == 0) {
+                    if (lane < d) {
+                        const double c1 = 0.0 + myp, c2 = 0.0 + myp * myp;
+                        const double qa = c2 / 1.0, qb = c1 / 1.0;
+                        const double var = qa - qb * qb;
+                        const double pr = (var <= par.delta_sq) ? par.k : 1.0;
+                        const size_t o = (size_t)R * d + lane;
+                        tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
+                    }
+                    if (lane == 0) {
+                        tab.w[R] = 0.0 + 1.0; tab.kind[R] = CC_KIND_OUTLIER; tab.key[R] = n_okeys; tab.id[R] = outlier_last_id;
+                        tab.uid[R] = outlier_last_id;
+                        olist[n_o] = R;
+                    }
+                }
+                n_o += 1;
+                n_okeys += 1;
+                outlier_last_id += 1;
+                M += 1;
+                target = R;
+                path = 2;
+                __syncthreads();
+            }
+            if (tid == 0) {
+                s_tgt[jj] = target;
+                s_lpath[jj] = path | (promoted ? 4 : 0);
+            }
+            cdone = jj + 1;
+        }
+        __syncthreads();
+        if (tid < cdone) {
+            lab_uid[cursor0 + c0 + tid] = tab.uid[s_tgt[tid]];  // (a row's creation number never changes)
+            lab_path[cursor0 + c0 + tid] = (int8_t)s_lpath[tid];
+        }
+        done = c0 + cdone;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl->cursor = cursor0 + done;
+        ctl->m_rows = M;
+        ctl->n_pkeys = n_pkeys; ctl->n_okeys = n_okeys;
+        ctl->pcore_last_id = pcore_last_id; ctl->outlier_last_id = outlier_last_id;
+        ctl->window_seq += 1ull;  // stamps and carry marks of earlier windows are history
+        ctl->mode = 0; ctl->car_n = 0;
+        ctl->stat_seq_points += done;
+        ctl->stat_seq_clk += clock64() - clk0;
+        ctl->stat_seq_wall += wall_clock64() - wall0;
+    }
+}

@@ -129,7 +129,8 @@ typedef struct cc_stats {
     int64_t scan_lean_launches;    /* of scan_g_launches: lean - no list of missed points, no seeded chain behind the scan */
     int64_t long_prepared;         /* of long_chains: chains of pcore microclusters whose running sums were laid out ahead of
                                     * k_chain, every step then evaluated by the step's own 32-lane group ...              */
-    int64_t long_replayed;         /* ... and of those, chains replayed from the start because the radius test rejected a step */
+    int64_t long_replayed;         /* ... and of those, chains replayed from the first step the radius test rejected */
+    int64_t seq_g_points;          /* of seq_points: taken by k_seq_g (table in HBM: beyond the sequential kernel's LDS image) */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */

@@ -12,6 +12,7 @@ import scenarios
 import test_fuzz_parity as F
 import test_hip_parity as H
 import test_pruned_scan as PS
+import test_sequential as SQ
 from golden_util import GOLDEN, StateDump, blob_inputs
 
 pytestmark = pytest.mark.gpu
@@ -28,6 +29,7 @@ KNOBS = {
     "sparse dirty scans eager": dict(CHRONOCLUST_HIP_SPARSE=2),  # whenever at most every second point needs them
     "two communicators": dict(CHRONOCLUST_HIP_TWO_COMMS=1),
     "register sequential kernel off": dict(CHRONOCLUST_HIP_SEQR=0),  # k_seq (table in LDS) also for d <= 4
+    "sequential kernel in HBM off": dict(CHRONOCLUST_HIP_SEQG=0),  # beyond k_seq's LDS image: the windowed path only
     "lean guessed scans off": dict(CHRONOCLUST_HIP_LEAN=0),  # k_missed and the seeded chain behind every guessed scan
     "quiet rounds off": dict(CHRONOCLUST_HIP_QUIET=0),  # k_decide re-derives every decision of every validation round
     "heavy rows off": dict(CHRONOCLUST_HIP_HEAVY=0),  # k_decide's atomics also for rows with thousands of claimants
@@ -114,6 +116,13 @@ def test_pruning_fuzz_slice_under_knob(knob, seed):
         h.online_microcluster_maintenance(X, t)
         o.online_microcluster_maintenance(X, t)
         PS._against_oracle(h, o)
+
+
+def test_sequential_kernels_under_knob(knob):
+    """The sequential kernels forced on a stream that outgrows the LDS image (k_seq, then k_seq_g - or, with that knob, the
+    windows again) and chosen by the policy on heavily overlapping microclusters."""
+    SQ.test_blob_golden_sequential("d20")
+    SQ.test_overlapping_microclusters_beyond_the_lds_image(20, 4.0, 2, True)
 
 
 def test_steady_stream_under_knob(knob):

@@ -1,7 +1,8 @@
-"""The one-wavefront sequential kernel (k_seq: the reference's loop taken literally, table in LDS) against the
-goldens of the Python reference and the oracle.  `sequential=2` forces it whenever the table fits its LDS image;
-tables that outgrow the image hand the stream back to the windowed path in the middle of a timepoint, so these
-cases also pin the switch between the two exact paths."""
+"""The sequential kernels (the reference's loop taken literally: k_seq, one wavefront on an LDS image of the table; k_seq_r,
+rows in registers, d <= 4; k_seq_g, one workgroup on the table in HBM once it has outgrown the image) against the goldens
+of the Python reference and the oracle.  `sequential=2` forces them; a table that outgrows the LDS image in the middle
+of a timepoint is handed from k_seq to k_seq_g (CHRONOCLUST_HIP_SEQG=0: back to the windowed path), so these cases also
+pin the switches between the exact paths."""
 import os
 
 import numpy as np
@@ -40,11 +41,17 @@ def test_nocluster_golden_sequential():
 @pytest.mark.parametrize("name", sorted(scenarios.BLOB_SCENARIOS))
 def test_blob_golden_sequential(name):
     """d14_filter: pdim filter + division path; d20 / d40: the table outgrows the LDS image (83 / 42 rows) after a few
-    hundred points and the windowed path finishes the timepoint; d5_norm: stays sequential."""
+    hundred points and k_seq_g finishes the timepoint on the table in HBM (with CHRONOCLUST_HIP_SEQG=0: the windowed
+    path); d5_norm: stays on the image."""
     dump = StateDump(os.path.join(GOLDEN, "blob_%s.npz" % name))
     Xs = blob_inputs(name, dump)
     h = _replay_dump(dump, Xs, scenarios.params_to_config(scenarios.BLOB_SCENARIOS[name]["params"]), sequential=2)
-    assert h.stats()["seq_points"] >= 0
+    s = h.stats()
+    assert s["seq_points"] >= 0
+    if os.environ.get("CHRONOCLUST_HIP_SEQG") == "0":
+        assert s["seq_g_points"] == 0
+    elif name == "d20":  # (100 populations: beyond the image's 77 rows for most of the timepoint)
+        assert s["seq_g_points"] > 0 and s["seq_points"] == len(Xs[-1])  # (the whole last timepoint)
 
 
 @pytest.mark.parametrize("seed", range(0, 192, 2))
@@ -79,6 +86,34 @@ def test_few_microclusters_long_stream_matches_oracle():
             h.online_microcluster_maintenance(X, t)
             _check_against_oracle(h, o)
     assert hs[0].stats()["seq_points"] > 0 and hs[2].stats()["seq_points"] == 0
+
+
+@pytest.mark.parametrize("d,k,pi_off,expect_g", [(20, 4.0, 2, True), (64, 4.0, 2, True), (14, 3.0, 0, False), (40, 2.0, 0, False)])
+def test_overlapping_microclusters_beyond_the_lds_image(d, k, pi_off, expect_g):
+    """Two populations whose spread sits at the preferred-dimension threshold: hundreds of heavily overlapping
+    microclusters, every window cut short after a handful of points - and a table beyond k_seq's LDS image.  With the
+    library's defaults the policy hands the stream to k_seq_g (the table in HBM) by itself; with the pdim filter (pi < d)
+    and without, k a power of two and not."""
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    from oracle import oracle as O
+    n, sigma = 12_000, 0.049
+    rng = np.random.default_rng(1400 + d)
+    cfg = scenarios.params_to_config(scenarios.blob_params(
+        n, param_epsilon=float(np.sqrt(1.5 * d * sigma * sigma / k)), param_k=k, param_pi=(d - pi_off) if pi_off else 0,
+        param_lambda=0.5, promote_after=3))
+    h, o = HDDStream(cfg), O.OracleHDDStream(cfg)
+    centres = rng.uniform(0.2, 0.8, (2, d))
+    tot = 0
+    for t in range(2):
+        X = np.ascontiguousarray(np.clip(centres[rng.integers(0, 2, n)] + rng.normal(0.0, sigma, (n, d)), 0.0, 1.0))
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _check_against_oracle(h, o)
+        tot += h.stats()["seq_g_points"]
+    # (the first two shapes are known to end up there - tools/long_rejects.py, DESIGN.md section 9; the others are whatever
+    # the policy makes of them: parity is the test)
+    if expect_g and os.environ.get("CHRONOCLUST_HIP_SEQG") != "0":
+        assert tot > n, (tot, h.stats())  # (most of the stream)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -36,7 +36,9 @@ def main():
         cases = [("fuzz la=3", lambda s: F.test_fuzz_case(s, 3)),
                  ("fuzz la=2", lambda s: F.test_fuzz_case(s, 2)),
                  ("forced pruning", lambda s: P.test_forced_pruning_fuzz(s)),
-                 ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s))]
+                 ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s)),
+                 # (the general fuzz cases with the sequential kernels forced: k_seq, and k_seq_g beyond its image)
+                 ("fuzz sequential", lambda s: S.test_fuzz_case_sequential(s))]
         if seed % 2 == 0:  # (few microclusters, long chains at every compiled width: tests/test_hip_parity.py holds seeds 0-15)
             cases.append(("long chains", lambda s: H.test_long_chains_fuzz(s)))
         if seed % 8 == 0:  # (two timepoints of 40-60 k points against 1 100-2 600 microclusters: seconds per case)
