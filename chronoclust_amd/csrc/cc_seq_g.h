@@ -5,7 +5,9 @@
 // k_seq_g: the reference's loop taken literally (hddstream.py:220-237) like k_seq, for the streams k_seq is made for -
 // overlapping microclusters, decisions that keep moving, windows cut short after a handful of points - once the table has
 // outgrown k_seq's LDS image (77 rows at d = 20, 25 at d = 64).  There the windowed path commits ~10 points per
-// millisecond whatever is done to its kernels; this kernel takes 3-5 us per point at any table size.
+// millisecond whatever is done to its kernels; this kernel takes 8-18 us per point at 150-450 rows
+// (bound by the latency of its row-major loads - a thread walks its row's dimensions, a wave's loads do not coalesce; the
+// filter's divisions are not what it waits for: a division-free verdict with a rigorous error bound changed nothing).
 // One workgroup of 1 024 threads works on the table where it lies:
 //   per point and stage (pcore rows, then outlier rows: hddstream.py:288-343 / 345-395) every thread takes the rows
 //   q = tid, tid + 1 024, ... of the stage's list (row indices in HBM scratch) - projected distance over the dimensions

@@ -139,8 +139,10 @@ def test_threshold_factor_never_changes_a_result(F):
     cfg = scenarios.params_to_config(scenarios.blob_params(n, param_omicron=0.0002, param_lambda=2))
     sc = dict(seed=77, n=n, d=d, g=g, sigma=0.01, timepoints=3, drift=0.01, churn=0.08)
     Xs = scenarios.make_blob_timepoints(sc, raw=True)
-    plain = _hdd(cfg, 0, window=2048)
-    pruned = _hdd(cfg, 2, F=F, window=2048)
+    # (sequential = 1: at F = 1 so many points are refused that the policy would hand the stream to the sequential kernel -
+    # k_seq_g, the table being beyond k_seq's image - and the last call would hold no pruned scan to speak of)
+    plain = _hdd(cfg, 0, window=2048, sequential=1)
+    pruned = _hdd(cfg, 2, F=F, window=2048, sequential=1)
     for t, X in enumerate(Xs):
         plain.online_microcluster_maintenance(X, t)
         pruned.online_microcluster_maintenance(X, t)
