@@ -170,6 +170,7 @@ struct cc_handle {
     bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
     bool allow_seq_g = true;    // CHRONOCLUST_HIP_SEQG=0: no sequential kernel beyond the LDS image (k_seq_g, the table in HBM)
     DevBuf<int> seq_lists;      // [2][table capacity] k_seq_g: rows of the pcore MCs / of the outlier MCs
+    DevBuf<double> seq_img;     // [4][d][table capacity] k_seq_g: dimension-major copy of the rows it scans (centroid, operand, CF1, CF2)
     int allow_sparse = 128;     // CHRONOCLUST_HIP_SPARSE=0: no sparse dirty scans (the tiles' scans or none); N: while at most one point in N needs them
     DevBuf<int> sp_list;        // [window] the round's list of points for the sparse dirty scans
     bool seq_sticky = false;    // the last call ended on the sequential kernel (k_seq): the next one starts there
@@ -1652,7 +1653,8 @@ struct OnlineRun {
             const bool f = h->hc.filter != 0, p2 = h->hc.pow2 != 0;
             const int list_cap = (int)std::min<size_t>(h->tab.cap, (size_t)INT_MAX / 2);
             h->seq_lists.ensure(2 * (size_t)list_cap);
-#define CC_SEQG(F, P) hipLaunchKernelGGL((k_seq_g<F, P>), dim3(1), dim3(CC_SEQG_THREADS), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk, h->seq_lists.p, list_cap)
+            h->seq_img.ensure(4 * (size_t)list_cap * (size_t)h->d);
+#define CC_SEQG(F, P) hipLaunchKernelGGL((k_seq_g<F, P>), dim3(1), dim3(CC_SEQG_THREADS), 0, sA, h->ctl.p, h->X.p, tab, h->lab_uid.p, h->lab_path.p, chunk, h->seq_lists.p, list_cap, h->seq_img.p)
             if (f && p2) CC_SEQG(true, true);
             else if (f) CC_SEQG(true, false);
             else if (p2) CC_SEQG(false, true);

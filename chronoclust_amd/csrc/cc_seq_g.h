@@ -5,9 +5,9 @@
 // k_seq_g: the reference's loop taken literally (hddstream.py:220-237) like k_seq, for the streams k_seq is made for -
 // overlapping microclusters, decisions that keep moving, windows cut short after a handful of points - once the table has
 // outgrown k_seq's LDS image (77 rows at d = 20, 25 at d = 64).  There the windowed path commits ~10 points per
-// millisecond whatever is done to its kernels; this kernel takes 8-18 us per point at 150-450 rows
-// (bound by the latency of its row-major loads - a thread walks its row's dimensions, a wave's loads do not coalesce; the
-// filter's divisions are not what it waits for: a division-free verdict with a rigorous error bound changed nothing).
+// millisecond whatever is done to its kernels; this kernel takes 8-14 us per point at 150-450 rows
+// (bound by the latency of its loads, not by the filter's divisions: a division-free verdict with a rigorous error bound
+// changed nothing).
 // One workgroup of 1 024 threads works on the table where it lies:
 //   per point and stage (pcore rows, then outlier rows: hddstream.py:288-343 / 345-395) every thread takes the rows
 //   q = tid, tid + 1 024, ... of the stage's list (row indices in HBM scratch) - projected distance over the dimensions
@@ -25,7 +25,8 @@
 template <bool FILTER, bool POW2>
 __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
                                                             long long* __restrict__ lab_uid, int8_t* __restrict__ lab_path,
-                                                            int n_max, int* __restrict__ lists, int list_cap)
+                                                            int n_max, int* __restrict__ lists, int list_cap,
+                                                            double* __restrict__ img)
 {
     const long long clk0 = clock64(), wall0 = wall_clock64();
     const Par par = cc_load_par(ctl);
@@ -53,6 +54,20 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
     __shared__ int s_tgt[64], s_lpath[64];
     int* const plist = lists;            // rows of the pcore MCs / of the outlier MCs, any order
     int* const olist = lists + list_cap;
+    // What the threads scan is a dimension-major copy of the rows' centroids and distance operands (and, for the pdim
+    // filter, of CF1 / CF2): entry (dimension i, row r) at i * list_cap + r, so that the loads of a wave - consecutive rows,
+    // one dimension - coalesce.  (Walking the table's own row-major rows, every load of a wave touched 64 cache lines: 18 us
+    // per point at d = 64 and 159 rows, 14 this way; at d = 20 it makes no difference.)  The first wave keeps it in line with every row it commits.
+    const size_t plane = (size_t)d * (size_t)list_cap;
+    double* const icen = img;
+    double* const iscl = img + plane;
+    double* const ic1 = img + 2 * plane;
+    double* const ic2 = img + 3 * plane;
+    for (size_t e = tid; e < (size_t)M * d; e += NT) {
+        const size_t r = e / d, i = e - r * d;
+        icen[i * list_cap + r] = tab.cen[e]; iscl[i * list_cap + r] = tab.scl[e];
+        if (FILTER) { ic1[i * list_cap + r] = tab.cf1[e]; ic2[i * list_cap + r] = tab.cf2[e]; }
+    }
 
     if (tid == 0) { s_np = 0; s_no = 0; }
     __syncthreads();
@@ -87,19 +102,31 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
 #pragma nounroll
                 for (int q = tid; q < n_list; q += NT) {
                     const int r = list[q];
-                    const double* const rcen = tab.cen + (size_t)r * d;
-                    const double* const rscl = tab.scl + (size_t)r * d;
+                    const double* const rcen = icen + r;
+                    const double* const rscl = iscl + r;
                     if (stage == 0 && FILTER) {
                         // hddstream.py:317-321: pdim of the MC with the point added must be <= pi
                         const double w1 = tab.w[r] + 1.0;
-                        const double* const rc1 = tab.cf1 + (size_t)r * d;
-                        const double* const rc2 = tab.cf2 + (size_t)r * d;
+                        const double* const rc1 = ic1 + r;
+                        const double* const rc2 = ic2 + r;
                         int ne1 = 0;
-#pragma unroll 4
-                        for (int i = 0; i < d; ++i) {
+                        int i = 0;
+#pragma nounroll
+                        for (; i + 8 <= d; i += 8) {
+                            double a1[8], a2[8];
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { a1[u] = rc1[(size_t)(i + u) * list_cap]; a2[u] = rc2[(size_t)(i + u) * list_cap]; }
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) {
+                                const double x = sp[i + u];
+                                const double var = cc_sqvar(a1[u] + x, a2[u] + x * x, w1);
+                                ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                            }
+                        }
+#pragma nounroll
+                        for (; i < d; ++i) {
                             const double x = sp[i];
-                            const double c1 = rc1[i] + x, c2 = rc2[i] + x * x;
-                            const double var = cc_sqvar(c1, c2, w1);
+                            const double var = cc_sqvar(rc1[(size_t)i * list_cap] + x, rc2[(size_t)i * list_cap] + x * x, w1);
                             ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
                         }
                         if (ne1 > par.pi) continue;
@@ -110,7 +137,7 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                     for (; i + 8 <= d; i += 8) {  // the loads of eight dimensions together, sums left to right
                         double e[8], o[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { e[u] = rcen[i + u]; o[u] = rscl[i + u]; }
+                        for (int u = 0; u < 8; ++u) { e[u] = rcen[(size_t)(i + u) * list_cap]; o[u] = rscl[(size_t)(i + u) * list_cap]; }
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             double x = sp[i + u] - e[u];       // mc_functions.py:37
@@ -120,9 +147,9 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                     }
 #pragma nounroll
                     for (; i < d; ++i) {
-                        double x = sp[i] - rcen[i];
+                        double x = sp[i] - rcen[(size_t)i * list_cap];
                         x = x * x;
-                        acc = acc + scaled(x, rscl[i]);
+                        acc = acc + scaled(x, rscl[(size_t)i * list_cap]);
                     }
                     const int key = tab.key[r];
                     if (cand_less(acc, key, bd, bk)) { bd = acc; bk = key; br = r; bq = q; }  // strict <, first in list order wins (:326/:373)
@@ -188,6 +215,9 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                         if (lane < d) {
                             const size_t o = (size_t)R * d + lane;
                             tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
+                            const size_t io = (size_t)lane * list_cap + R;
+                            icen[io] = qb; iscl[io] = op_of(pr);
+                            if (FILTER) { ic1[io] = c1; ic2[io] = c2; }
                         }
                         if (lane == 0) tab.w[R] = w1;
                         if (stage == 1) {
@@ -231,6 +261,9 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                         const double pr = (var <= par.delta_sq) ? par.k : 1.0;
                         const size_t o = (size_t)R * d + lane;
                         tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
+                        const size_t io = (size_t)lane * list_cap + R;
+                        icen[io] = qb; iscl[io] = op_of(pr);
+                        if (FILTER) { ic1[io] = c1; ic2[io] = c2; }
                     }
                     if (lane == 0) {
                         tab.w[R] = 0.0 + 1.0; tab.kind[R] = CC_KIND_OUTLIER; tab.key[R] = n_okeys; tab.id[R] = outlier_last_id;
