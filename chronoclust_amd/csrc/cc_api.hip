@@ -1468,7 +1468,9 @@ struct OnlineRun {
     // (k_seq_g, beyond the LDS image: 3-5 us per point at a few hundred rows)
     bool seq_g_applies() const { return h->allow_seq_g && h->hc.m_rows >= seq_cap; }
     double seq_rate_guess() const { return seq_g_applies() ? 150.0 : seq_r_applies() ? 1500.0 : 700.0; }
-    bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && (h->hc.m_rows < seq_cap || h->allow_seq_g); }
+    // (never in a group - every rank has to take the same path, and wall-clock measurements differ -, never with no_create:
+    // the sequential kernels know the reference's loop only)
+    bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && !no_create && (h->hc.m_rows < seq_cap || h->allow_seq_g); }
 
     // lookahead (re)start: the current window is a fresh one (scanned in place), the lookahead scan enqueued next covers
     // the one after it
