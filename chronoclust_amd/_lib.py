@@ -8,7 +8,7 @@ import numpy as np
 from . import build as _build
 
 PCORE, OUTLIER = 0, 1
-MAX_DIM = 64
+MAX_DIM = 128
 
 _ERRORS = {-1: "no HIP device / HIP runtime error", -2: "bad argument", -3: "non-finite input", -4: "out of memory",
            -5: "internal error", -6: "exchange between ranks failed"}

@@ -1466,6 +1466,9 @@ struct OnlineRun {
     // image: ~0.9 us per point; k_seq_r, rows in registers, d <= 4: ~0.6 us)
     bool seq_r_applies() const { return h->allow_seq_r && h->d >= 2 && h->d <= 4; }
     // (k_seq_g, beyond the LDS image: 3-5 us per point at a few hundred rows)
+    // d > CC_WINDOW_MAX_DIM: the windowed path (two dimensions per lane of a 32-lane group, 2 d registers per point in the scans)
+    // does not take such points; k_seq_g does, from the first one on
+    bool wide() const { return h->d > CC_WINDOW_MAX_DIM; }
     bool seq_g_applies() const { return h->allow_seq_g && h->hc.m_rows >= seq_cap; }
     double seq_rate_guess() const { return seq_g_applies() ? 150.0 : seq_r_applies() ? 1500.0 : 700.0; }
     // (never in a group - every rank has to take the same path, and wall-clock measurements differ -, never with no_create:
@@ -1626,8 +1629,8 @@ struct OnlineRun {
         // LDS image and either the caller forces it or (default) the windows keep being cut short and it measures
         // faster than they do.  Never inside a multi-GPU group (every rank has to take the same path, and wall-clock
         // measurements differ between ranks).
-        seq_mode = h->tun.sequential;
-        seq_cap = cc_seq_cap_rows(h->d);
+        seq_mode = wide() ? 2 : h->tun.sequential;
+        seq_cap = wide() ? 0 : cc_seq_cap_rows(h->d);
         seq_on = seq_possible() && (seq_mode == 2 || h->seq_sticky);
         // default policy: the sequential kernel takes over after two batches in a row whose windows were cut short
         // at a few hundred points; it works in stints (32 k points, doubling), after each of which one batch of
@@ -1702,7 +1705,7 @@ struct OnlineRun {
         // capacity is used up - the windows' loop makes room)
         const bool full = !seq_possible() || (got < chunk && done < N && (use_g || !h->allow_seq_g));
         const bool stint_over = seq_mode != 2 && seq_stint_left <= 0;
-        if ((full || stint_over) && done < N) {
+        if ((full || stint_over) && done < N && !wide()) {
             // back to the windows: a fresh window at the cursor, no carry set, no pending lookahead scan
             seq_on = false;
             seq_probe = stint_over && !full;
@@ -2148,6 +2151,9 @@ struct OnlineRun {
 int online_range(cc_handle* h, long long range_a, long long range_e, bool no_create, bool resume)
 {
     if (range_e <= range_a) return (int)CC_OK;
+    if (h->d > CC_WINDOW_MAX_DIM && (h->comm.active() || no_create || !h->allow_seq_g))
+        return fail(h, CC_ERR_BAD_ARG, "more than " + std::to_string(CC_WINDOW_MAX_DIM) + " dimensions: the online phase runs on the sequential "
+                    "workgroup kernel (k_seq_g) only - not in a multi-GPU group, not with CHRONOCLUST_HIP_SEQG=0");
     if (h->d == 0) return fail(h, CC_ERR_BAD_ARG, "no points uploaded");
     OnlineRun run(h, range_a, range_e, no_create, resume);
     return run.run();
@@ -2438,7 +2444,8 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                 else if (d <= 16) CC_EPS(16);
                 else if (d <= 24) CC_EPS(24);
                 else if (d <= 40) CC_EPS(40);
-                else CC_EPS(64);
+                else if (d <= 64) CC_EPS(64);
+                else CC_EPS(128);
 #undef CC_EPS
             }
             hipLaunchKernelGGL(k_subspace_pref, dim3((unsigned)(((size_t)my_rows * d + 255) / 256)), dim3(256), 0, h->stream,
@@ -2655,7 +2662,8 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
             else if (d <= 16) CC_ASSOC(16);
             else if (d <= 24) CC_ASSOC(24);
             else if (d <= 40) CC_ASSOC(40);
-            else CC_ASSOC(64);
+            else if (d <= 64) CC_ASSOC(64);
+            else CC_ASSOC(128);
 #undef CC_ASSOC
             hipLaunchKernelGGL(k_assoc_merge, dim3((c_hi - c_lo + 255) / 256), dim3(256), 0, h->stream, h->a_pdist.p,
                                h->a_pidx.p, S, mc, c_lo, c_hi, h->a_idx.p, h->a_dist.p);

@@ -20,7 +20,7 @@
 // ---------------------------------------------------------------------------------
 
 #define CC_SEQG_THREADS 1024
-#define CC_SEQG_CHUNK_DOUBLES 512  // points staged per chunk: 512 / d of them, at most 64
+#define CC_SEQG_CHUNK_DOUBLES 512  // points staged per chunk: 512 / d of them (four at d = 128), at most 64
 
 template <bool FILTER, bool POW2>
 __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl, const double* __restrict__ X, Table tab,
@@ -46,7 +46,6 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
     auto scaled = [&](double x, double op) { return pow2 ? x * op : (op == 1.0 ? x : x / op); };
 
     __shared__ __attribute__((aligned(16))) double s_pts[CC_SEQG_CHUNK_DOUBLES];
-    __shared__ double s_term[64];
     __shared__ double s_cd[NW];          // per wave: best distance, key, row, list position
     __shared__ int s_ck[NW], s_cr[NW], s_cq[NW];
     __shared__ int s_np, s_no;
@@ -89,7 +88,8 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
         int cdone = 0;
         for (int jj = 0; jj < cnt; ++jj) {
             const double* sp = s_pts + jj * d;
-            const double myp = (tid < d) ? sp[tid] : 0.0;  // (first wave) this lane's dimension of the point
+            // (first wave) this lane's dimensions of the point: lane and lane + 64 (d <= 128 = CC_MAX_DIM)
+            const double myp[2] = {(tid < d) ? sp[tid] : 0.0, (tid < 64 && tid + 64 < d) ? sp[tid + 64] : 0.0};
             int target = -1, path = 2;
             bool promoted = false;
             // stage 0: _add_to_pcore (hddstream.py:288-343), stage 1: _add_to_outlier (:345-395)
@@ -196,33 +196,42 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                 // tentative add (microcluster.py:213-233) with lane = dimension, then the radius test (:334-337 / :378-381)
                 if (wave == 0) {
                     const double w1 = tab.w[R] + 1.0;
-                    double c1 = 0.0, c2 = 0.0, qb = 0.0, pr = 1.0, term = 0.0;
-                    if (lane < d) {
-                        c1 = tab.cf1[(size_t)R * d + lane] + myp;
-                        c2 = tab.cf2[(size_t)R * d + lane] + myp * myp;
-                        const double qa = c2 / w1;
-                        qb = c1 / w1;
-                        const double var = qa - qb * qb;
-                        pr = (var <= par.delta_sq) ? par.k : 1.0;
-                        term = scaled(var, op_of(pr));  // mc_functions.py:52: var / pref'
+                    double c1[2] = {0.0, 0.0}, c2[2] = {0.0, 0.0}, qb[2] = {0.0, 0.0}, pr[2] = {1.0, 1.0}, term[2] = {0.0, 0.0};
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int i = lane + 64 * hh;
+                        if (i < d) {
+                            c1[hh] = tab.cf1[(size_t)R * d + i] + myp[hh];
+                            c2[hh] = tab.cf2[(size_t)R * d + i] + myp[hh] * myp[hh];
+                            const double qa = c2[hh] / w1;
+                            qb[hh] = c1[hh] / w1;
+                            const double var = qa - qb[hh] * qb[hh];
+                            pr[hh] = (var <= par.delta_sq) ? par.k : 1.0;
+                            term[hh] = scaled(var, op_of(pr[hh]));  // mc_functions.py:52: var / pref'
+                        }
                     }
                     double r2 = 0.0;
 #pragma nounroll
-                    for (int i = 0; i < d; ++i) r2 = r2 + cc_readlane_f64(term, i);  // mc_functions.py:54, left to right
+                    for (int i = 0; i < d; ++i) r2 = r2 + cc_readlane_f64(i < 64 ? term[0] : term[1], i & 63);  // mc_functions.py:54, left to right
                     int verdict = 0;
                     if (r2 <= par.eps_sq) {
                         verdict = 1;
-                        if (lane < d) {
-                            const size_t o = (size_t)R * d + lane;
-                            tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
-                            const size_t io = (size_t)lane * list_cap + R;
-                            icen[io] = qb; iscl[io] = op_of(pr);
-                            if (FILTER) { ic1[io] = c1; ic2[io] = c2; }
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            const int i = lane + 64 * hh;
+                            if (i < d) {
+                                const size_t o = (size_t)R * d + i;
+                                tab.cf1[o] = c1[hh]; tab.cf2[o] = c2[hh]; tab.cen[o] = qb[hh]; tab.pref[o] = pr[hh]; tab.scl[o] = op_of(pr[hh]);
+                                const size_t io = (size_t)i * list_cap + R;
+                                icen[io] = qb[hh]; iscl[io] = op_of(pr[hh]);
+                                if (FILTER) { ic1[io] = c1[hh]; ic2[io] = c2[hh]; }
+                            }
                         }
                         if (lane == 0) tab.w[R] = w1;
                         if (stage == 1) {
                             // hddstream.py:416-430
-                            const int gt1 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < d && pr > 1.0));
+                            const int gt1 = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < d && pr[0] > 1.0)) +
+                                            __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane + 64 < d && pr[1] > 1.0));
                             if (w1 >= par.beta_mu && gt1 <= par.pi) {
                                 verdict = 3;
                                 // out of the outlier list (the last entry takes its place), onto the pcore list
@@ -254,16 +263,20 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                 if (M >= (int)tab.cap || n_o >= list_cap) { full = true; break; }  // (the host makes room and comes back)
                 const int R = M;
                 if (wave == 0) {
-                    if (lane < d) {
-                        const double c1 = 0.0 + myp, c2 = 0.0 + myp * myp;
-                        const double qa = c2 / 1.0, qb = c1 / 1.0;
-                        const double var = qa - qb * qb;
-                        const double pr = (var <= par.delta_sq) ? par.k : 1.0;
-                        const size_t o = (size_t)R * d + lane;
-                        tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
-                        const size_t io = (size_t)lane * list_cap + R;
-                        icen[io] = qb; iscl[io] = op_of(pr);
-                        if (FILTER) { ic1[io] = c1; ic2[io] = c2; }
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int i = lane + 64 * hh;
+                        if (i < d) {
+                            const double c1 = 0.0 + myp[hh], c2 = 0.0 + myp[hh] * myp[hh];
+                            const double qa = c2 / 1.0, qb = c1 / 1.0;
+                            const double var = qa - qb * qb;
+                            const double pr = (var <= par.delta_sq) ? par.k : 1.0;
+                            const size_t o = (size_t)R * d + i;
+                            tab.cf1[o] = c1; tab.cf2[o] = c2; tab.cen[o] = qb; tab.pref[o] = pr; tab.scl[o] = op_of(pr);
+                            const size_t io = (size_t)i * list_cap + R;
+                            icen[io] = qb; iscl[io] = op_of(pr);
+                            if (FILTER) { ic1[io] = c1; ic2[io] = c2; }
+                        }
                     }
                     if (lane == 0) {
                         tab.w[R] = 0.0 + 1.0; tab.kind[R] = CC_KIND_OUTLIER; tab.key[R] = n_okeys; tab.id[R] = outlier_last_id;

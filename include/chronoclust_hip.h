@@ -54,7 +54,13 @@ enum cc_status {
 
 enum cc_kind { CC_PCORE = 0, CC_OUTLIER = 1 };
 
-#define CC_MAX_DIM 64
+/* Dimensions of a point (hddstream.py:107-114 takes any).  Up to CC_WINDOW_MAX_DIM the online phase runs on the windowed,
+ * speculative path (and the sequential kernels where the policy prefers them); from there to CC_MAX_DIM on the sequential
+ * workgroup kernel alone (k_seq_g: the reference's loop on the table in HBM, ~10-20 us per point) - exact like every path,
+ * one GPU only (cc_online* in a multi-GPU group returns CC_ERR_BAD_ARG for such data).  The offline phase and the trackers
+ * take any d <= CC_MAX_DIM. */
+#define CC_MAX_DIM 128
+#define CC_WINDOW_MAX_DIM 64
 
 typedef struct cc_params {
     double eps_sq;
