@@ -21,7 +21,7 @@ Outputs
   nocluster/    the 10-row subset inputs + what the reference writes for them
   tracker_scenarios.json   every scenario of the reference's two tracking
                 unit-test files, recorded as call sequences + observed ids
-  blob_*.npz    d = 20 / 14 / 40 synthetic scenarios (inputs regenerated from
+  blob_*.npz    d = 20 / 14 / 40 / 5 / 80 synthetic scenarios (inputs regenerated from
                 the seed by tests/scenarios.py) with the reference's per-point
                 labels, MC tables, clusters and result.csv text
 """
@@ -338,7 +338,7 @@ def gen_tracker():
 
 
 # --------------------------------------------------------------------------
-# blob scenarios (BASELINE.md section 4 generator), d = 20 / 14 / 40
+# blob scenarios (BASELINE.md section 4 generator), d = 20 / 14 / 40 / 5 / 80
 # --------------------------------------------------------------------------
 
 def gen_blobs(names=None):

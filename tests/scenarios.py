@@ -44,6 +44,9 @@ BLOB_SCENARIOS = {
     # d = 40 (stress shape)
     "d40": dict(seed=11, n=3000, d=40, g=30, sigma=0.01, timepoints=2, drift=0.01, churn=0.1,
                 params=blob_params(3000)),
+    # d = 80: beyond the windowed path's 64 dimensions (k_seq_g clusters these points; d = 128 instantiations offline)
+    "d80": dict(seed=13, n=2000, d=80, g=15, sigma=0.01, timepoints=3, drift=0.01, churn=0.1,
+                params=blob_params(2000, param_epsilon=0.08, param_omicron=0.0002, param_lambda=1.5)),
     # normalise_data=True end to end (scaler arithmetic on the path), overlapping blobs
     "d5_norm": dict(seed=3, n=4000, d=5, g=12, sigma=0.03, timepoints=3, drift=0.02, churn=0.1, normalise=True,
                     scale=50.0,

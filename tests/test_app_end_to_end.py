@@ -114,7 +114,7 @@ def test_nocluster_integration_golden(tmp_path):
 
 @pytest.mark.parametrize("name", sorted(scenarios.BLOB_SCENARIOS))
 def test_blob_end_to_end(name, tmp_path):
-    """d = 20 / 14 / 40 / 5 scenarios through app.run: result.csv bytes (lineage + association strings, pcore id
+    """d = 20 / 14 / 40 / 5 / 80 scenarios through app.run: result.csv bytes (lineage + association strings, pcore id
     set order, rounded weights and centroids) and per-point cluster ids of the recorded reference run."""
     from chronoclust_amd import app
     sc = scenarios.BLOB_SCENARIOS[name]
