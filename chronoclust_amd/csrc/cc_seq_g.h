@@ -16,7 +16,7 @@
 //   add of the winner with lane = dimension (microcluster.py:213-233), the ordered radius sum and the test, and commits
 //   the row (and a promotion, hddstream.py:416-430) in place; a point nobody absorbs opens a new row (:434-462).
 // Two barriers per stage: the waves of one workgroup share their CU's vector L1, a barrier orders the first wave's stores
-// before everybody's loads of the next point.  Same arithmetic, same order of operations as k_seq / the oracle.
+// before everybody's loads of the next point.  Same arithmetic, same order of operations as k_seq.
 // ---------------------------------------------------------------------------------
 
 #define CC_SEQG_THREADS 1024
