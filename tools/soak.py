@@ -31,6 +31,7 @@ def main():
     import test_pruned_scan as P
     import test_sequential as S
     import test_hip_parity as H
+    import test_wide_dims as W
     bad, n, t0 = [], 0, time.time()
     for seed in range(a, b):
         cases = [("fuzz la=3", lambda s: F.test_fuzz_case(s, 3)),
@@ -39,6 +40,7 @@ def main():
                  ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s)),
                  # (the general fuzz cases with the sequential kernels forced: k_seq, and k_seq_g beyond its image)
                  ("fuzz sequential", lambda s: S.test_fuzz_case_sequential(s))]
+        cases.append(("wide streams", lambda s: W.test_wide_streams_fuzz(s)))  # (d = 65 .. 128 on k_seq_g; the suite holds seeds 0-9)
         if seed % 2 == 0:  # (few microclusters, long chains at every compiled width: tests/test_hip_parity.py holds seeds 0-15)
             cases.append(("long chains", lambda s: H.test_long_chains_fuzz(s)))
         if seed % 8 == 0:  # (two timepoints of 40-60 k points against 1 100-2 600 microclusters: seconds per case)
