@@ -2078,6 +2078,10 @@ struct OnlineRun {
         h->stats.sharded_windows += sharded_windows;
         h->stats.seq_points += h->hc.stat_seq_points;
         h->stats.seq_r_points += h->hc.stat_seq_r_points;
+#ifdef CC_SEQG_TIMERS
+        fprintf(stderr, "[cc] k_seq_g (shader cycles, thread 0): scan %llu minimum %llu add %llu barrier %llu rest %llu chunk %llu | points %llu\n",
+                h->hc.dbg_long[0], h->hc.dbg_long[1], h->hc.dbg_long[2], h->hc.dbg_long[3], h->hc.dbg_long[4], h->hc.dbg_long[5], h->hc.dbg_long[7]);
+#endif
 #ifdef CC_LONG_TIMERS
         fprintf(stderr, "[cc] k_chain_long, workgroup 0 (shader cycles): collect %llu stage %llu chains %llu step-dim %llu step %llu rows %llu state %llu | batches %llu\n",
                 h->hc.dbg_long[0], h->hc.dbg_long[1], h->hc.dbg_long[2], h->hc.dbg_long[3], h->hc.dbg_long[4], h->hc.dbg_long[5], h->hc.dbg_long[6], h->hc.dbg_long[7]);

@@ -76,6 +76,15 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
     }
     __syncthreads();
     int n_p = s_np, n_o = s_no;
+#ifdef CC_SEQG_TIMERS
+    // build variant (-DCC_SEQG_TIMERS -DCC_LONG_TIMERS: the latter declares Ctl::dbg_long): shader cycles per phase, thread 0,
+    // printed at the end of a call
+    long long tq_prev = clock64();
+    unsigned long long tq_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CC_TQ(i) do { const long long now_ = clock64(); tq_acc[i] += (unsigned long long)(now_ - tq_prev); tq_prev = now_; } while (0)
+#else
+#define CC_TQ(i) do { } while (0)
+#endif
 
     const int C = (CC_SEQG_CHUNK_DOUBLES / d) < 64 ? (CC_SEQG_CHUNK_DOUBLES / d) : 64;
     int done = 0;
@@ -85,6 +94,7 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
         __syncthreads();  // (the previous chunk's points and targets have been consumed)
         for (int e = tid; e < cnt * d; e += NT) s_pts[e] = X[(cursor0 + c0) * d + e];
         __syncthreads();
+        CC_TQ(5);  // chunk of points
         int cdone = 0;
         for (int jj = 0; jj < cnt; ++jj) {
             const double* sp = s_pts + jj * d;
@@ -104,56 +114,106 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                     const int r = list[q];
                     const double* const rcen = icen + r;
                     const double* const rscl = iscl + r;
+                    double acc = 0.0;
+                    // (a pass over the dimensions is a chain of round trips to L2, ~1 700 cycles each, whatever is computed in
+                    // between - the filter's divisions included: as many loads per trip as the registers take)
                     if (stage == 0 && FILTER) {
-                        // hddstream.py:317-321: pdim of the MC with the point added must be <= pi
+                        // hddstream.py:317-321: pdim of the MC with the point added must be <= pi - evaluated beside the
+                        // distance, whose loads share the trip (a row the filter drops has its distance computed in vain)
+                        // Only the verdict "var <= delta^2" per dimension is needed, and the reference's var = fl(fl(c2 / w) -
+                        // fl(fl(c1 / w)^2)) costs two IEEE divisions - ~70 instructions, 280 cycles of a wave's issue - per
+                        // dimension and row: three quarters of the scan at d = 128.  With one reciprocal per row,
+                        // v = c2 rw - (c1 rw)^2 differs from it by at most 10 u (|A| + B^2), u = 2^-53 (the reference's expression:
+                        // within 2 u |A| + 4 u B^2 of the exact A - B^2; v: within 3 u |A| + 6 u B^2): whenever v is further than
+                        // 4e-15 (|a| + b^2) from delta^2 the verdict is certain; a wave in which some lane is not certain (or
+                        // sees something that is not finite) evaluates the reference's own expression for those dimensions.
                         const double w1 = tab.w[r] + 1.0;
+                        const double rw = 1.0 / w1;
                         const double* const rc1 = ic1 + r;
                         const double* const rc2 = ic2 + r;
                         int ne1 = 0;
                         int i = 0;
 #pragma nounroll
                         for (; i + 8 <= d; i += 8) {
-                            double a1[8], a2[8];
+                            double a1[8], a2[8], e[8], o[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) { a1[u] = rc1[(size_t)(i + u) * list_cap]; a2[u] = rc2[(size_t)(i + u) * list_cap]; }
+                            for (int u = 0; u < 8; ++u) {
+                                const size_t at = (size_t)(i + u) * list_cap;
+                                a1[u] = rc1[at]; a2[u] = rc2[at]; e[u] = rcen[at]; o[u] = rscl[at];
+                            }
+                            unsigned unsure = 0u;
 #pragma unroll
                             for (int u = 0; u < 8; ++u) {
                                 const double x = sp[i + u];
-                                const double var = cc_sqvar(a1[u] + x, a2[u] + x * x, w1);
-                                ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                                a1[u] = a1[u] + x; a2[u] = a2[u] + x * x;  // (the sums the reference divides)
+                                const double a = a2[u] * rw, b = a1[u] * rw;
+                                const double bb = b * b;
+                                const double v = a - bb;
+                                const double slack = 4e-15 * (fabs(a) + bb);
+                                const bool yes = par.delta_sq - v > slack, no = v - par.delta_sq > slack;
+                                ne1 += (yes && par.k != 1.0) ? 1 : 0;
+                                unsure |= (!yes && !no) ? (1u << u) : 0u;
+                                double y = x - e[u];               // mc_functions.py:37
+                                y = y * y;                          // :38
+                                acc = acc + scaled(y, o[u]);        // :39 + :41
+                            }
+                            if (__builtin_amdgcn_ballot_w64(unsure != 0u) != 0ull) {
+#pragma unroll
+                                for (int u = 0; u < 8; ++u)
+                                    if ((unsure >> u) & 1u) {
+                                        const double var = cc_sqvar(a1[u], a2[u], w1);
+                                        ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                                    }
                             }
                         }
 #pragma nounroll
                         for (; i < d; ++i) {
+                            const size_t at = (size_t)i * list_cap;
                             const double x = sp[i];
-                            const double var = cc_sqvar(rc1[(size_t)i * list_cap] + x, rc2[(size_t)i * list_cap] + x * x, w1);
+                            const double var = cc_sqvar(rc1[at] + x, rc2[at] + x * x, w1);
                             ne1 += (((var <= par.delta_sq) ? par.k : 1.0) != 1.0) ? 1 : 0;
+                            double y = x - rcen[at];
+                            y = y * y;
+                            acc = acc + scaled(y, rscl[at]);
                         }
                         if (ne1 > par.pi) continue;
-                    }
-                    double acc = 0.0;
-                    int i = 0;
+                    } else {
+                        int i = 0;
 #pragma nounroll
-                    for (; i + 8 <= d; i += 8) {  // the loads of eight dimensions together, sums left to right
-                        double e[8], o[8];
+                        for (; i + 16 <= d; i += 16) {  // the loads of sixteen dimensions together, sums left to right
+                            double e[16], o[16];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) { e[u] = rcen[(size_t)(i + u) * list_cap]; o[u] = rscl[(size_t)(i + u) * list_cap]; }
+                            for (int u = 0; u < 16; ++u) { e[u] = rcen[(size_t)(i + u) * list_cap]; o[u] = rscl[(size_t)(i + u) * list_cap]; }
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            double x = sp[i + u] - e[u];       // mc_functions.py:37
-                            x = x * x;                          // :38
-                            acc = acc + scaled(x, o[u]);        // :39 + :41
+                            for (int u = 0; u < 16; ++u) {
+                                double x = sp[i + u] - e[u];       // mc_functions.py:37
+                                x = x * x;                          // :38
+                                acc = acc + scaled(x, o[u]);        // :39 + :41
+                            }
                         }
-                    }
 #pragma nounroll
-                    for (; i < d; ++i) {
-                        double x = sp[i] - rcen[(size_t)i * list_cap];
-                        x = x * x;
-                        acc = acc + scaled(x, rscl[(size_t)i * list_cap]);
+                        for (; i + 4 <= d; i += 4) {
+                            double e[4], o[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { e[u] = rcen[(size_t)(i + u) * list_cap]; o[u] = rscl[(size_t)(i + u) * list_cap]; }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                double x = sp[i + u] - e[u];
+                                x = x * x;
+                                acc = acc + scaled(x, o[u]);
+                            }
+                        }
+#pragma nounroll
+                        for (; i < d; ++i) {
+                            double x = sp[i] - rcen[(size_t)i * list_cap];
+                            x = x * x;
+                            acc = acc + scaled(x, rscl[(size_t)i * list_cap]);
+                        }
                     }
                     const int key = tab.key[r];
                     if (cand_less(acc, key, bd, bk)) { bd = acc; bk = key; br = r; bq = q; }  // strict <, first in list order wins (:326/:373)
                 }
+                CC_TQ(0);  // scan
                 // the wave's minimum by (distance, key) ...
                 {
                     const double D = cc_wave_min_f64(bd);
@@ -180,6 +240,7 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                     }
                 }
                 __syncthreads();
+                CC_TQ(1);  // wave minimum + barrier
                 // ... and the workgroup's (every thread looks at the sixteen entries: the same winner everywhere)
                 double D = CC_INF;
                 int K = CC_IDX_INF, R = -1, Q = -1;
@@ -245,7 +306,9 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                     }
                     if (lane == 0) s_verdict = verdict;
                 }
+                CC_TQ(2);  // selection + tentative add (first wave)
                 __syncthreads();  // the row as committed is what the next point sees
+                CC_TQ(3);  // barrier
                 const int verdict = s_verdict;
                 if (verdict == 0) continue;
                 target = R;
@@ -297,6 +360,7 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                 s_lpath[jj] = path | (promoted ? 4 : 0);
             }
             cdone = jj + 1;
+            CC_TQ(4);  // new row, bookkeeping
         }
         __syncthreads();
         if (tid < cdone) {
@@ -306,6 +370,12 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
         done = c0 + cdone;
     }
     __syncthreads();
+#ifdef CC_SEQG_TIMERS
+    if (tid == 0) {
+        tq_acc[7] = (unsigned long long)done;
+        for (int i = 0; i < 8; ++i) atomicAdd(&ctl->dbg_long[i], tq_acc[i]);
+    }
+#endif
     if (tid == 0) {
         ctl->cursor = cursor0 + done;
         ctl->m_rows = M;
