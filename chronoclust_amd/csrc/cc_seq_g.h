@@ -6,8 +6,8 @@
 // overlapping microclusters, decisions that keep moving, windows cut short after a handful of points - once the table has
 // outgrown k_seq's LDS image (77 rows at d = 20, 25 at d = 64).  There the windowed path commits ~10 points per
 // millisecond whatever is done to its kernels; this kernel takes 8-14 us per point at 150-450 rows
-// (bound by the latency of its loads, not by the filter's divisions: a division-free verdict with a rigorous error bound
-// changed nothing).
+// (cycles per point with the -DCC_SEQG_TIMERS build at d = 20 / 434 rows: scan 12 k, workgroup minimum 2 k, the first wave's
+// tentative add 6 k; at d = 128 / 535 rows with the pdim filter 50 k / 10 k / 15 k - tools/overlap_stream.py).
 // One workgroup of 1 024 threads works on the table where it lies:
 //   per point and stage (pcore rows, then outlier rows: hddstream.py:288-343 / 345-395) every thread takes the rows
 //   q = tid, tid + 1 024, ... of the stage's list (row indices in HBM scratch) - projected distance over the dimensions
