@@ -272,8 +272,13 @@ __global__ __launch_bounds__(CC_SEQG_THREADS) void k_seq_g(Ctl* __restrict__ ctl
                         }
                     }
                     double r2 = 0.0;
+                    {
+                        const int d0 = d < 64 ? d : 64;
 #pragma nounroll
-                    for (int i = 0; i < d; ++i) r2 = r2 + cc_readlane_f64(i < 64 ? term[0] : term[1], i & 63);  // mc_functions.py:54, left to right
+                        for (int i = 0; i < d0; ++i) r2 = r2 + cc_readlane_f64(term[0], i);  // mc_functions.py:54, left to right
+#pragma nounroll
+                        for (int i = 64; i < d; ++i) r2 = r2 + cc_readlane_f64(term[1], i - 64);
+                    }
                     int verdict = 0;
                     if (r2 <= par.eps_sq) {
                         verdict = 1;
