@@ -43,7 +43,7 @@ class CcStats(C.Structure):
                 ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64), ("probe_launches", C.c_int64),
                 ("seq_r_points", C.c_int64), ("heavy_launches", C.c_int64),
                 ("scan_lean_launches", C.c_int64), ("long_prepared", C.c_int64), ("long_replayed", C.c_int64),
-                ("seq_g_points", C.c_int64)]
+                ("seq_g_points", C.c_int64), ("link_launches", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -130,6 +130,7 @@ SYMBOLS = {
     "cc_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
     "cc_comm_set_relaxed": (C.c_int, [C.c_void_p, C.c_int32]),
     "cc_get_relaxed_stats": (C.c_int, [C.c_void_p, C.POINTER(CcRelaxedStats)]),
+    "cc_policy_seq_rate_guess": (C.c_double, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "cc_shard_rows": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p]),
     "cc_set_shard_thresholds": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
 }
@@ -148,6 +149,11 @@ def load():
             raise ChronoclustHipError(
                 "HIP library %s not built; run `python -m chronoclust_amd.build` (needs hipcc). "
                 "chronoclust_amd has no CPU fallback." % path)
+        if _build.is_stale(path) and os.environ.get("CHRONOCLUST_HIP_ALLOW_STALE") != "1":
+            # (keyed to the CONTENT of csrc/ and the header, not to file times: the GPU box receives a copy of the tree)
+            raise ChronoclustHipError(
+                "HIP library %s was not built from the sources beside it (csrc/ or include/chronoclust_hip.h changed since, or "
+                "its .sha256 stamp is missing); run `python -m chronoclust_amd.build`." % path)
         lib = C.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

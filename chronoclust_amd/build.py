@@ -11,13 +11,37 @@ import hashlib
 SOURCES = [os.path.join(_HERE, "csrc", "cc_api.hip")] + sorted(
     p for p in glob.glob(os.path.join(_HERE, "csrc", "*")) if p.endswith((".h", ".hip")) and not p.endswith("cc_api.hip"))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "chronoclust_hip.h")
+# bit-exactness: no FMA contraction, no fast-math anywhere (host or device)
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
+
+
+def sources_digest():
+    """SHA-256 over the contents of every file the library is compiled from (csrc/*, the C-ABI header) and the compiler
+    flags; the build-time defines of a variant are not part of it (a variant is stale when its sources are).  Staleness is
+    keyed to this, not to file times: a copied tree (the GPU box receives one) need not keep those, and a fresh-looking
+    .so beside changed sources must not be loaded silently (_lib.load refuses it)."""
+    hsh = hashlib.sha256()
+    for path in SOURCES + [HEADER]:
+        hsh.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            hsh.update(f.read())
+        hsh.update(b"\0")
+    hsh.update(" ".join(FLAGS).encode())
+    return hsh.hexdigest()
+
+
+def is_stale(path=None):
+    """True when `path` (default: the in-tree library) was not built from the sources as they are now."""
+    path = path or LIB_PATH
+    stamp = path + ".sha256"
+    if not os.path.exists(path) or not os.path.exists(stamp):
+        return True
+    with open(stamp) as f:
+        return f.read().strip() != sources_digest()
 
 
 def needs_build():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+    return is_stale(LIB_PATH)
 
 
 def build(force=False, verbose=False, out=None, defines=()):
@@ -26,13 +50,12 @@ def build(force=False, verbose=False, out=None, defines=()):
     if out is None and not force and not needs_build():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           # bit-exactness: no FMA contraction, no fast-math anywhere (host or device)
-           "-ffp-contract=off", "-fno-fast-math"] + ["-D" + x for x in defines] + [
-           "-o", out or LIB_PATH, SOURCES[0]]
+    cmd = [hipcc] + FLAGS + ["-D" + x for x in defines] + ["-o", out or LIB_PATH, SOURCES[0]]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open((out or LIB_PATH) + ".sha256", "w") as f:
+        f.write(sources_digest() + "\n")
     return out or LIB_PATH
 
 

@@ -154,14 +154,21 @@ class HDDStream(object):
         progress = _progress_lines(log, X.shape[0])  # hddstream.py:218-220: tqdm's bar, written to the log
         self._X = X if device_scaling is None else None  # scaled values are fetched from the device on demand
         self._n_points = X.shape[0]
-        if X.shape[0] > 0 and device_scaling is not None:
-            self._h.points_upload_scaled(X, device_scaling[0], device_scaling[1])
-            self._h.online_run()
-            self.labels_uid, self.labels_path = self._h.labels_download()
-        elif X.shape[0] > 0:
-            self.labels_uid, self.labels_path = self._h.online(X)
-        else:
-            self.labels_uid, self.labels_path = np.empty(0, np.int64), np.empty(0, np.int8)
+        try:
+            if X.shape[0] > 0 and device_scaling is not None:
+                self._h.points_upload_scaled(X, device_scaling[0], device_scaling[1])
+                self._h.online_run()
+                self.labels_uid, self.labels_path = self._h.labels_download()
+            elif X.shape[0] > 0:
+                self.labels_uid, self.labels_path = self._h.online(X)
+            else:
+                self.labels_uid, self.labels_path = np.empty(0, np.int64), np.empty(0, np.int8)
+        except BaseException:
+            # (the reference's loop dies with its bar at the point that raised: the bar is closed where it stands - at 0,
+            # the online phase being one call - instead of being left to tqdm's destructor, which would write a stray
+            # record into the log at some later moment)
+            progress(0)
+            raise
         progress(X.shape[0])
         log.info("Finish online microcluster maintenance for timepoint {}".format(input_dataset_daystamp))
         log.info("Online maintenance yield {} pcores and {} outlier".format(

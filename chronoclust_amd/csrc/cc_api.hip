@@ -166,6 +166,8 @@ struct cc_handle {
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
+    bool allow_link = true;     // CHRONOCLUST_HIP_LINK=0: round 0 does not link the points that decide "create" among themselves (cc_link.h)
+    DevBuf<int> link_near;      // [window] k_link_scan: per window point that decided "create", the earliest such point before it that would absorb it
     bool allow_heavy = true;    // CHRONOCLUST_HIP_HEAVY=0: k_decide's atomics also for rows that take a large share of a window
     bool allow_seq_r = true;    // CHRONOCLUST_HIP_SEQR=0: the sequential kernel with the table in LDS whatever d
     bool allow_seq_g = true;    // CHRONOCLUST_HIP_SEQG=0: no sequential kernel beyond the LDS image (k_seq_g, the table in HBM)
@@ -491,7 +493,7 @@ void ensure_window_buffers(cc_handle* h, int win, int seg)
     h->long_list.ensure(2 * CC_LONG_CAP);
     h->lstat.ensure(2 * CC_LSTAT_ROWS + 2);
     h->lprev.ensure(CC_MAX_WINDOW);
-    h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1); h->sp_list.ensure(w);
+    h->dpath.ensure(w); h->rk.ensure(w); h->rec.ensure(1); h->sp_list.ensure(w); h->link_near.ensure(w);
     h->win_alloc = win; h->seg_alloc = seg; h->d_alloc = (int)d;
 }
 
@@ -787,6 +789,24 @@ hipEvent_t get_sync_event(cc_handle* h, size_t i)
     return h->sync_pool[i];
 }
 
+// k_link_scan over the padded dimensionality (the scans' ladder)
+void launch_link_scan(cc_handle* h, hipStream_t st, int win)
+{
+    const dim3 grid((win + 63) / 64, (win + 4 * CC_LINK_SUB - 1) / (4 * CC_LINK_SUB)), block(256);
+    const int d = h->d;
+#define CC_LINK_DP(DP) hipLaunchKernelGGL((k_link_scan<DP>), grid, block, 0, st, (const Ctl*)h->ctl.p, (const double*)h->X.p, \
+                                          (const double*)h->Xt.p, (const int*)h->T0.p, h->link_near.p)
+    if (d <= 4) CC_LINK_DP(4);
+    else if (d <= 8) CC_LINK_DP(8);
+    else if (d <= 14) CC_LINK_DP(14);
+    else if (d <= 16) CC_LINK_DP(16);
+    else if (d <= 20) CC_LINK_DP(20);
+    else if (d <= 32) CC_LINK_DP(32);
+    else if (d <= 40) CC_LINK_DP(40);
+    else CC_LINK_DP(64);
+#undef CC_LINK_DP
+}
+
 struct RowList {
     std::vector<int> pcore, outlier;  // table rows in Python list order
 };
@@ -892,6 +912,8 @@ int cc_create(int device, cc_handle** out)
         if (sa) h->split_a_mode = std::max(0, std::min(2, atoi(sa)));
         const char* ln = getenv("CHRONOCLUST_HIP_LEAN");
         h->allow_lean = !(ln && ln[0] == '0');
+        const char* lk = getenv("CHRONOCLUST_HIP_LINK");
+        h->allow_link = !(lk && lk[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
         if (sp && atoi(sp) >= 0) h->allow_sparse = atoi(sp);
         push_ctl(h);
@@ -1422,6 +1444,7 @@ struct OnlineRun {
     bool sparse_now = false;  // with nodirty: sparse dirty scans for the round's list of points
     bool la_on = false;       // lookahead scans are being enqueued
     bool shard_on = false;    // snapshot scans are split over the ranks of the group
+    bool link_now = false;    // round 0 of this batch's windows links the points that decide "create" (cc_link.h)
     int Rcur = 1;             // validation rounds enqueued per window of the batch
     int batch_windows = 2;
 
@@ -1470,7 +1493,7 @@ struct OnlineRun {
     // does not take such points; k_seq_g does, from the first one on
     bool wide() const { return h->d > CC_WINDOW_MAX_DIM; }
     bool seq_g_applies() const { return h->allow_seq_g && h->hc.m_rows >= seq_cap; }
-    double seq_rate_guess() const { return seq_g_applies() ? 150.0 : seq_r_applies() ? 1500.0 : 700.0; }
+    double seq_rate_guess() const { return cc::seq_rate_guess(h->d, h->hc.m_rows, seq_cap, h->allow_seq_r, h->allow_seq_g); }
     // (never in a group - every rank has to take the same path, and wall-clock measurements differ -, never with no_create:
     // the sequential kernels know the reference's loop only)
     bool seq_possible() const { return seq_mode != 1 && !h->comm.active() && !no_create && (h->hc.m_rows < seq_cap || h->allow_seq_g); }
@@ -1582,6 +1605,10 @@ struct OnlineRun {
 #ifdef CC_LONG_TIMERS
         for (int i = 0; i < 8; ++i) c.dbg_long[i] = 0;
 #endif
+#ifdef CC_ROUND_DEBUG
+        for (int i = 0; i < CC_MAX_ROUNDS + 2; ++i)
+            for (int q = 0; q < 6; ++q) c.dbg_round[i][q] = 0;
+#endif
         c.n_heavy = c.n_heavy_new = 0;  // (rows are renumbered between calls: the marks of the last call are void)
         HIPCHK(hipMemsetAsync(h->tab.heavy.p, 0, h->tab.cap * sizeof(int), h->stream));
         c.stat_seq_clk = c.stat_seq_wall = 0;
@@ -1644,6 +1671,8 @@ struct OnlineRun {
         sparse_now = dec.sparse != 0;
         cursor_prev = range_a;
         seq_host = c.window_seq;
+        // (a call starts with whatever is new since the last one: the first batch links, the later ones while the table grows)
+        link_now = h->allow_link && !no_create && !wide();
     }
 
     // a stint of the sequential kernel (k_seq): one chunk of points, then back to the windows if the table outgrew its LDS
@@ -1791,7 +1820,13 @@ struct OnlineRun {
         evScan = nullptr;  // the scan of the batch's first window is complete (the second stream was drained)
         if (la_on) HIPCHK(hipEventRecord(evCommit, sA));  // everything so far (table, control block) is in place
         int probe_left = (dec.probe != 0) ? 1 : 0;
-        for (int wv = 0; wv < batch_windows; ++wv, ++seq_host) {
+        // No window beyond the end of the range: when windows commit in full, ceil(left / window) of them finish the call (a
+        // window that is cut short leaves its rest to the next batch, as anywhere else).  Every window enqueued past the end
+        // is a dozen launches that find nothing to do - 50-100 us each, up to fifteen of them at the end of every call
+        // (profiles/r06_tool_startup_timeline_before.txt: w36-w47).  A function of counters that are the same on every rank.
+        const int windows_now = (int)std::max<long long>(1, std::min<long long>(batch_windows,
+                                    (N - done + (long long)std::max(1, h->hc.win_cfg) - 1) / (long long)std::max(1, h->hc.win_cfg)));
+        for (int wv = 0; wv < windows_now; ++wv, ++seq_host) {
             hipEvent_t scan_end = nullptr;  // the event recorded right behind the last timed scan (nothing after it yet)
             auto timed_scan = [&](hipStream_t st, int mode, int round) {
                 const Rows& rws = (mode == 1) ? srows[round & 1] : trows;
@@ -1880,7 +1915,16 @@ struct OnlineRun {
             hipLaunchKernelGGL(k_decide, dim3(dblocks + ac_blocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car,
                                dec_part, dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, (const int*)nullptr,
                                h->T0.p, h->dpath.p, dec_S, Sd, 0, 0, scan_rows, dec_inner, dec_outer,
-                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0, 0);
+                               (const CommitRec*)h->rec.p, sc_now, ac_blocks, long_list, long_cap, dec_tail, 0, heavy_on ? 1 : 0, 0,
+                               link_now ? h->link_near.p : (int*)nullptr);
+            if (link_now) {
+                // the window's own creators (cc_link.h): points that decided "create" and would be absorbed by an earlier
+                // such point claim the microcluster that one creates - before the first chain replay, not after two of them
+                launch_link_scan(h, sA, gw);
+                hipLaunchKernelGGL(k_link_apply, dim3((gw + 255) / 256), dim3(256), 0, sA, h->ctl.p, tab, h->T0.p,
+                                   (const int*)h->link_near.p, h->dpath.p);
+                ++h->stats.link_launches;
+            }
             if (scan_rows > 0)
                 hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)h->T0.p, 0, scan_rows, 0);
             if (heavy_on && ++h->stats.heavy_launches > 0)
@@ -1937,7 +1981,7 @@ struct OnlineRun {
                 hipLaunchKernelGGL(k_decide, dim3(dblocks), dim3(decide_threads), 0, sA, h->ctl.p, h->X.p, tab, ver, car, dec_part,
                                    dec_stride, h->clean.p, h->dpart.p, h->dpart2.p, h->dseed.p, told, tnew, h->dpath.p, dec_S, Sd, r, nodirty ? (sparse_r ? 2 : 1) : 0, scan_rows,
                                    dec_inner, dec_outer, (const CommitRec*)nullptr, ScanCopy{}, 0, long_list, long_cap, -1,
-                                   r == Rcur ? 1 : 0, heavy_on ? 1 : 0, h->allow_quiet ? 1 : 0);
+                                   r == Rcur ? 1 : 0, heavy_on ? 1 : 0, h->allow_quiet ? 1 : 0, (int*)nullptr);
                 // (the claims of the last round are not replayed: nothing to gather either)
                 if (scan_rows > 0 && r < Rcur)
                     hipLaunchKernelGGL(k_claims, dim3(scan_rows), dim3(256), 0, sA, h->ctl.p, tab, (const int*)tnew, r, scan_rows, h->allow_quiet ? 1 : 0);
@@ -1964,6 +2008,11 @@ struct OnlineRun {
         if (la_on) sync_stream(h, sB);
         seq_host = h->hc.window_seq;
         done = h->hc.cursor;
+        // Round 0 links the points that decide "create" among themselves (cc_link.h: two more small launches per window)
+        // while the batch just read back created a microcluster per 256 points or more - a function of device counters
+        // that are identical on every rank
+        link_now = h->allow_link && !no_create &&
+                   ((long long)(h->hc.m_rows - m_known) * 256 >= std::max<long long>(1, h->hc.cursor - cursor_prev));
         m_known = h->hc.m_rows;
         const bool shard_was = shard_on;
         {
@@ -2023,6 +2072,13 @@ struct OnlineRun {
                 set_lookahead(dec.lookahead != 0);
                 push_ctl(h);
             }
+#ifdef CC_ROUND_DEBUG
+            for (int r = 1; r <= CC_MAX_ROUNDS; ++r)
+                if (h->hc.dbg_round[r][5] != 0)
+                    fprintf(stderr, "[cc]    round %d so far: %llu decisions, %llu refused, create->join new %llu, create->join row %llu, join->create %llu, other MC %llu | windows ended in round %d: %lld\n",
+                            r, h->hc.dbg_round[r][5], h->hc.dbg_round[r][0], h->hc.dbg_round[r][1], h->hc.dbg_round[r][2], h->hc.dbg_round[r][3],
+                            h->hc.dbg_round[r][4], r, (long long)h->hc.round_hist[r]);
+#endif
             if (h->trace)
                 fprintf(stderr, "[cc] %.2f ms done %lld rows %d | batch: %lld windows %lld points trunc %lld (%lld at an undecidable point) lookahead %lld dirty tiles %lld / %lld (points so far: %lld unlocated, %lld unsafe) | next window %d rounds %d\n",
                         now_ms() - batch_t0, done, h->hc.m_rows, (long long)dec.wins, (long long)dec.pts, (long long)dec.trunc, (long long)dec.unk, (long long)h->hc.stat_lookahead, (long long)dec.dtiles, (long long)dec.tiles,
@@ -2914,6 +2970,13 @@ int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_
         out[i + 1] = obs[i].after_sequential ? policy.after_sequential(obs[i].cursor, obs[i].m_rows) : policy.after_batch(obs[i]);
     *carry = policy.carry();
     return CC_OK;
+}
+
+double cc_policy_seq_rate_guess(int32_t d, int32_t m_rows, int32_t allow_seq_r, int32_t allow_seq_g)
+{
+    if (d < 1 || d > CC_MAX_DIM || m_rows < 0) return -1.0;
+    const int seq_cap = d > CC_WINDOW_MAX_DIM ? 0 : cc_seq_cap_rows(d);
+    return cc::seq_rate_guess(d, m_rows, seq_cap, allow_seq_r != 0, allow_seq_g != 0);
 }
 
 int cc_get_stats(cc_handle* h, cc_stats* out)

@@ -254,6 +254,12 @@ struct Ctl {
 #ifdef CC_LONG_TIMERS
     unsigned long long dbg_long[8];  // build variant: shader cycles per phase of k_chain_long (workgroup 0 of each launch)
 #endif
+#ifdef CC_ROUND_DEBUG
+    // build variant: decisions of validation round r that differ from the claim they validate, by what changed -
+    // [r][0] refused (CC_T_UNKNOWN), [r][1] "create" -> joins a MC created inside the window, [r][2] "create" -> joins a table
+    // row, [r][3] joins -> "create", [r][4] another MC, [r][5] all decisions of the round
+    unsigned long long dbg_round[CC_MAX_ROUNDS + 2][6];
+#endif
 };
 
 // Displacement classes of a version row / carried row relative to the snapshot its window was scanned against

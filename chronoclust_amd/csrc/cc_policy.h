@@ -25,6 +25,20 @@ inline bool policy_want_shard(const cc_policy_config& c, int m_rows)
     return c.can_shard != 0 && (long long)m_rows * c.d >= c.shard_min_row_dims;
 }
 
+// Points per millisecond the sequential kernel that WOULD take over is assumed to manage before it has been measured in
+// this call (the takeover rule of cc_api.hip compares the windows' measured rate with it).  k_seq_r (rows in registers,
+// d <= 4) ~0.6 us per point, k_seq (table in LDS) ~1.3 us, whatever the data.  k_seq_g (table in HBM, from `seq_cap` rows
+// on) is one workgroup of 1 024 threads that walks rows / 1 024 rows per thread: 8-14 us per point measured at 150-450
+// rows (profiles/r05_tool_seq_g.txt) - 100 points per ms up to 1 024 rows, and in proportion to 1 024 / rows beyond: at
+// 20 000-50 000 rows a truncating stream whose windows still make 30-140 points per ms must not be handed a 32 768-point
+// stint of a kernel that manages 2-5.
+inline double seq_rate_guess(int d, int m_rows, int seq_cap, bool allow_seq_r, bool allow_seq_g)
+{
+    if (allow_seq_g && m_rows >= seq_cap) return 100.0 * std::min(1.0, 1024.0 / (double)std::max(1, m_rows));
+    if (allow_seq_r && d >= 2 && d <= 4) return 1500.0;
+    return 700.0;
+}
+
 class WindowPolicy {
 public:
     static constexpr int kStartSmall = 256;   // window on a (nearly) empty table
@@ -134,8 +148,10 @@ public:
         //    speculated remainder is wasted: aim at the average committed length; grow back by doubling while nothing
         //    is truncated.
         const long long grew = (long long)o.m_rows - prev_.m_rows, pts = o.cursor - prev_.cursor;
-        // while MCs are being created every window needs its chains replayed two or three times: all the rounds
-        if (pts > 0 && grew * 50 > pts) rcur_ = Rmax;
+        // while MCs are being created a window may need one round more than the last batch's windows did (a promotion inside
+        // the window, a link of round 0 that did not hold - cc_link.h): one spare round.  (Before round 0 linked a window's
+        // creators such windows took three rounds and got all the rounds there are; `used` says so itself when they do.)
+        if (pts > 0 && grew * 50 > pts) rcur_ = std::min(Rmax, std::max(rcur_, used + 1));
         const long long wins = o.stat_windows - prev_.stat_windows;
         //  - The same holds while MCs are being promoted: a promoted MC competes in a list it was not scanned for, so
         //    the dirty scans run unpruned; the device counts the point tiles whose dirty scan ran.

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
                                                 int scan_rows, int part_inner, size_t part_outer,
                                                 const CommitRec* __restrict__ ac_rec, ScanCopy ac_sc, int ac_blocks,
                                                 int* __restrict__ long_list, int long_cap, int stat_tail, int last_round,
-                                                int heavy_on, int quiet_ok)
+                                                int heavy_on, int quiet_ok, int* __restrict__ link_near)
 {
     CC_LATENCY_KERNEL();
     // the last ac_blocks workgroups of a round-0 launch before a lookahead window's validation: cc_apply_carry
@@ -828,7 +828,21 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
     if (gl == 0) {
         Tnew[j] = T;
         dpath[j] = (int8_t)path;
+        // (round 0 with the creators' links, cc_link.h: no link yet; the claims of the points that decided "create" are
+        // registered by k_link_apply, for the microcluster they end up claiming)
+        if (link_near != nullptr) link_near[j] = CC_IDX_INF;
         if (round > 0 && (T == CC_T_UNKNOWN || T != Told[j])) atomicMin(&ctl->fc[round], j);
+#ifdef CC_ROUND_DEBUG
+        if (round > 0) {
+            const int to = Told[j];
+            atomicAdd(&ctl->dbg_round[round][5], 1ull);
+            if (T == CC_T_UNKNOWN) atomicAdd(&ctl->dbg_round[round][0], 1ull);
+            else if (T != to) {
+                const int c = (to == M0 + j) ? (T >= M0 ? 1 : 2) : (T == M0 + j ? 3 : 4);
+                atomicAdd(&ctl->dbg_round[round][c], 1ull);
+            }
+        }
+#endif
         if ((j & 15) == 0) {  // the next k_chain takes maxima into them
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE] = 0ull;
             ver.tile_dsq[(size_t)(j >> 4) * CC_DSQ_STRIDE + 1] = 0ull;
@@ -839,7 +853,8 @@ __global__ __launch_bounds__(256) void k_decide(Ctl* __restrict__ ctl, const dou
         // commit reads the claims themselves -, so they are not registered: three atomics per point saved, and the ones
         // that serialise when a population takes a large share of the events (one address per MC)
         // (heavy_on: k_claims_heavy follows this launch and gathers the claims of the heavy rows - Table::heavy)
-        if (last_round == 0 && T >= 0 && !(T < M0 && T < scan_rows) && !(heavy_on != 0 && T < M0 && tab.heavy[T] != 0)) {
+        if (last_round == 0 && T >= 0 && !(T < M0 && T < scan_rows) && !(heavy_on != 0 && T < M0 && tab.heavy[T] != 0) &&
+            !(link_near != nullptr && T == M0 + j)) {
             // first / last point of this window that targets T, for the round that replays these claims
             // (provisional ids of new MCs index the free rows behind the table)
             const unsigned long long sn = (stamp + 1ull) << 20;

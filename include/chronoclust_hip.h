@@ -137,6 +137,8 @@ typedef struct cc_stats {
                                     * k_chain, every step then evaluated by the step's own 32-lane group ...              */
     int64_t long_replayed;         /* ... and of those, chains replayed from the first step the radius test rejected */
     int64_t seq_g_points;          /* of seq_points: taken by k_seq_g (table in HBM: beyond the sequential kernel's LDS image) */
+    int64_t link_launches;         /* windows whose round 0 linked the points that decided "create" among themselves
+                                    * (k_link_scan + k_link_apply: while microclusters are being created)                  */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -376,6 +378,12 @@ typedef struct cc_policy_decision {
 } cc_policy_decision;
 int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,
                      const cc_policy_obs* obs, int32_t n, cc_policy_decision* out);
+/* The one wall-clock rule of the library (a stream of short, truncated windows is handed to the sequential kernel when that
+ * is faster) compares the windows' measured rate with an ASSUMED rate of the sequential kernel until that has been measured
+ * in the call: points per millisecond, as a function of the dimensionality and of the table size - k_seq_g, the kernel for
+ * tables beyond the LDS image, slows down in proportion to the rows once they exceed its 1 024 threads.  Pure; < 0 on a
+ * bad argument.  No reference counterpart. */
+double cc_policy_seq_rate_guess(int32_t d, int32_t m_rows, int32_t allow_seq_r, int32_t allow_seq_g);
 
 #ifdef __cplusplus
 }

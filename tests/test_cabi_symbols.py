@@ -27,6 +27,36 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert set(names) == set(_lib.SYMBOLS), "ctypes binding and header disagree"
 
 
+def test_staleness_is_keyed_to_content_not_to_file_times(tmp_path):
+    """A library whose stamp does not match the sources beside it is stale however new its file looks, and the loader
+    refuses it (the GPU box receives a COPY of the tree with the prebuilt .so: file times say nothing there)."""
+    import shutil
+    path = build.build()
+    assert not build.is_stale(path) and not build.needs_build()
+    os.utime(path, (1, 1))  # an ancient file time changes nothing
+    assert not build.needs_build()
+    copy = str(tmp_path / "libcopy.so")
+    shutil.copy(path, copy)
+    assert build.is_stale(copy)  # no stamp: unknown provenance
+    with open(copy + ".sha256", "w") as f:
+        f.write("0" * 64 + "\n")
+    assert build.is_stale(copy)  # built from other sources
+    old_env, old_lib = os.environ.get("CHRONOCLUST_HIP_LIB"), _lib._lib
+    os.environ["CHRONOCLUST_HIP_LIB"] = copy
+    _lib._lib = None
+    try:
+        with pytest.raises(_lib.ChronoclustHipError, match="not built from the sources"):
+            _lib.load()
+    finally:
+        _lib._lib = old_lib
+        if old_env is None:
+            os.environ.pop("CHRONOCLUST_HIP_LIB", None)
+        else:
+            os.environ["CHRONOCLUST_HIP_LIB"] = old_env
+    shutil.copy(path + ".sha256", copy + ".sha256")
+    assert not build.is_stale(copy)
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU the product must fail loudly, not compute on the host."""
     import torch

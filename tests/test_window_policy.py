@@ -121,3 +121,26 @@ def test_five_batches_without_progress_stop_the_call():
     # may have been a batch without dirty scans: those come back first) - plain scans with the dirty scans launched always
     # decide a window's first point (round 5: seed 9348 of the forced-pruning soak, three such batches in a row)
     assert decs[1]["prune"] == 1 and decs[3]["prune"] == 0 and decs[4]["prune"] == 0 and decs[6]["prune"] == 0
+
+
+def test_assumed_rate_of_the_sequential_kernel_falls_with_the_table():
+    """The takeover rule of the sequential kernel compares the windows' measured rate with an assumed one until the kernel
+    has been measured in the call.  For k_seq_g (tables beyond the LDS image) that rate must fall with the table size: one
+    workgroup walks rows / 1 024 rows per thread, and a truncating stream on 20 000-50 000 rows whose windows still make
+    30-140 points per millisecond must not be handed a 32 768-point stint of a kernel that manages a tenth of that
+    (the guess used to be 150 whatever the table)."""
+    g = _lib.load().cc_policy_seq_rate_guess
+    # d = 20: the LDS image holds 77 rows; below that k_seq, d <= 4 the register kernel
+    assert g(20, 10, 1, 1) == 700.0 and g(3, 10, 1, 1) == 1500.0 and g(3, 10, 0, 1) == 700.0
+    # beyond the image: k_seq_g at its measured 8-14 us per point up to 1 024 rows ...
+    assert 70.0 <= g(20, 150, 1, 1) <= 125.0 and g(20, 1024, 1, 1) == g(20, 150, 1, 1)
+    # ... and in proportion to 1 024 / rows beyond
+    assert g(20, 20_000, 1, 1) == pytest.approx(100.0 * 1024 / 20_000) and g(20, 50_000, 1, 1) < 30.0 / 10
+    rates = [g(20, m, 1, 1) for m in (100, 1000, 2000, 5000, 20_000, 50_000)]
+    assert all(a >= b for a, b in zip(rates, rates[1:]))
+    # windows that still commit 30 points per millisecond on a 20 000-row table keep the stream (the rule: take over when
+    # win_rate < guess); the same windows on a 300-row table hand it over
+    assert not (30.0 < g(20, 20_000, 1, 1)) and 30.0 < g(20, 300, 1, 1)
+    # without k_seq_g nothing takes over beyond the image; more than 64 dimensions run on it from the first row
+    assert g(20, 5000, 1, 0) == 700.0 and g(100, 0, 1, 1) == 100.0
+    assert g(0, 10, 1, 1) < 0 and g(20, -1, 1, 1) < 0

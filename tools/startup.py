@@ -23,7 +23,9 @@ if __name__ == "__main__":
                  rounds=int(os.environ.get("ROUNDS", "0")))
     bench.set_params(h, cfg, n, d)
     h.points_upload(X)
+    import time
     for rep in range(int(os.environ.get("REPS", "3"))):
+        time.sleep(0.02)  # (a gap the trace tools cut the repetitions at)
         h.reset()
         h.online_run()
         s = h.stats()
