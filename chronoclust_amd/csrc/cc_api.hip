@@ -100,11 +100,48 @@ struct TableStore {
     }
 };
 
-struct HostCluster {
-    std::vector<int> members;  // pcore list positions in merge order
+// The clusters of the last offline phase, flat: cluster c = members [off[c], off[c + 1]) of `mem`, pcore list positions in
+// merge order (a vector per cluster cost 5 000 allocations per call at C2: 350 us of the ordered expansion's 380)
+struct HostClusters {
+    std::vector<int> mem, off{0};
+    size_t size() const { return off.size() - 1; }
+    void clear() { mem.clear(); off.assign(1, 0); }
 };
 
 }  // namespace
+
+// Page-locked host scratch for the small read-backs and uploads of a call (offline phase: row order, flags, counts, lists):
+// a copy to or from pageable memory is driven by the host thread - it first waits for the stream to drain -, one to or from
+// page-locked memory is a stream operation; six to ten of them per cc_offline call were 300 us of idle device.  Bump
+// allocation per call (`reset`), never freed in between; growing it (rare) drains the stream first.
+struct PinArena {
+    char* p = nullptr;
+    size_t cap = 0, used = 0;
+    void reset() { used = 0; }
+    void reserve(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(bytes, (size_t)1 << 20);
+        if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+            p = nullptr;
+            throw HipErr{hipErrorOutOfMemory, "hipHostMalloc"};
+        }
+        cap = want;
+    }
+    template <typename T>
+    T* take(size_t n)  // (within what reserve() was given)
+    {
+        used = (used + 63) & ~(size_t)63;
+        T* r = reinterpret_cast<T*>(p + used);
+        used += std::max<size_t>(n, 1) * sizeof(T);
+        if (used > cap) throw HipErr{hipErrorOutOfMemory, "page-locked scratch exhausted"};
+        return r;
+    }
+    ~PinArena() { if (p) (void)hipHostFree(p); }
+};
 
 struct cc_handle {
     int device = 0;
@@ -119,6 +156,7 @@ struct cc_handle {
     int d = 0;
     TableStore tab, tab2;
     Ctl hc{};  // host mirror of the device control block
+    Ctl* hc_pin = nullptr;  // two page-locked staging blocks for it (read-back between batches / restart push)
     DevBuf<Ctl> ctl;
     bool tainted = false;  // a pref value outside {1, k} may be present -> never take the x * (1/k) shortcut
     int adapt_win = 0;      // window size the last call settled at (0: none yet)
@@ -216,7 +254,8 @@ struct cc_handle {
     DevBuf<int8_t> core;
     DevBuf<unsigned long long> adj, adjw;
     DevBuf<double> c_cf1, c_cf2, c_cen, c_pref, c_w;
-    std::vector<HostCluster> clusters;
+    HostClusters clusters;
+    PinArena pin;  // page-locked scratch of the current call
     std::vector<long long> pcore_ids_host, pcore_uid_host;  // ids / creation numbers of the pcores, list order
     DevBuf<int32_t> pc_map, pc_out;                         // cc_point_clusters: creation number -> cluster, result
     int n_core = 0;
@@ -416,6 +455,26 @@ void pull_ctl(cc_handle* h)
 {
     HIPCHK(hipMemcpyAsync(&h->hc, h->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
     sync_stream(h, h->stream);
+}
+// The same between the batches of a call, through page-locked staging blocks: a copy to or from pageable memory is driven
+// by the host - it waits for the stream to drain and only then starts the copy (30 us of idle device before the copy
+// kernel at every read-back, profiles/r06_tool_startup_gaps_before.txt) -, one from page-locked memory is a stream
+// operation like any other.  pull: the block is read once the stream has drained.  push: only ever called right after a
+// pull (the stream is idle, the previous push's copy has completed), so one block serves.
+void pull_ctl_pinned(cc_handle* h)
+{
+    if (!h->hc_pin) { pull_ctl(h); return; }
+    HIPCHK(hipMemcpyAsync(h->hc_pin, h->ctl.p, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+    sync_stream(h, h->stream);
+    memcpy(&h->hc, h->hc_pin, sizeof(Ctl));
+}
+void push_ctl_pinned(cc_handle* h)
+{
+    if (!h->hc_pin) { push_ctl(h); return; }
+    memset(h->hc.pstat, 0, sizeof(h->hc.pstat));
+    h->hc.n_missed_all[0] = h->hc.n_missed_all[1] = 0;
+    memcpy(h->hc_pin + 1, &h->hc, sizeof(Ctl));
+    HIPCHK(hipMemcpyAsync(h->ctl.p, h->hc_pin + 1, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
 }
 
 // grow the table to at least `rows` rows, keeping the first m_rows rows
@@ -861,6 +920,7 @@ int cc_create(int device, cc_handle** out)
         HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo));
         h->ctl.ensure(1);
+        if (hipHostMalloc((void**)&h->hc_pin, 2 * sizeof(Ctl), hipHostMallocDefault) != hipSuccess) h->hc_pin = nullptr;
         h->badflag.ensure(4);
         memset(&h->hc, 0, sizeof(Ctl));
         h->tun.window = 32768;
@@ -934,6 +994,7 @@ void cc_destroy(cc_handle* h)
     (void)hipSetDevice(h->device);
     if (h->pf.worker.joinable()) h->pf.worker.join();
     if (h->pf.stream) (void)hipStreamDestroy(h->pf.stream);
+    if (h->hc_pin) (void)hipHostFree(h->hc_pin);
     for (int q = 0; q < 2; ++q)
         if (h->pf.pin[q]) (void)hipHostFree(h->pf.pin[q]);
     // (a pending collective whose peer is gone must not hang the destructor: bounded wait, then abort)
@@ -2004,7 +2065,7 @@ struct OnlineRun {
     int after_batch()
     {
         HIPCHK(hipGetLastError());
-        pull_ctl(h);
+        pull_ctl_pinned(h);
         if (la_on) sync_stream(h, sB);
         seq_host = h->hc.window_seq;
         done = h->hc.cursor;
@@ -2070,7 +2131,7 @@ struct OnlineRun {
                 h->hc.win_cfg = dec.win_cfg;
                 h->hc.win_b = (int)std::min<long long>(dec.win_cfg, N - done);
                 set_lookahead(dec.lookahead != 0);
-                push_ctl(h);
+                push_ctl_pinned(h);
             }
 #ifdef CC_ROUND_DEBUG
             for (int r = 1; r <= CC_MAX_ROUNDS; ++r)
@@ -2469,8 +2530,35 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         h->pcore_uid_host.clear();
         h->n_core = 0;
         if (n_clusters) *n_clusters = 0;
-        RowList rl = list_order(h);
-        const int mp = (int)rl.pcore.size(), d = h->d;
+        // (CHRONOCLUST_HIP_TRACE=1: host wall time per phase of the call)
+        auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tph[8] = {now_us(), 0, 0, 0, 0, 0, 0, 0};
+        // the pcore rows in list order (ascending key), from page-locked copies of the kind / key columns; creation numbers
+        // of all rows beside them (cc_point_clusters joins the per-point labels to the clusters through the pcores')
+        const int m_all = h->hc.m_rows;
+        h->pin.reset();
+        h->pin.reserve((size_t)m_all * 72 + ((size_t)1 << 16));  // (everything below but the neighbour lists: 49 B per row)
+        std::vector<int> prow_host;
+        const long long* uid_all = nullptr;
+        if (m_all > 0) {
+            int* kind = h->pin.take<int>((size_t)m_all);
+            int* key = h->pin.take<int>((size_t)m_all);
+            long long* uid = h->pin.take<long long>((size_t)m_all);
+            HIPCHK(hipMemcpyAsync(kind, h->tab.kind.p, (size_t)m_all * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(key, h->tab.key.p, (size_t)m_all * 4, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(uid, h->tab.uid.p, (size_t)m_all * 8, hipMemcpyDeviceToHost, h->stream));
+            sync_stream(h, h->stream);
+            uid_all = uid;
+            std::vector<unsigned long long> order;  // (key, row) packed: one plain sort, no indirection
+            order.reserve((size_t)m_all);
+            for (int r = 0; r < m_all; ++r)
+                if (kind[r] == CC_KIND_PCORE) order.push_back(((unsigned long long)((unsigned)key[r] ^ 0x80000000u) << 32) | (unsigned)r);  // (signed order)
+            std::sort(order.begin(), order.end());
+            prow_host.resize(order.size());
+            for (size_t i = 0; i < order.size(); ++i) prow_host[i] = (int)(order[i] & 0xFFFFFFFFull);
+        }
+        tph[1] = now_us();
+        const int mp = (int)prow_host.size(), d = h->d;
         if (mp == 0) return (int)CC_OK;
         const size_t md = (size_t)mp * d;
         const int words = (mp + 63) / 64;
@@ -2486,7 +2574,9 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         h->pv_cf1.ensure(md); h->pv_cf2.ensure(md); h->pv_cen.ensure(md); h->pv_pref.ensure(md); h->pv_w.ensure(mp);
         h->pv_id.ensure(mp); h->prow.ensure(mp); h->wvec.ensure(rows_pad * d); h->nn.ensure(rows_pad); h->pdim.ensure(mp);
         h->core.ensure(mp); h->adj.ensure(rows_pad * words); h->adjw.ensure(rows_pad * words);
-        HIPCHK(hipMemcpyAsync(h->prow.p, rl.pcore.data(), (size_t)mp * 4, hipMemcpyHostToDevice, h->stream));
+        int* const prow_pin = h->pin.take<int>((size_t)mp);
+        memcpy(prow_pin, prow_host.data(), (size_t)mp * 4);
+        HIPCHK(hipMemcpyAsync(h->prow.p, prow_pin, (size_t)mp * 4, hipMemcpyHostToDevice, h->stream));
         PcoreView pv{h->pv_cf1.p, h->pv_cf2.p, h->pv_cen.p, h->pv_pref.p, h->pv_w.p, h->pv_id.p};
         const Ctl& c = h->hc;
         const cc_params& p = h->par;
@@ -2497,11 +2587,17 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         const int my_rows = p_hi - p_lo;
         if (my_rows > 0) {
             {
-                const dim3 grid((words + 3) / 4, (my_rows + CC_EPS_PCH - 1) / CC_EPS_PCH), block(256);
-#define CC_EPS(DP) hipLaunchKernelGGL((k_eps_neighbours<DP>), grid, block, 0, h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words, p_lo, p_hi)
+                // p rows per workgroup: CC_EPS_PCH on large tables; a table of a few thousand rows would be a few hundred
+                // workgroups of one wave per SIMD each (5 000 rows: 400 workgroups, 141 us for 46 us of arithmetic) - whole
+                // staging passes (CC_EPS_TP rows), at least ~8 workgroups per CU
+                int pch = CC_EPS_PCH;
+                while (pch > CC_EPS_TP && (long long)((words + 3) / 4) * ((my_rows + pch - 1) / pch) < 8ll * h->n_cus) pch /= 2;
+                const dim3 grid((words + 3) / 4, (my_rows + pch - 1) / pch), block(256);
+#define CC_EPS(DP) hipLaunchKernelGGL((k_eps_neighbours<DP>), grid, block, 0, h->stream, pv.cen, mp, d, p.ups_eps, h->adj.p, words, p_lo, p_hi, pch)
                 if (d <= 4) CC_EPS(4);
                 else if (d <= 8) CC_EPS(8);
                 else if (d <= 16) CC_EPS(16);
+                else if (d <= 20) CC_EPS(20);
                 else if (d <= 24) CC_EPS(24);
                 else if (d <= 40) CC_EPS(40);
                 else if (d <= 64) CC_EPS(64);
@@ -2525,49 +2621,60 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
         // the reachability rows as neighbour lists: counts -> offsets (host prefix sums) -> ascending positions
         h->nw_cnt.ensure(mp);
         hipLaunchKernelGGL(k_adj_counts, dim3(mp), dim3(64), 0, h->stream, h->adjw.p, words, mp, h->nw_cnt.p);
-        std::vector<int8_t> core(mp);
-        std::vector<int> pdim(mp), nn(mp), nw_cnt(mp);
-        h->pcore_ids_host.resize(mp);
-        {
-            // creation numbers of the pcores (cc_point_clusters joins the per-point labels to the clusters through them)
-            std::vector<long long> uid_all((size_t)h->hc.m_rows);
-            HIPCHK(hipMemcpyAsync(uid_all.data(), h->tab.uid.p, uid_all.size() * 8, hipMemcpyDeviceToHost, h->stream));
-            sync_stream(h, h->stream);
-            h->pcore_uid_host.resize(mp);
-            for (int i = 0; i < mp; ++i) h->pcore_uid_host[(size_t)i] = uid_all[(size_t)rl.pcore[(size_t)i]];
-        }
-        HIPCHK(hipMemcpyAsync(core.data(), h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(pdim.data(), h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(nn.data(), h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(nw_cnt.data(), h->nw_cnt.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipMemcpyAsync(h->pcore_ids_host.data(), h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
+        h->pcore_uid_host.resize(mp);
+        for (int i = 0; i < mp; ++i) h->pcore_uid_host[(size_t)i] = uid_all[(size_t)prow_host[(size_t)i]];
+        int8_t* const core = h->pin.take<int8_t>((size_t)mp);
+        int* const pdim = h->pin.take<int>((size_t)mp);
+        int* const nn = h->pin.take<int>((size_t)mp);
+        int* const nw_cnt = h->pin.take<int>((size_t)mp);
+        long long* const ids_pin = h->pin.take<long long>((size_t)mp);
+        long long* const nw_off = h->pin.take<long long>((size_t)mp + 1);
+        HIPCHK(hipMemcpyAsync(core, h->core.p, mp, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(pdim, h->pdim.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(nn, h->nn.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(nw_cnt, h->nw_cnt.p, (size_t)mp * 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(ids_pin, h->pv_id.p, (size_t)mp * 8, hipMemcpyDeviceToHost, h->stream));
         sync_stream(h, h->stream);
         HIPCHK(hipGetLastError());
-        std::vector<long long> nw_off((size_t)mp + 1, 0);
+        h->pcore_ids_host.assign(ids_pin, ids_pin + mp);
+        tph[2] = now_us();
+        nw_off[0] = 0;
         for (int i = 0; i < mp; ++i) nw_off[(size_t)i + 1] = nw_off[i] + nw_cnt[i];
         const long long n_edges = nw_off[mp];
-        std::vector<int> nbr((size_t)std::max<long long>(n_edges, 1));
+        // (the lists go into a block of their own: the first one must stay where it is)
+        std::vector<int> nbr_pageable;
+        const int* nbr = nullptr;
         if (n_edges > 0) {
             h->nw_off.ensure((size_t)mp + 1);
             h->nw_nbr.ensure((size_t)n_edges);
-            HIPCHK(hipMemcpyAsync(h->nw_off.p, nw_off.data(), ((size_t)mp + 1) * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->nw_off.p, nw_off, ((size_t)mp + 1) * 8, hipMemcpyHostToDevice, h->stream));
             hipLaunchKernelGGL(k_adj_fill, dim3(mp), dim3(64), 0, h->stream, h->adjw.p, words, mp, h->nw_off.p, h->nw_nbr.p);
-            HIPCHK(hipMemcpyAsync(nbr.data(), h->nw_nbr.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost, h->stream));
+            int* dst;
+            if (h->pin.used + (size_t)n_edges * 4 + 128 <= h->pin.cap) dst = h->pin.take<int>((size_t)n_edges);
+            else {  // (dense neighbourhoods: more edges than the scratch was sized for)
+                nbr_pageable.resize((size_t)n_edges);
+                dst = nbr_pageable.data();
+            }
+            HIPCHK(hipMemcpyAsync(dst, h->nw_nbr.p, (size_t)n_edges * 4, hipMemcpyDeviceToHost, h->stream));
             sync_stream(h, h->stream);
             HIPCHK(hipGetLastError());
+            nbr = dst;
         }
 
+        tph[3] = now_us();
         // ---- ordered expansion on the host: predecon.py:62-120, 242-267 (integer / graph work only) ----
         auto for_each_nw = [&](int q, auto&& fn) {  // the weighted neighbours of q in ascending (= dict) order
             for (long long e = nw_off[q]; e < nw_off[(size_t)q + 1]; ++e) fn(nbr[(size_t)e]);
         };
         std::vector<int8_t> cls(mp, 0);  // 0 'u', 1 'c', 2 'n'
         std::vector<int> queue;
+        h->clusters.mem.reserve((size_t)mp);
+        h->clusters.off.reserve((size_t)mp + 1);
         const int lam = p.pi;
         for (int seed = 0; seed < mp; ++seed) {
             if (cls[seed] != 0) continue;
             if (!core[seed]) { cls[seed] = 2; continue; }
-            HostCluster cl;
+            const size_t cl_begin = h->clusters.mem.size();
             queue.clear();
             for_each_nw(seed, [&](int x) { queue.push_back(x); });
             size_t head = 0;
@@ -2579,22 +2686,19 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                     if (cls[x] == 0) queue.push_back(x);
                     if (cls[x] == 0 || cls[x] == 2) {
                         cls[x] = 1;
-                        cl.members.push_back(x);
+                        h->clusters.mem.push_back(x);
                     }
                 });
             }
-            if (!cl.members.empty()) h->clusters.push_back(std::move(cl));  // predecon.py:83 (W > 0)
+            if (h->clusters.mem.size() > cl_begin) h->clusters.off.push_back((int)h->clusters.mem.size());  // predecon.py:83 (W > 0)
         }
         for (int i = 0; i < mp; ++i) h->n_core += core[i];
 
+        tph[4] = now_us();
         // ---- cluster CF sums in merge order + preferred dimensions on the device ----
         const int nc = (int)h->clusters.size();
         if (nc) {
-            std::vector<int> mem, off(1, 0);
-            for (auto& cl : h->clusters) {
-                mem.insert(mem.end(), cl.members.begin(), cl.members.end());
-                off.push_back((int)mem.size());
-            }
+            const std::vector<int>&mem = h->clusters.mem, &off = h->clusters.off;
             const size_t cd = (size_t)nc * d;
             h->mem_dev.ensure(mem.size()); h->off_dev.ensure(off.size());
             h->c_cf1.ensure(cd); h->c_cf2.ensure(cd); h->c_cen.ensure(cd); h->c_pref.ensure(cd); h->c_w.ensure(nc);
@@ -2605,10 +2709,15 @@ int cc_offline(cc_handle* h, int32_t* n_clusters, int8_t* out_core, int32_t* out
                                h->c_pref.p, h->c_w.p);
             sync_stream(h, h->stream);
         }
-        if (out_core) memcpy(out_core, core.data(), mp);
-        if (out_pdim) memcpy(out_pdim, pdim.data(), (size_t)mp * 4);
-        if (out_nn) memcpy(out_nn, nn.data(), (size_t)mp * 4);
-        if (out_nw) memcpy(out_nw, nw_cnt.data(), (size_t)mp * 4);
+        tph[5] = now_us();
+        if (h->trace)
+            fprintf(stderr, "[cc] offline phase, host wall time: list order %.0f us, pair kernels + read-back %.0f, neighbour lists %.0f, "
+                    "ordered expansion %.0f, cluster sums %.0f (%d pcores, %d clusters)\n", tph[1] - tph[0], tph[2] - tph[1], tph[3] - tph[2],
+                    tph[4] - tph[3], tph[5] - tph[4], mp, nc);
+        if (out_core) memcpy(out_core, core, mp);
+        if (out_pdim) memcpy(out_pdim, pdim, (size_t)mp * 4);
+        if (out_nn) memcpy(out_nn, nn, (size_t)mp * 4);
+        if (out_nw) memcpy(out_nw, nw_cnt, (size_t)mp * 4);
         if (n_clusters) *n_clusters = nc;
         return (int)CC_OK;
     });
@@ -2619,7 +2728,7 @@ int cc_num_core(cc_handle* h) { return h ? h->n_core : CC_ERR_BAD_ARG; }
 int cc_cluster_size(cc_handle* h, int32_t c)
 {
     if (!h || c < 0 || c >= (int)h->clusters.size()) return CC_ERR_BAD_ARG;
-    return (int)h->clusters[c].members.size();
+    return h->clusters.off[(size_t)c + 1] - h->clusters.off[(size_t)c];
 }
 
 int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, double* cf1, double* cf2, double* cen,
@@ -2627,10 +2736,10 @@ int cc_cluster_export(cc_handle* h, int32_t c, int64_t* members, double* w, doub
 {
     if (!h || c < 0 || c >= (int)h->clusters.size()) return CC_ERR_BAD_ARG;
     return guarded(h, [&]() {
-        const HostCluster& cl = h->clusters[c];
         const size_t d = (size_t)h->d;
+        const int a = h->clusters.off[(size_t)c], e = h->clusters.off[(size_t)c + 1];
         if (members)
-            for (size_t i = 0; i < cl.members.size(); ++i) members[i] = h->pcore_ids_host[cl.members[i]];
+            for (int i = a; i < e; ++i) members[i - a] = h->pcore_ids_host[(size_t)h->clusters.mem[(size_t)i]];
         if (w) HIPCHK(hipMemcpyAsync(w, h->c_w.p + c, 8, hipMemcpyDeviceToHost, h->stream));
         if (cf1) HIPCHK(hipMemcpyAsync(cf1, h->c_cf1.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
         if (cf2) HIPCHK(hipMemcpyAsync(cf2, h->c_cf2.p + (size_t)c * d, d * 8, hipMemcpyDeviceToHost, h->stream));
@@ -2645,7 +2754,7 @@ int cc_clusters_total_members(cc_handle* h)
 {
     if (!h) return CC_ERR_BAD_ARG;
     size_t tot = 0;
-    for (auto& cl : h->clusters) tot += cl.members.size();
+    tot = h->clusters.mem.size();
     return (int)tot;
 }
 
@@ -2655,15 +2764,11 @@ int cc_clusters_export(cc_handle* h, int64_t* members, int32_t* offsets, double*
     if (!h) return CC_ERR_BAD_ARG;
     return guarded(h, [&]() {
         const size_t nc = h->clusters.size(), d = (size_t)h->d;
-        size_t pos = 0;
-        for (size_t c = 0; c < nc; ++c) {
-            if (offsets) offsets[c] = (int32_t)pos;
-            for (int m : h->clusters[c].members) {
-                if (members) members[pos] = h->pcore_ids_host[m];
-                ++pos;
-            }
-        }
-        if (offsets) offsets[nc] = (int32_t)pos;
+        const size_t tot = h->clusters.mem.size();
+        if (offsets)
+            for (size_t c = 0; c <= nc; ++c) offsets[c] = (int32_t)h->clusters.off[c];
+        if (members)
+            for (size_t i = 0; i < tot; ++i) members[i] = h->pcore_ids_host[(size_t)h->clusters.mem[i]];
         if (nc == 0) return (int)CC_OK;
         if (w) HIPCHK(hipMemcpyAsync(w, h->c_w.p, nc * 8, hipMemcpyDeviceToHost, h->stream));
         if (cf1) HIPCHK(hipMemcpyAsync(cf1, h->c_cf1.p, nc * d * 8, hipMemcpyDeviceToHost, h->stream));
@@ -2904,8 +3009,8 @@ int cc_point_clusters(cc_handle* h, int32_t* out_idx)
         const long long n_uid = h->hc.outlier_last_id;
         std::vector<int32_t> map((size_t)std::max<long long>(n_uid, 1), -1);
         for (size_t c = 0; c < h->clusters.size(); ++c)
-            for (int m : h->clusters[c].members) {
-                const long long u = h->pcore_uid_host[(size_t)m];
+            for (int i = h->clusters.off[c]; i < h->clusters.off[c + 1]; ++i) {
+                const long long u = h->pcore_uid_host[(size_t)h->clusters.mem[(size_t)i]];
                 if (u >= 0 && u < n_uid) map[(size_t)u] = (int32_t)c;
             }
         h->pc_map.ensure(map.size());

@@ -134,13 +134,13 @@ __global__ void k_core_flags(PcoreView pv, int mp, int d, double eps_sq, double 
 // Euclidean distance = sqrt of the left-to-right sum of squares (the reference's np.linalg.norm is
 // platform-defined in the last ulp: nrm2 under numba, sqrt(dot) under numpy).
 // (p_base / p_end: the p rows of this launch - on the multi-GPU path a rank takes a block of p rows)
-#define CC_EPS_PCH 256
+#define CC_EPS_PCH 256  // p rows per workgroup on large tables; small ones take fewer (`pch`), so that the launch fills the machine
 #define CC_EPS_TP 32
 
 template <int DP>
 __global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict__ cen, int mp, int d, double eps,
                                                         unsigned long long* __restrict__ adj, int words, int p_base,
-                                                        int p_end)
+                                                        int p_end, int pch)
 {
     __shared__ __attribute__((aligned(16))) double s_p[CC_EPS_TP * DP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void k_eps_neighbours(const double* __restrict
     double cq[DP];
 #pragma unroll
     for (int i = 0; i < DP; ++i) cq[i] = (qvalid && i < d) ? cen[(size_t)q * d + i] : 0.0;
-    const int p0 = p_base + blockIdx.y * CC_EPS_PCH;
-    const int p1 = min(p_end, p0 + CC_EPS_PCH);
+    const int p0 = p_base + blockIdx.y * pch;
+    const int p1 = min(p_end, p0 + pch);
     for (int pt = p0; pt < p1; pt += CC_EPS_TP) {
         const int tp = min(CC_EPS_TP, p1 - pt);
         __syncthreads();

@@ -137,9 +137,13 @@ public:
         const long long trunc_batch = o.stat_truncated - prev_.stat_truncated;
         const int rounds_batch = rcur_;
         const long long unk_batch = o.stat_trunc_unknown - prev_.stat_trunc_unknown;
+        // (a window that stopped at a point whose decision could not be made - both snapshot candidates changed and no live
+        // version beats the bound - would stop there after any number of rounds: only windows whose decisions were still
+        // moving ask for one more)
+        const long long trunc_moving = trunc_batch - unk_batch;
         if (trunc_batch > 0 && nodirty_) {
             // points refused for want of the dirty scans: the next batch launches them again, nothing else changes
-        } else if (trunc_batch > 0) rcur_ = std::min(Rmax, std::max(used, rcur_) + 1);
+        } else if (trunc_moving > 0) rcur_ = std::min(Rmax, std::max(used, rcur_) + 1);
         else rcur_ = std::max(1, std::min(rcur_, used));
         // ---- window size ----
         //  - While many MCs are being created the validation of a window is quadratic in its size (their versions cannot
