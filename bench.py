@@ -55,6 +55,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39.3 T instruction-lanes/s
 PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")
+PMC_BENCH_STEP_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench_step.json")  # tools/pmc_bench_step.py: counted on bench.py itself
 PMC_VALU_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
 SCAN_SOURCES = ("cc_scan.h", "cc_common.h", "cc_div.h")  # what defines the snapshot-scan kernels the PMC files describe
 REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
@@ -74,9 +75,20 @@ def csrc_digest(names=None):
 
 
 def scan_digest():
-    """The sources of the snapshot-scan kernels alone: a change to the validation or offline kernels leaves the scan's
+    """The sources of the snapshot-scan kernels alone - and the host function that sets their launch geometry (sub-range
+    split, phase-B grouping, the row count from which phase A is a kernel of its own: launch_scan_dp in cc_api.hip; the
+    instructions per (wave, row) depend on it) -: a change to the validation or offline kernels leaves the scan's
     counters valid."""
-    return csrc_digest(SCAN_SOURCES)
+    m = hashlib.sha256(csrc_digest(SCAN_SOURCES).encode())
+    try:
+        with open(os.path.join(ROOT, "chronoclust_amd", "csrc", "cc_api.hip")) as f:
+            text = f.read()
+        a = text.index("void launch_scan_dp(")
+        b = text.index("void launch_scan(", a)
+        m.update(text[a:b].encode())
+    except (OSError, ValueError):
+        m.update(b"launch_scan_dp not found")
+    return m.hexdigest()
 
 
 def pmc_matches(pm):
@@ -140,6 +152,7 @@ def compact_line(full, detail_file=None):
         line["roofline"] = {
             "bound": rf.get("bound"), "kernel": str(rf.get("kernel", ""))[:120], "achieved": rf.get("achieved"),
             "peak": rf.get("peak"), "unit": str(rf.get("unit", ""))[:60], "frac": rf.get("frac"),
+            "step_frac": rf.get("step_frac"), "model_frac": (rf.get("model") or {}).get("frac"),
             "valu_busy": dom.get("valu_busy_fraction"), "effective_frac": (rf.get("effective") or {}).get("frac"),
             "hbm_frac": hbm.get("frac"), "hbm_achieved_gbs": hbm.get("achieved"), "hbm_peak_gbs": hbm.get("peak"),
             "traffic": rf.get("traffic"), "algorithmic_bytes": hbm.get("algorithmic_bytes_per_launch"),
@@ -153,6 +166,7 @@ def compact_line(full, detail_file=None):
                                 "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:140],
                                 "labels_match_gpu_prefix": cb.get("labels_match_gpu_prefix"),
                                 "all_cores_value": allc.get("value"), "all_cores": allc.get("cores"),
+                                "steady_value": (cb.get("steady") or {}).get("value"), "steady_rows": (cb.get("steady") or {}).get("rows"),
                                 "reference_py": ref.get("value")}
     ss = full.get("strong_scaling")
     if ss:
@@ -346,7 +360,7 @@ def set_params(h, cfg, n, d):
                  cfg["omicron"] * 0, ups, ups ** 2, delta, pi)
 
 
-def cpu_baseline(cfg, X, sample, cores, gpu_uid):
+def cpu_baseline(cfg, X, sample, cores, gpu_uid, gpu_tables=None, steady_sample=30000):
     """The oracle (oracle/chrono_oracle.c, a scalar C port of the reference's loop) on a prefix of the same stream:
     one thread, then one independent copy of the same work on every host core (the algorithm is a sequential chain,
     so cores can only be used by independent streams - as the GPU replicas do)."""
@@ -378,6 +392,25 @@ def cpu_baseline(cfg, X, sample, cores, gpu_uid):
                             "note": "%d independent copies of the same sample, one thread per usable host core, "
                                     "ctypes threads; the sequential chain of one stream cannot use more than one "
                                     "core" % cores}
+    if gpu_tables is not None and steady_sample > 0:
+        # The C port in the STEADY state - the table the stream ends on (5 000 pcore microclusters at C2), every point joins
+        # an existing microcluster: what the GPU path's steady state (tools/steady.py) stands beside.  The final tables of
+        # the GPU run are injected (co_inject_mc, list order), the same stream's first points run again on them (same
+        # daystamp: no decay), one thread.
+        s_o = O.OracleHDDStream(cfg)
+        s_o.set_dataset_dependent_parameters(X)
+        s_o._push_params()
+        n_rows = 0
+        for kind, t in ((O.PCORE, gpu_tables[0]), (O.OUTLIER, gpu_tables[1])):
+            for i in range(len(t["id"])):
+                s_o.inject(kind, t["cf1"][i], t["cf2"][i], t["cen"][i], t["pref"][i], t["w"][i], t["id"][i], t["uid"][i])
+            n_rows += len(t["id"])
+        ms = min(steady_sample, X.shape[0])
+        t3 = time.perf_counter()
+        s_o.online_microcluster_maintenance(X[:ms], 0, reset_param=False, offline=False)
+        st = time.perf_counter() - t3
+        out["steady"] = {"value": ms / st, "unit": "points/s", "cores": 1, "rows": n_rows,
+                         "sample": "%d points on the stream's final table (%d microclusters, injected from the GPU run), one thread" % (ms, n_rows)}
     # the Python reference itself, measured in the build container (1 core, d = 20, 100 - 400 microclusters;
     # BASELINE.md section 2): it cannot be imported on the GPU box
     try:
@@ -508,8 +541,8 @@ def scan_roofline(acc, d, kernel):
     full = (acc["pruned_scan_full_rows"] / acc["pruned_scan_rows"]) if acc.get("pruned_scan_rows") else 0.0
     # a pruned launch of this run may complete more rows than the steady-state launches the counters were taken on (the
     # first pruned windows of a stream): every completed row beyond that share is charged the plain scan's row
-    if full_pmc is None:  # (files of round 4 did not record their own share: the figures their runs printed)
-        full_pmc = 0.013 if d <= 20 else 0.0013
+    if full_pmc is None:  # (a file that does not record the share of rows its own launches completed: no extra charge)
+        full_pmc = full
     extra = max(0.0, full - full_pmc) * pm["k_scan_u"]["valu_instructions_per_wave_row"]
     per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p") if k in pm) + extra
     lanes_u = pairs_u * pm["k_scan_u"]["valu_instructions_per_wave_row"]
@@ -530,6 +563,50 @@ def scan_roofline(acc, d, kernel):
                                "busy fractions are of the kernel's own run time, `frac` above is over this run's launches "
                                "(short start-up windows and co-running validation kernels included)"}
     return out
+
+
+def counted_on_bench(rf, cfg, scan_ms_per_step, ms_per_step):
+    """The roofline from instructions COUNTED on the bench itself (tools/pmc_bench_step.py: rocprofv3 --pmc SQ_INSTS_VALU over
+    `bench.py --steps 1 --warmup 1`, per kernel): the snapshot-scan kernels' instruction-lanes of one step / this run's
+    HIP-event scan time per step -> achieved / frac; the lanes of ALL kernels of a step / this run's step time -> step_frac.
+    Every step is the same deterministic work, so the counts of that pass are this run's; they are quoted only for the
+    csrc/ digest and the workload they were counted on.  The model figure (instructions per (wave, row) of full windows
+    running alone x this run's pairs) stays beside it as `model`."""
+    import glob
+    why = "no profiles/rNN_pmc_bench_step.json"
+    for path in sorted(glob.glob(PMC_BENCH_STEP_GLOB), reverse=True):
+        try:
+            with open(path) as f:
+                pm = json.load(f)
+        except (OSError, ValueError):
+            continue
+        name = os.path.basename(path)
+        if pm.get("csrc_sha256") != csrc_digest():
+            why = "profiles/%s was counted on other kernel sources (csrc/ digest differs)" % name
+            continue
+        if (pm.get("points"), pm.get("dim"), pm.get("microclusters"), pm.get("window")) != (
+                cfg["points"], cfg["dim"], cfg["microclusters"], cfg["window"]):
+            why = "profiles/%s was counted on another workload" % name
+            continue
+        lanes_scan = pm["snapshot_scan"]["instruction_lanes_per_step"]
+        lanes_all = pm["all_kernels"]["instruction_lanes_per_step"]
+        achieved = lanes_scan / (scan_ms_per_step * 1e-3) / 1e12
+        rf["model"] = {"achieved": rf.get("achieved"), "frac": rf.get("frac"), "pmc_source": rf.get("pmc_source"),
+                       "derived": rf.get("derived")}
+        rf["achieved"], rf["frac"] = achieved, achieved / FP64_VALU_PEAK_TOPS
+        rf["step_frac"] = lanes_all / (ms_per_step * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS
+        if rf["model"]["frac"]:
+            rf["model_over_counted"] = rf["model"]["frac"] / rf["frac"]
+        rf["pmc_source"] = "profiles/" + name
+        rf["derived"] = "achieved = SQ_INSTS_VALU x 64 lanes of the snapshot-scan kernels of ONE bench step, counted by rocprofv3 " \
+                        "on bench.py itself (pmc_source) / this run's HIP-event scan time per step; step_frac = the same count over " \
+                        "ALL kernels of the step / this run's step time / peak"
+        rf["counted"] = {"scan_instruction_lanes_per_step": lanes_scan, "all_instruction_lanes_per_step": lanes_all,
+                         "scan_launches_per_step_counted": pm["snapshot_scan"]["launches_per_step"],
+                         "kernels_by_lanes": {k: v["instruction_lanes_per_step"] for k, v in list(pm["kernels"].items())[:10]}}
+        return
+    rf["step_frac"] = None
+    rf["counted_note"] = "not quoted: %s; run tools/r6_pmc_bench_step.sh on the GPU box" % why
 
 
 def scan_kernel_name(s, d):
@@ -916,6 +993,7 @@ def main():
                 "launch_note": "every launch of the kernel is timed with HIP events on its stream: lookahead scans "
                                "(second stream, beside the validation kernels of the previous window, including the "
                                "few that go unused) and in-place scans (short windows of the start-up phase included)"})
+            counted_on_bench(out["roofline"], out["config"], scan_ms / args.steps, out["ms_per_step"])
             # HBM traffic of the same kernel from the rocprofv3 PMC passes of this round (FETCH_SIZE / WRITE_SIZE in
             # separate runs); only quoted when it was measured on this workload shape AND on these kernel sources
             pmc, name = newest_pmc(PMC_TRAFFIC_GLOB)
@@ -931,7 +1009,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not args.only_leg:
             # (the GPU box gives a one-GPU job 16 of the host's cores; os.cpu_count() reports the whole machine)
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            out["cpu_baseline"] = cpu_baseline(cfg, X, args.cpu_sample, max(1, min(usable, args.cpu_cores)), uid)
+            from chronoclust_amd import _lib as _L
+            out["cpu_baseline"] = cpu_baseline(cfg, X, args.cpu_sample, max(1, min(usable, args.cpu_cores)), uid,
+                                               gpu_tables=(h.export(_L.PCORE), h.export(_L.OUTLIER)))
             out["cpu_baseline"]["host_cpu_count"] = os.cpu_count()
     h.close()
     del X

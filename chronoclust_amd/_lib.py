@@ -163,6 +163,22 @@ def load():
     return _lib
 
 
+HOST_ONLY_SYMBOLS = ("cc_policy_replay", "cc_policy_seq_rate_guess", "cc_shard_rows", "cc_format_points_csv")
+
+
+def load_host_only(path):
+    """Binds a library that holds only the entry points that are plain host code (csrc/cc_host_abi.inc built by itself: the
+    sanitizer builds of tests/host_san/) in the place of the HIP library, so that policy_replay, shard_rows and
+    format_points_csv of this module drive it.  Test infrastructure: nothing that needs a handle works afterwards."""
+    global _lib
+    lib = C.CDLL(path)
+    for name in HOST_ONLY_SYMBOLS:
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = SYMBOLS[name]
+    _lib = lib
+    return lib
+
+
 def _f64(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
 

@@ -9,7 +9,7 @@ import hashlib
 
 # the one translation unit first (it includes every header beside it); every file under csrc/ counts for staleness
 SOURCES = [os.path.join(_HERE, "csrc", "cc_api.hip")] + sorted(
-    p for p in glob.glob(os.path.join(_HERE, "csrc", "*")) if p.endswith((".h", ".hip")) and not p.endswith("cc_api.hip"))
+    p for p in glob.glob(os.path.join(_HERE, "csrc", "*")) if p.endswith((".h", ".hip", ".inc")) and not p.endswith("cc_api.hip"))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "chronoclust_hip.h")
 # bit-exactness: no FMA contraction, no fast-math anywhere (host or device)
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]

@@ -2978,16 +2978,6 @@ int cc_get_relaxed_stats(cc_handle* h, cc_relaxed_stats* out)
     return CC_OK;
 }
 
-int cc_shard_rows(int32_t n, int32_t world, int32_t rank, int32_t unit, int32_t* lo, int32_t* hi)
-{
-    if (n < 0 || world < 1 || rank < 0 || rank >= world || unit < 1 || !lo || !hi) return CC_ERR_BAD_ARG;
-    int a = 0, b = 0;
-    cc_shard_range(n, world, rank, unit, &a, &b);
-    *lo = a;
-    *hi = b;
-    return CC_OK;
-}
-
 int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows)
 {
     if (!h) return CC_ERR_BAD_ARG;
@@ -3025,35 +3015,6 @@ int cc_point_clusters(cc_handle* h, int32_t* out_idx)
     });
 }
 
-int64_t cc_format_points_csv(const double* values, int64_t n, int32_t d, int64_t first_id, const int32_t* label_idx,
-                             const char* label_bytes, const int32_t* label_offsets, int32_t n_labels, char* out,
-                             int64_t cap)
-{
-    if (!values || n < 0 || d < 0 || !label_idx || !label_bytes || !label_offsets || n_labels < 1 || !out) return CC_ERR_BAD_ARG;
-    char* o = out;
-    char* const end = out + cap;
-    int max_label = 0;
-    for (int i = 0; i < n_labels; ++i) max_label = std::max(max_label, label_offsets[i + 1] - label_offsets[i]);
-    const int64_t row_max = 24 + 1 + max_label + (int64_t)d * 33 + 2;
-    for (int64_t r = 0; r < n; ++r) {
-        if (end - o < row_max) return CC_ERR_OOM;  // the caller's buffer is too small
-        o += cc::format_i64(first_id + r, o);
-        *o++ = ',';
-        int li = label_idx[r];
-        if (li < 0 || li >= n_labels) li = n_labels - 1;  // (-1: the last entry, "None")
-        const int ll = label_offsets[li + 1] - label_offsets[li];
-        memcpy(o, label_bytes + label_offsets[li], (size_t)ll);
-        o += ll;
-        const double* v = values + r * d;
-        for (int i = 0; i < d; ++i) {
-            *o++ = ',';
-            if (v[i] == v[i]) o += cc::format_repr(v[i], o);  // (NaN: an empty field, DataFrame.to_csv's na_rep)
-        }
-        *o++ = '\n';
-    }
-    return (int64_t)(o - out);
-}
-
 int cc_sync(cc_handle* h)
 {
     if (!h) return CC_ERR_BAD_ARG;
@@ -3065,24 +3026,7 @@ int cc_sync(cc_handle* h)
     });
 }
 
-int cc_policy_replay(const cc_policy_config* cfg, cc_policy_carry* carry, int64_t start_cursor, int32_t start_rows,
-                     const cc_policy_obs* obs, int32_t n, cc_policy_decision* out)
-{
-    if (!cfg || !carry || n < 0 || (n > 0 && !obs) || !out) return CC_ERR_BAD_ARG;
-    cc::WindowPolicy policy(*cfg, *carry);
-    out[0] = policy.start(start_cursor, start_rows);
-    for (int i = 0; i < n; ++i)
-        out[i + 1] = obs[i].after_sequential ? policy.after_sequential(obs[i].cursor, obs[i].m_rows) : policy.after_batch(obs[i]);
-    *carry = policy.carry();
-    return CC_OK;
-}
-
-double cc_policy_seq_rate_guess(int32_t d, int32_t m_rows, int32_t allow_seq_r, int32_t allow_seq_g)
-{
-    if (d < 1 || d > CC_MAX_DIM || m_rows < 0) return -1.0;
-    const int seq_cap = d > CC_WINDOW_MAX_DIM ? 0 : cc_seq_cap_rows(d);
-    return cc::seq_rate_guess(d, m_rows, seq_cap, allow_seq_r != 0, allow_seq_g != 0);
-}
+#include "cc_host_abi.inc"
 
 int cc_get_stats(cc_handle* h, cc_stats* out)
 {

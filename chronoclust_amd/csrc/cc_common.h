@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "cc_host.h"
+
 #define CC_KIND_PCORE 0
 #define CC_KIND_OUTLIER 1
 #define CC_KIND_DEAD 2
@@ -282,24 +284,7 @@ struct Ctl {
 #define CC_FLAG_SPARSE 64  // the point is on the round's list of points whose dirty scans run point by point (the sparse
                            // dirty scans: compacted tiles of such points, both kinds covered) although its tile's did not
 
-// Exact multi-GPU path: the block [lo, hi) of n rows that rank `rank` of `world` takes, in whole
-// units of `unit` rows (1: table rows of a snapshot scan, current pcores of the association argmin; 64: p rows of
-// the offline pair matrices = whole words of the adjacency bitmask).  Every rank gets the same share
-// ceil(units / world) * unit, so the blocks tile [0, n) in rank order and all-gathers have one block size.
-__host__ __device__ inline int cc_shard_share(int n, int world, int unit)
-{
-    const int units = (n + unit - 1) / unit;
-    return ((units + world - 1) / world) * unit;
-}
-__host__ __device__ inline void cc_shard_range(int n, int world, int rank, int unit, int* lo, int* hi)
-{
-    const int share = cc_shard_share(n, world, unit);
-    const long long a = (long long)rank * share;
-    *lo = (int)(a < n ? a : n);
-    const long long b = a + share;
-    *hi = (int)(b < n ? b : n);
-}
-
+// (cc_shard_share / cc_shard_range: cc_host.h - plain C++, shared with the host-only sanitizer build)
 __host__ __device__ inline bool cand_less(double ad, int ak, double bd, int bk)
 {
     return ad < bd || (ad == bd && ak < bk);

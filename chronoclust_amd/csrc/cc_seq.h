@@ -15,10 +15,8 @@
 // exact, so switching between them between windows never changes a result.
 // ---------------------------------------------------------------------------------
 
-#define CC_SEQ_DOUBLES 6600  // LDS image of the table: (4 d + 5) doubles per row
+// (CC_SEQ_DOUBLES - the LDS image of the table: (4 d + 5) doubles per row - and cc_seq_cap_rows: cc_host.h)
 #define CC_SEQ_CHUNK_DOUBLES 512  // points staged ahead: 512 / d of them (at most 64), eight doubles per lane in flight
-
-__host__ __device__ inline int cc_seq_cap_rows(int d) { return CC_SEQ_DOUBLES / (4 * d + 5); }
 
 __device__ __forceinline__ double cc_readlane_f64(double v, int l)
 {

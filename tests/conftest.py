@@ -18,3 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _library_built_from_these_sources():
+    """The loader refuses a library that was not built from the sources beside it (chronoclust_amd.build.is_stale: content
+    hash, not file times).  Build it once per session when it is stale - hipcc cross-compiles for gfx950 without a GPU;
+    on the GPU box the prebuilt library and its stamp travel with the tree and nothing is compiled."""
+    from chronoclust_amd import build
+    if build.needs_build():
+        build.build()
+    yield

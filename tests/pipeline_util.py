@@ -1,8 +1,27 @@
 """The per-timepoint pipeline of chronoclust/app.py:157-216 without file I/O: HDDStream, cluster records,
 TrackByLineage, TrackByHistoricalAssociation.  Shared by the full-size GPU tests (test infrastructure)."""
+import contextlib
+import os
 from decimal import ROUND_HALF_UP, Decimal
 
 import numpy as np
+
+
+@contextlib.contextmanager
+def knobs(**env):
+    """Code-path knobs of the library (CHRONOCLUST_HIP_*) around the creation of a handle: they are read
+    when a handle is created."""
+    kv = {k: str(v) for k, v in env.items()}
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update(kv)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 class _RecordingHandle(object):

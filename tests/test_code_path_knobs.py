@@ -33,6 +33,7 @@ KNOBS = {
     "lean guessed scans off": dict(CHRONOCLUST_HIP_LEAN=0),  # k_missed and the seeded chain behind every guessed scan
     "quiet rounds off": dict(CHRONOCLUST_HIP_QUIET=0),  # k_decide re-derives every decision of every validation round
     "heavy rows off": dict(CHRONOCLUST_HIP_HEAVY=0),  # k_decide's atomics also for rows with thousands of claimants
+    "creator links off": dict(CHRONOCLUST_HIP_LINK=0),  # round 0 does not link the points that decide "create": the validation rounds retarget them
     "long chains not laid out": dict(CHRONOCLUST_HIP_LONGPREP=0),  # k_chain_long alone walks them, one workgroup per chain
     # phase A of the pruned scan as a kernel of its own (k_scan_a + k_scan_p<MASKED>) whatever the table size (default: from
     # 10 000 rows on), with pruning forced so that the small tables of these suites run it at all

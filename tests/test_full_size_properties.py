@@ -4,6 +4,7 @@ would need minutes: size-independent properties of the exact algorithm, plus an 
 import numpy as np
 import pytest
 
+import pipeline_util as P
 import scenarios
 
 pytestmark = pytest.mark.gpu
@@ -63,6 +64,36 @@ def test_c2_labels_do_not_depend_on_window_or_segments(c2):
             for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
                 assert np.array_equal(a[key], b[key])
         assert [c.members_in_merge_order for c in g.final_clusters] == [c.members_in_merge_order for c in h.final_clusters]
+
+
+@pytest.mark.parametrize("env", [dict(CHRONOCLUST_HIP_PRUNE=0), dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANA=2),
+                                 dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_GUESS=0), dict(CHRONOCLUST_HIP_LINK=0, CHRONOCLUST_HIP_NODIRTY=0)],
+                         ids=["plain_scans", "pruned_forced_split", "seeded_thresholds_only", "no_links_dirty_scans_always"])
+def test_c2_pruned_steady_state_equals_plain_scans_at_full_size(c2, env):
+    """The pruned chain at C2's own size - 5 000 rows, 32 768-point windows, guessed / lean thresholds, lookahead: the 800 000
+    points behind the start-up phase - against the PLAIN scan of every window (CHRONOCLUST_HIP_PRUNE=0), against the pruned
+    chain forced from the first window on in its two-kernel form, and against seeded thresholds only: bit for bit.  (The
+    tunings of the test above all prune; a threshold bug that only shows at full size would be invariant under them.
+    tools/full_oracle.py runs the whole stream through the oracle - minutes of CPU, recorded under profiles/.)"""
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    X, cfg, h = c2
+    assert h.stats()["scan_p_launches"] > 20  # (the default run's steady state is pruned)
+    with P.knobs(**env):
+        g = HDDStream(cfg)
+    g.online_microcluster_maintenance(X, 0)
+    st = g.stats()
+    if env.get("CHRONOCLUST_HIP_PRUNE") == 0:
+        assert st["scan_p_launches"] == 0 and st["scan_u_launches"] > 20
+    if env.get("CHRONOCLUST_HIP_PRUNE") == 2:
+        assert st["scan_p_launches"] == st["scan_u_launches"]
+    if env.get("CHRONOCLUST_HIP_LINK") == 0:
+        assert st["link_launches"] == 0 and h.stats()["link_launches"] > 0
+    assert np.array_equal(g.labels_uid, h.labels_uid)
+    for kind in (0, 1):
+        a, b = g.table(kind), h.table(kind)
+        for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+            assert np.array_equal(a[key], b[key]), (kind, key)
+    assert [c.members_in_merge_order for c in g.final_clusters] == [c.members_in_merge_order for c in h.final_clusters]
 
 
 def test_c2_prefix_matches_oracle(c2):

@@ -73,6 +73,17 @@ def test_c3_results_do_not_depend_on_window_or_lookahead(c3, tuning):
     P.same_results(P.run_pipeline(Xs, cfg, tuning=tuning), res)
 
 
+def test_c3_pruned_scans_equal_plain_scans(c3):
+    """All five timepoints with CHRONOCLUST_HIP_PRUNE=0 (every window's snapshot scan the plain k_scan_u): labels, tables,
+    merge order, lineage and association strings equal the default run's, whose steady state is pruned."""
+    Xs, cfg, res = c3
+    assert all(r["stats"]["scan_p_launches"] > 0 for r in res)
+    with P.knobs(CHRONOCLUST_HIP_PRUNE=0):
+        plain = P.run_pipeline(Xs, cfg)
+    assert all(r["stats"]["scan_p_launches"] == 0 for r in plain)
+    P.same_results(plain, res)
+
+
 def test_c3_array_built_cluster_records_equal_object_built(c3):
     """HDDStream.cluster_records (arrays) against the reference's per-object construction (app.py:179-190) at
     5 000 clusters: same weights, pcore id order, lineage and association strings."""
@@ -142,6 +153,56 @@ def test_shape_results_do_not_depend_on_window_or_lookahead(shape):
     name, X, cfg, res = shape
     for tuning in SHAPES[name][4]:
         P.same_results(P.run_pipeline([X], cfg, tuning=tuning), res)
+
+
+def test_c4_shape_pruned_scans_equal_plain_scans(shape):
+    name, X, cfg, res = shape
+    if name != "C4":
+        pytest.skip("the C5 shape's plain scans take minutes: test_c5_shape_pruned_equals_plain_on_the_settled_table, tools/full_oracle.py c5plain")
+    with P.knobs(CHRONOCLUST_HIP_PRUNE=0):
+        plain = P.run_pipeline([X], cfg)
+    assert plain[0]["stats"]["scan_p_launches"] == 0 and res[0]["stats"]["scan_p_launches"] > 0
+    P.same_results(plain, res)
+
+
+def test_c5_shape_pruned_equals_plain_on_the_settled_table():
+    """50 000 rows x 40 dimensions, full windows, lookahead: the split pruned scan (k_scan_a + k_scan_p<MASKED>, the default from
+    10 000 rows on), the one-kernel form and the PLAIN scan over the same 262 144 fresh points on the same settled table -
+    bit for bit.  The table is settled by the default path (2 M points); the other handles take it over through the
+    checkpoint arrays (cc_inject_bulk: another row numbering, the same lists), so the plain scans - 20 us per point at this
+    shape - only run over the stretch that is compared.  (The whole 2 M stream with plain scans: tools/full_oracle.py c5plain.)"""
+    from chronoclust_amd.clustering.hddstream import HDDStream
+    n, d, g, m = 2_000_000, 40, 50_000, 262_144
+    X = scenarios.make_blobs(42, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    centres = np.random.default_rng(42).uniform(0.1, 0.9, (g, d))  # (make_blobs(42, ..) draws its centres first)
+    rng = np.random.default_rng(4242)
+    Y = np.ascontiguousarray(np.clip(centres[rng.integers(0, g, m)] + rng.normal(0.0, 0.01, (m, d)), 0.0, 1.0))
+    base = HDDStream(cfg)
+    base.online_microcluster_maintenance(X, 0)
+    state = base.get_state()
+    base.online_microcluster_maintenance(Y, 0, reset_param=False)
+    st0 = base.stats()
+    runs = {}
+    for name, env in (("plain", dict(CHRONOCLUST_HIP_PRUNE=0)), ("one kernel", dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANA=0)),
+                      ("split", dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANA=2))):
+        with P.knobs(**env):
+            h = HDDStream(cfg)
+        h.set_state(state)
+        h._set_dataset_dependent_parameters(X)  # (mu of the 2 M timepoint)
+        s0 = h.stats()
+        h.online_microcluster_maintenance(Y, 0, reset_param=False)
+        s1 = h.stats()
+        runs[name] = (s1["scan_p_launches"] - s0["scan_p_launches"], s1["scan_u_launches"] - s0["scan_u_launches"])
+        assert np.array_equal(h.labels_uid, base.labels_uid), name
+        for kind in (0, 1):
+            a, b = h.table(kind), base.table(kind)
+            for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
+                assert np.array_equal(a[key], b[key]), (name, kind, key)
+        assert [c.members_in_merge_order for c in h.final_clusters] == [c.members_in_merge_order for c in base.final_clusters]
+    assert runs["plain"][0] == 0 and runs["plain"][1] >= m // 32768
+    assert runs["one kernel"][0] == runs["one kernel"][1] > 0 and runs["split"][0] == runs["split"][1] > 0
+    assert st0["scan_p_launches"] > 0 and st0["rows"] == g
 
 
 def test_shape_prefix_matches_oracle(shape):

@@ -4,7 +4,7 @@ checks prefixes only).  Test infrastructure: the oracle is the checker here, the
   python3 tools/full_oracle.py c2         C2 (1 M x 20, 5 000 microclusters): the WHOLE stream through the C oracle in one
                                           thread - all 10^6 labels, both tables, the merge-ordered clusters - against the HIP
                                           path's single call.
-  python3 tools/full_oracle.py c5tail     a C5-shaped stream (1 M x 40, 50 000 microclusters): the SECOND half - the pruned
+  python3 tools/full_oracle.py c5tail     a C5-shaped stream (2 M x 40, 50 000 microclusters): the last 40 % - the pruned
                                           scans on a 50 000-row table, full windows, lookahead - replayed by the oracle from
                                           the GPU's own mid-stream tables (co_inject_mc), chunk by chunk on all host cores:
                                           chunk c starts from the HIP path's state after chunk c - 1 and must reproduce its
@@ -105,10 +105,11 @@ def c5_stream(n):
 
 def run_c5tail():
     from oracle import oracle as O
-    n = int(os.environ.get("N", 1_000_000))
-    half = n // 2
+    n = int(os.environ.get("N", 2_000_000))
+    half = int(n * float(os.environ.get("TAIL_FROM", "0.6")))  # (40 points per blob: the table has settled by ~1.2 M, the scans are pruned from there)
     X, cfg = c5_stream(n)
-    workers = int(os.environ.get("WORKERS", max(1, (os.cpu_count() or 2) - 1)))
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 2)
+    workers = int(os.environ.get("WORKERS", max(1, usable - 1)))
     n_chunks = int(os.environ.get("CHUNKS", workers))
     edges = [half + (n - half) * c // n_chunks for c in range(n_chunks + 1)]
     # the single call: what a user runs
@@ -134,8 +135,9 @@ def run_c5tail():
     for kind, nm in ((0, "pcore"), (1, "outlier")):
         check("chunked HIP run == single call: %s table" % nm, same_tables(states[-1][nm], single.table(kind)),
               table_sha(states[-1][nm]))
-    print("rows at the half-way point: %d pcore + %d outlier; snapshot scans pruned / all, cumulative per chunk: %s" % (
-        len(states[0]["pcore"]["id"]), len(states[0]["outlier"]["id"]), pruned), flush=True)
+    print("rows at point %d: %d pcore + %d outlier; snapshot scans pruned / all, cumulative per chunk: %s" % (
+        half, len(states[0]["pcore"]["id"]), len(states[0]["outlier"]["id"]), pruned), flush=True)
+    check("the replayed stretch runs on pruned scans", pruned[-1][0] - pruned[0][0] >= (pruned[-1][1] - pruned[0][1]) * 0.9, str(pruned[-1]))
 
     def replay(c):
         t0 = time.time()
