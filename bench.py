@@ -177,6 +177,9 @@ def compact_line(full, detail_file=None):
                 legs[name] = {k: leg.get(k) for k in ("value", "ms_per_step", "n_gpus", "rccl_ranks_seen",
                                                      "all_ranks_bit_identical", "semantics", "sharded_windows_per_step",
                                                      "agreement_with_exact_by_cluster", "predicted_value") if leg.get(k) is not None}
+                st = leg.get("split_threshold")
+                if st:
+                    legs[name]["split_threshold"] = st.get("row_dims_plain_scan")
         line["strong_scaling"] = dict(legs, unit="points/s of ONE stream on all n_gpus ranks")
     for name in LEG_NAMES:
         if isinstance(full.get(name), dict) and "error" in full[name]:
@@ -665,7 +668,11 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     else:  # one rank, no group: what every rank's library says about itself (cc_comm_info), gathered like the others
         seen = [int(x) for x in group.all_gather_bytes(b"%d" % h.comm_info()["world"])]
     # the split threshold of this leg (the library's own default is the same figure): stated in the line below
-    h.set_shard_thresholds(0 if force_split else args.shard_min_row_dims, 0 if force_split else -1)
+    # (default: the thresholds cc_comm_init_rccl derived from its own measurement of this group's all-gather and scan -
+    # cc_comm_calibrate; a group of one keeps the library's constant)
+    h.set_shard_thresholds(0 if force_split else (args.shard_min_row_dims if args.shard_min_row_dims is not None else -1),
+                           0 if force_split else -1)
+    thresholds = h.stats()
     set_params(h, cfg, n, d)
     h.points_upload(X)
     del X
@@ -701,7 +708,14 @@ def exact_leg(args, rank, world, local_rank, group, sync, n, d, g, seed, label, 
     return {
         "workload": "%s: ONE stream, 1 timepoint, %dx%d synthetic blobs, %d microclusters, exact sequential "
                     "semantics; online + offline phases per step; every rank holds the table and the points%s" % (
-                        label, n, d, g, split_note(s, info, world, d, 0 if force_split else args.shard_min_row_dims)),
+                        label, n, d, g, split_note(s, info, world, d, 0 if force_split else int(thresholds["split_threshold_row_dims"]))),
+        "split_threshold": {"row_dims_plain_scan": int(thresholds["split_threshold_row_dims"]),
+                            "row_dims_pruned_chain": int(thresholds["split_threshold_row_dims_pruned"]),
+                            "measured_allgather_us": thresholds["calib_allgather_us"],
+                            "measured_scan_ns_per_row_dim": thresholds["calib_scan_ns_per_row_dim"],
+                            "source": "forced (0)" if force_split else ("--shard-min-row-dims" if args.shard_min_row_dims is not None else
+                                      "cc_comm_calibrate: all-gather of a window's records x world / (world - 1) / plain scan per (row, dim), group maxima; "
+                                      "a group of one keeps the library's constant")},
         "value": multi.one_stream_rate(n, args.stream_steps, elapsed), "unit": "points/s", "scaling": "strong",
         "n_gpus": world, "rccl_ranks_seen": seen, "steps": args.stream_steps, "warmup": args.stream_warmup,
         "ms_per_step": 1e3 * elapsed / args.stream_steps,
@@ -866,8 +880,9 @@ def main():
     ap.add_argument("--no-c2-legs", action="store_true", help="skip the two C2-shaped strong-scaling legs")
     ap.add_argument("--only-leg", default=None, help="profiling: only this leg, after a token headline (20 000 points, 100 microclusters, no CPU baseline)")
     ap.add_argument("--dry-launch", action="store_true", help="the ranks only rendezvous and rank 0 prints who came (no GPU is touched)")
-    ap.add_argument("--shard-min-row-dims", type=int, default=400_000,
-                    help="one-stream legs: a snapshot scan is split over the ranks from this many (row, dim) entries on")
+    ap.add_argument("--shard-min-row-dims", type=int, default=None,
+                    help="one-stream legs: a snapshot scan is split over the ranks from this many (row, dim) entries on "
+                         "(default: what the library measured when the group was formed, cc_comm_calibrate)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         # no launcher: start the N ranks from here (nothing in this process has loaded the HIP library)
@@ -1072,7 +1087,7 @@ def main():
                 out["strong_scaling"][name] = {
                     k: leg.get(k) for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks_seen", "transport",
                                             "sharded_windows_per_step", "pruned_scan_launches_per_step",
-                                            "all_ranks_bit_identical", "agreement_with_exact_by_cluster") if k in leg}
+                                            "all_ranks_bit_identical", "agreement_with_exact_by_cluster", "split_threshold") if k in leg}
                 out["strong_scaling"][name]["semantics"] = "relaxed" if "relaxed" in name else "exact"
         # the ranks must agree on whether to go on: one that failed may have left the others' group
         failed = not group.all_equal(b"ok" if "error" not in leg else b"failed:" + str(rank).encode()) or "error" in leg

@@ -43,7 +43,10 @@ class CcStats(C.Structure):
                 ("scan_g_launches", C.c_int64), ("missed_points", C.c_int64), ("probe_launches", C.c_int64),
                 ("seq_r_points", C.c_int64), ("heavy_launches", C.c_int64),
                 ("scan_lean_launches", C.c_int64), ("long_prepared", C.c_int64), ("long_replayed", C.c_int64),
-                ("seq_g_points", C.c_int64), ("link_launches", C.c_int64)]
+                ("seq_g_points", C.c_int64), ("link_launches", C.c_int64),
+                ("scan_p2_launches", C.c_int64),
+                ("calib_allgather_us", C.c_double), ("calib_scan_ns_per_row_dim", C.c_double),
+                ("split_threshold_row_dims", C.c_int64), ("split_threshold_row_dims_pruned", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -53,7 +56,7 @@ class CcPolicyConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
                                          "allow_sparse", "allow_guess", "allow_probe")] + \
-               [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64)]
+               [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64), ("shard_min_row_dims_pruned", C.c_int64)]
 
 
 class CcPolicyCarry(C.Structure):
@@ -126,6 +129,7 @@ SYMBOLS = {
     "cc_comm_unique_id": (C.c_int, [C.c_char_p]),
     "cc_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
     "cc_comm_init_local": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "cc_comm_calibrate": (C.c_int, [C.c_void_p]),
     "cc_comm_destroy": (C.c_int, [C.c_void_p]),
     "cc_comm_info": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p]),
     "cc_comm_set_relaxed": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -499,6 +503,15 @@ class Handle(object):
         if len(unique_id) != COMM_ID_BYTES:
             raise ValueError("unique_id must be %d bytes" % COMM_ID_BYTES)
         self._check(self._lib.cc_comm_init_rccl(self._h, bytes(unique_id), int(rank), int(world)))
+
+    def comm_calibrate(self):
+        """Measures the all-gather of a window's records and a plain scan and derives the split thresholds from them
+        (cc_comm_calibrate; collective: every rank of the group calls it - the members of an in-process group from their
+        own threads; cc_comm_init_rccl has done it already).  Returns the measured figures and the thresholds."""
+        self._check(self._lib.cc_comm_calibrate(self._h))
+        s = self.stats()
+        return {k: s[k] for k in ("calib_allgather_us", "calib_scan_ns_per_row_dim", "split_threshold_row_dims",
+                                  "split_threshold_row_dims_pruned")}
 
     def comm_destroy(self):
         self._check(self._lib.cc_comm_destroy(self._h))

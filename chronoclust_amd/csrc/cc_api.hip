@@ -204,6 +204,7 @@ struct cc_handle {
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
+    bool allow_scan_p2 = true;  // CHRONOCLUST_HIP_SCANP2=0: the pruned scan of a window as k_scan_p (one point per lane) instead of k_scan_p2
     bool allow_link = true;     // CHRONOCLUST_HIP_LINK=0: round 0 does not link the points that decide "create" among themselves (cc_link.h)
     DevBuf<int> link_near;      // [window] k_link_scan: per window point that decided "create", the earliest such point before it that would absorb it
     bool allow_heavy = true;    // CHRONOCLUST_HIP_HEAVY=0: k_decide's atomics also for rows that take a large share of a window
@@ -273,6 +274,8 @@ struct cc_handle {
     // a snapshot scan is split over the ranks when the table holds at least this many (row, dim) entries
     // (below that a window's scan is shorter than the all-gather that would follow it)
     long long shard_min_row_dims = 400000;
+    long long shard_min_row_dims_pruned = 0;  // ... while the scans are pruned chains (0: the same; set by cc_comm_calibrate)
+    double calib_ag_us = 0.0, calib_scan_ns = 0.0;  // what cc_comm_calibrate measured (group maxima)
     int offline_shard_min_rows = 8192;  // the pair matrices of the offline phase / association tracker likewise
     DevBuf<Cand> gsend, gpart;  // one merged record per window point (two parities) / the gathered records of all ranks
     DevBuf<Cand> gsend2, gpart2;  // guessed thresholds in a group: the missed points' new records, compact / gathered
@@ -343,9 +346,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld, \"shard_min_row_dims_pruned\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end, (long long)c.shard_min_row_dims_pruned,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -625,6 +628,16 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 // B behind it; lists of points (the ones a guessed threshold missed, probes) keep the one-kernel form
                 auto scan_p_window = [&](int srank, int sworld, double gF, unsigned long long* found_) {
                     if (h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000)) {
+                        if constexpr (DP <= 40) {
+                            // one kernel, two points per lane in phase A, phase B from the same residency (k_scan_p2)
+                            if (h->allow_scan_p2) {
+                                hipLaunchKernelGGL((k_scan_p2<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                                   rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
+                                                   h->pstat_p(), gF, found_);
+                                ++h->stats.scan_p2_launches;
+                                return;
+                            }
+                        }
                         hipLaunchKernelGGL((k_scan_p<DP, NW, false>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                            rows.key, h->thr.p, h->thr32.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
                                            h->pstat_p(), (const int*)nullptr, gF, found_, (const unsigned*)nullptr, (size_t)0, 0, 1);
@@ -972,6 +985,8 @@ int cc_create(int device, cc_handle** out)
         if (sa) h->split_a_mode = std::max(0, std::min(2, atoi(sa)));
         const char* ln = getenv("CHRONOCLUST_HIP_LEAN");
         h->allow_lean = !(ln && ln[0] == '0');
+        const char* p2 = getenv("CHRONOCLUST_HIP_SCANP2");
+        h->allow_scan_p2 = !(p2 && p2[0] == '0');
         const char* lk = getenv("CHRONOCLUST_HIP_LINK");
         h->allow_link = !(lk && lk[0] == '0');
         const char* sp = getenv("CHRONOCLUST_HIP_SPARSE");
@@ -1642,6 +1657,7 @@ struct OnlineRun {
         pcfg.allow_guess = h->allow_guess ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
         pcfg.allow_probe = h->allow_probe ? 1 : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
+        pcfg.shard_min_row_dims_pruned = h->shard_min_row_dims_pruned;
         pcfg.n_end = N;
         const cc_policy_carry pcarry{h->adapt_win, h->clean_batches, h->since_shrink, 0};
         policy.emplace(pcfg, pcarry);
@@ -2909,6 +2925,113 @@ int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world)
             if (r != ncclSuccess) return fail(h, CC_ERR_COMM, std::string("ncclCommInitRank (second communicator): ") + api.GetErrorString(r));
             h->comm.nccl[1] = comm2;
         }
+        // the split thresholds from a measurement of this group's own exchange (collective: every rank is here)
+        const char* cal = getenv("CHRONOCLUST_HIP_CALIBRATE");
+        if (!(cal && cal[0] == '0')) {
+            const int rc = cc_comm_calibrate(h);
+            if (rc != CC_OK) return rc;
+        }
+        return (int)CC_OK;
+    });
+}
+
+int cc_comm_calibrate(cc_handle* h)
+{
+    if (!h) return CC_ERR_BAD_ARG;
+    return guarded(h, [&]() {
+        if (!h->comm.active()) return fail(h, CC_ERR_BAD_ARG, "cc_comm_calibrate: the handle belongs to no group");
+        const int world = h->comm.world, rank = h->comm.rank;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        auto timed3 = [&](auto&& fn) {  // one untimed pass, then the minimum of three
+            fn();
+            sync_stream(h, h->stream);
+            float best = 1e30f;
+            for (int i = 0; i < 3; ++i) {
+                HIPCHK(hipEventRecord(e0, h->stream));
+                fn();
+                HIPCHK(hipEventRecord(e1, h->stream));
+                sync_stream(h, h->stream);
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            return (double)best * 1e3;  // us
+        };
+        // (1) the exchange of a split window: one full window's records from every rank
+        const int win = std::min(h->tun.window, CC_MAX_WINDOW);
+        const size_t rec = ((size_t)win * 4 + 4) * sizeof(Cand);
+        DevBuf<char> sbuf, rbuf;
+        sbuf.ensure(rec);
+        rbuf.ensure(rec * (size_t)world);
+        HIPCHK(hipMemsetAsync(sbuf.p, 0, rec, h->stream));
+        const double ag_us = timed3([&]() { h->comm.all_gather(sbuf.p, rbuf.p, rec, h->stream, 0); });
+        // (2) what a table row costs: the plain snapshot scan of a full window over 4 096 synthetic rows x 20 dimensions, on
+        // scratch buffers and a control block of its own (the handle's state is not touched)
+        constexpr int DPc = 20, Rc = 4096;
+        constexpr int NWc = ScanShape<DPc, false>::NW;
+        DevBuf<Ctl> cctl;
+        DevBuf<double> cxt, ccen, cscl;
+        DevBuf<int> ckind, ckey;
+        DevBuf<Cand> cpart;
+        const int tiles = (win + 63) / 64;
+        const int Sc = std::max(1, std::min(16, (h->n_cus * scan_u_wgs_per_cu<DPc>()) / std::max(1, tiles)));
+        cctl.ensure(1); cxt.ensure((size_t)win * DPc); ccen.ensure((size_t)Rc * DPc); cscl.ensure((size_t)Rc * DPc);
+        ckind.ensure(Rc); ckey.ensure(Rc); cpart.ensure((size_t)2 * win * Sc * 4);
+        {
+            std::vector<double> x((size_t)win * DPc), cen((size_t)Rc * DPc), scl((size_t)Rc * DPc, 0.25);
+            unsigned long long st = 0x9E3779B97F4A7C15ull;
+            auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (double)(st >> 11) * 0x1p-53; };
+            for (auto& v : x) v = 0.1 + 0.8 * rnd();
+            for (auto& v : cen) v = 0.1 + 0.8 * rnd();
+            std::vector<int> kind(Rc, CC_KIND_PCORE), key(Rc);
+            for (int i = 0; i < Rc; ++i) key[i] = i;
+            Ctl c;
+            memset(&c, 0, sizeof c);
+            c.d = DPc; c.m_rows = Rc; c.win_b = win; c.win_cfg = win; c.n_points = win; c.xt_stride = win;
+            c.k = 4.0; c.inv_k = 0.25; c.pow2 = 1;
+            HIPCHK(hipMemcpyAsync(cctl.p, &c, sizeof c, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(cxt.p, x.data(), x.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(ccen.p, cen.data(), cen.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(cscl.p, scl.data(), scl.size() * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(ckind.p, kind.data(), (size_t)Rc * 4, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(ckey.p, key.data(), (size_t)Rc * 4, hipMemcpyHostToDevice, h->stream));
+            sync_stream(h, h->stream);  // (the host vectors go out of scope)
+        }
+        const double scan_us = timed3([&]() {
+            hipLaunchKernelGGL((k_scan_u<DPc, NWc>), dim3(tiles, Sc), dim3(64 * NWc), 0, h->stream, (const Ctl*)cctl.p, (const double*)cxt.p,
+                               (const double*)ccen.p, (const double*)cscl.p, (const int*)ckind.p, (const int*)ckey.p, cpart.p, 0, 0,
+                               (size_t)win * Sc * 4, 0, 1);
+        });
+        HIPCHK(hipGetLastError());
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        // (3) every rank takes the group's maxima: the thresholds decide the sequence of collectives and must be the same
+        // everywhere (an all-gather of two doubles per rank through the transport itself)
+        double mine[2] = {ag_us, scan_us * 1e3 / ((double)Rc * DPc)};  // us, ns per (row, dim)
+        DevBuf<double> dsend, drecv;
+        dsend.ensure(2);
+        drecv.ensure((size_t)2 * world);
+        HIPCHK(hipMemcpyAsync(dsend.p, mine, sizeof mine, hipMemcpyHostToDevice, h->stream));
+        h->comm.all_gather(dsend.p, drecv.p, sizeof mine, h->stream, 0);
+        std::vector<double> all((size_t)2 * world);
+        HIPCHK(hipMemcpyAsync(all.data(), drecv.p, all.size() * 8, hipMemcpyDeviceToHost, h->stream));
+        sync_stream(h, h->stream);
+        double ag = 0.0, sc = 0.0;
+        for (int r = 0; r < world; ++r) { ag = std::max(ag, all[(size_t)2 * r]); sc = std::max(sc, all[(size_t)2 * r + 1]); }
+        h->calib_ag_us = ag;
+        h->calib_scan_ns = sc;
+        if (world > 1 && sc > 0.0) {
+            // time saved by the split = scan x (1 - 1 / world); it pays from scan >= exchange x world / (world - 1) on
+            const double row_dims = ag * 1e3 * (double)world / (double)(world - 1) / sc;
+            h->shard_min_row_dims = (long long)std::min(row_dims, 1e15);
+            h->shard_min_row_dims_pruned = (long long)std::min(row_dims * 3.3, 1e15);
+        }
+        if (h->trace)
+            fprintf(stderr, "[cc] rank %d of %d: all-gather of a %d-point window's records %.1f us, plain scan %.3f ns per (row, dim) "
+                    "(group maxima) -> scans split from %lld (plain) / %lld (pruned) row-dims on\n", rank, world, win, ag, sc,
+                    (long long)h->shard_min_row_dims, (long long)(h->shard_min_row_dims_pruned > 0 ? h->shard_min_row_dims_pruned : h->shard_min_row_dims));
         return (int)CC_OK;
     });
 }
@@ -2981,7 +3104,7 @@ int cc_get_relaxed_stats(cc_handle* h, cc_relaxed_stats* out)
 int cc_set_shard_thresholds(cc_handle* h, int64_t min_row_dims, int32_t offline_min_rows)
 {
     if (!h) return CC_ERR_BAD_ARG;
-    if (min_row_dims >= 0) h->shard_min_row_dims = min_row_dims;
+    if (min_row_dims >= 0) { h->shard_min_row_dims = min_row_dims; h->shard_min_row_dims_pruned = 0; }  // (one threshold for both kinds of scan)
     if (offline_min_rows >= 0) h->offline_shard_min_rows = offline_min_rows;
     return CC_OK;
 }
@@ -3033,6 +3156,10 @@ int cc_get_stats(cc_handle* h, cc_stats* out)
     if (!h || !out) return CC_ERR_BAD_ARG;
     *out = h->stats;
     out->window = h->tun.window;
+    out->calib_allgather_us = h->calib_ag_us;
+    out->calib_scan_ns_per_row_dim = h->calib_scan_ns;
+    out->split_threshold_row_dims = h->shard_min_row_dims;
+    out->split_threshold_row_dims_pruned = h->shard_min_row_dims_pruned > 0 ? h->shard_min_row_dims_pruned : h->shard_min_row_dims;
     return CC_OK;
 }
 

@@ -20,9 +20,13 @@
 
 namespace cc {
 
-inline bool policy_want_shard(const cc_policy_config& c, int m_rows)
+// (two thresholds since round 6: a pruned chain spends a third of a plain scan's time on the same rows, so it pays to split it
+// only from a table about three times as large; shard_min_row_dims_pruned == 0 - configurations recorded before - means "the
+// same as for plain scans")
+inline bool policy_want_shard(const cc_policy_config& c, int m_rows, bool pruned)
 {
-    return c.can_shard != 0 && (long long)m_rows * c.d >= c.shard_min_row_dims;
+    const long long thr = (pruned && c.shard_min_row_dims_pruned > 0) ? c.shard_min_row_dims_pruned : c.shard_min_row_dims;
+    return c.can_shard != 0 && (long long)m_rows * c.d >= thr;
 }
 
 // Points per millisecond the sequential kernel that WOULD take over is assumed to manage before it has been measured in
@@ -60,8 +64,8 @@ public:
         la_on_ = c_.lookahead == 3;
         nodirty_ = false;
         sparse_ = false;
-        shard_on_ = policy_want_shard(c_, m_rows);
         prune_on_ = c_.prune_applicable != 0 && c_.prune_mode != 0;  // (independent of the split: k_scan_p takes a row range)
+        shard_on_ = policy_want_shard(c_, m_rows, prune_on_);
         prune_resume_at_ = 0;
         prune_backoff_ = 65536;
         guess_on_ = false;
@@ -213,10 +217,6 @@ public:
         // profiles/r05_tool_startup_lookahead.txt -; once on it stays on until a window is cut short)
         const bool calm = tiles > 0 && (dtiles * 8 <= tiles || few_flagged);
         const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned && (la_on_ || calm));
-        // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)
-        const bool shard_next = policy_want_shard(c_, o.m_rows);
-        const bool shard_flip = shard_next != shard_on_;
-        shard_on_ = shard_next;
         // While plain scans run, the batch's first window also runs the pruned chain on 128 of its points (a probe: its
         // results are not used, its sample is): pruned scans come back as soon as the probe says they would pay, instead
         // of being tried on whole batches that cost twice the plain scan when they fail.
@@ -233,6 +233,10 @@ public:
                                  (nodirty_ && prune_resume_at_ != std::numeric_limits<long long>::max()));
         const bool prune_flip = prune_next != prune_on_;
         prune_on_ = prune_next;
+        // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)
+        const bool shard_next = policy_want_shard(c_, o.m_rows, prune_on_);
+        const bool shard_flip = shard_next != shard_on_;
+        shard_on_ = shard_next;
         probe_gate_ = grew == 0 && !unpruned && want >= std::min(8192, c_.window);
         // Guessed thresholds (k_scan_p with Ctl::tg instead of k_seed + k_seed_merge, which cost as much as the scan they
         // serve): while a mean join distance exists and few points are missed - more than one in sixteen: back to seeds

@@ -1815,6 +1815,333 @@ __global__ __launch_bounds__(64 * NW, (DP <= 20 ? CC_SCANP_WGS20 : (DP <= 40 ? 3
 }
 
 // ---------------------------------------------------------------------------------
+// k_scan_p2 (round 6): the pruned scan of a window in ONE kernel with phase A the way k_scan_a runs it - TWO points per lane, the
+// expanded form, the threshold folded into the accumulator's start (cc_tau32) - and phase B from the same residency.
+// k_scan_p's phase A waits on its wave-uniform LDS reads (two 16-byte broadcasts per row and 64 points: VALU 56 % busy, 41 % of the
+// waves' time parked on s_waitcnt, profiles/r05_pmc_valu_d20.json); splitting phase A off (k_scan_a) halves the LDS bytes per
+// (point, row) and the instructions, but at 5 000 rows the second launch, its prologue and the masks' round trip through L2 cost what
+// that saves.  Here a workgroup covers 128 window points: its waves test every row of their sub-range for both 64-point halves
+// (7 VALU instructions per (64 points, row) where k_scan_p spends 15) and complete the rows that stay - 1.3 % at C2 - at once,
+// half by half.  The points' coordinates are NOT held in registers (2 x d doubles per lane would halve the occupancy): the
+// workgroup stages them once in LDS (128 x d doubles, 20 KB at d = 20: all its waves scan the same points) and phase B reads
+// them from there; centroid and operands of a surviving row are scalar loads as in k_scan_p.  Same thresholds, same exact
+// abandon test every eight dimensions, same candidates and bounds as k_scan_p: a row phase A keeps is evaluated exactly, so only
+// "abandoned implies beyond T" matters, and that is cc_tau32's statement (tests/test_pruned_scan.py, the forced-pruning fuzz
+// and the full-size plain-scan comparisons run it; CHRONOCLUST_HIP_SCANP2=0 goes back to k_scan_p).
+// ---------------------------------------------------------------------------------
+#ifndef CC_SCANP2_WGS
+#define CC_SCANP2_WGS 4  // workgroups per CU the kernel is compiled for
+#endif
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, CC_SCANP2_WGS) void k_scan_p2(
+    Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
+    const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr, size_t thr_stride,
+    Cand* __restrict__ part, int round, int mode, size_t part_stride, int shard_rank, int shard_world,
+    unsigned long long* __restrict__ pstat, double guess_F, unsigned long long* __restrict__ found)
+{
+    static_assert(DP % 2 == 0 && DP > CC_PRE && DP <= 64 && CC_PRE == 8, "k_scan_p2 shapes");
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 128;
+    if (j0 >= B) return;
+    part += (size_t)win.q * part_stride;
+    thr += (size_t)win.q * thr_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    int row_lo = 0, row_hi = win.rows;
+    if (shard_world > 1) cc_shard_range(win.rows, shard_world, shard_rank, 1, &row_lo, &row_hi);
+    const int per = (row_hi - row_lo + nsub - 1) / nsub;
+    const int r0 = row_lo + sub * per;
+    const int r1 = min(row_hi, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+
+    // LDS: the workgroup's 128 points (dimension-major, [i][128]); per wave a tile of 16 centred prefixes + their h; at the end the
+    // same bytes carry the candidate exchange of the waves
+    constexpr int PTS_DOUBLES = DP * 128;
+    constexpr int MERGE_BYTES = (NW > 1 ? NW - 1 : 1) * 8 * 64 * (int)sizeof(Cand);
+    constexpr int PTS_BYTES = PTS_DOUBLES * 8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[PTS_BYTES > MERGE_BYTES ? PTS_BYTES : MERGE_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_pre[NW * CC_SCAN_TM * CC_PRE];
+    __shared__ float s_h[NW * CC_SCAN_TM];
+    double* const s_pts = reinterpret_cast<double*>(smem);
+    float* const tile = s_pre + (size_t)wv * CC_SCAN_TM * CC_PRE;
+    float* const thh = s_h + (size_t)wv * CC_SCAN_TM;
+    for (int e = (int)threadIdx.x; e < PTS_DOUBLES; e += 64 * NW) {
+        const int i = e >> 7, x = e & 127;
+        s_pts[e] = (j0 + x < B) ? Xt[win.cursor + j0 + x + (size_t)i * n_pts] : 0.0;
+    }
+    // the exact thresholds of the 128 points, per kind (the same for every wave of the workgroup: in LDS, not in eight
+    // registers per lane - phase B and the epilogue read them); points beyond the window: -inf, they keep no row alive
+    const bool guessed = guess_F > 0.0;
+    __shared__ double s_T[2 * 128];
+    for (int e = (int)threadIdx.x; e < 2 * 128; e += 64 * NW) {
+        const int K = e >> 7, x = e & 127;
+        double T;
+        if (guessed) T = (ctl->tg_ok[win.q][K] != 0) ? guess_F * ctl->tg[win.q][K] : CC_INF;
+        else T = (j0 + x < B) ? thr[(size_t)(j0 + x) * 2 + K] : CC_INF;
+        s_T[e] = (j0 + x < B) ? T : -CC_INF;
+    }
+    double org[CC_PRE];
+#pragma unroll
+    for (int i = 0; i < CC_PRE; ++i) org[i] = g_cen[i];  // (wave-uniform: scalar loads)
+    const double cmd = 2.0 * __builtin_fmax(ctl->x_absmax, __longlong_as_double((long long)ctl->cen_absmax));
+    const double inv_k = ctl->inv_k;
+    __syncthreads();  // the points and thresholds are staged
+
+    bool valid[2];
+    cc_f2 p2[2][CC_PRE / 2];
+    cc_f2 ninit[2][2];   // [half][kind]: the accumulator's start {-tau, 0}
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        valid[u] = j0 + u * 64 + lane < B;
+        double s2 = 0.0;
+        float pmf = 0.0f;
+        float ph[CC_PRE];
+#pragma unroll
+        for (int i = 0; i < CC_PRE; ++i) {
+            ph[i] = valid[u] ? (float)(s_pts[i * 128 + u * 64 + lane] - org[i]) : 0.0f;
+            s2 += (double)ph[i] * (double)ph[i];
+            const float a = __builtin_fabsf(ph[i]);
+            pmf = a > pmf ? a : pmf;
+        }
+#pragma unroll
+        for (int i = 0; i < CC_PRE / 2; ++i) p2[u][i] = cc_f2{ph[2 * i], ph[2 * i + 1]};
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            const float tau = valid[u] ? cc_tau32(s_T[K * 128 + u * 64 + lane], s2, (double)pmf, cmd, inv_k) : __builtin_inff();
+            ninit[u][K] = cc_f2{-tau, 0.0f};
+        }
+    }
+    auto thx = [&](int u, int K) -> double { return s_T[K * 128 + u * 64 + lane]; };
+    double lb[2][2], bd[2][2][2];
+    int bs[2][2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            lb[u][K] = CC_INF;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                bd[u][K][r] = valid[u] ? CC_INF : -CC_INF;
+                bs[u][K][r] = -1;
+            }
+        }
+    unsigned dflag = 0u;  // bit 2 u + K (wave-uniform): phase A abandoned a row of kind K for half u
+    int n_rows = 0, n_full = 0;
+
+    // phase B for one row and one half: the whole distance from its first dimension with the reference's four operations per
+    // term, the exact abandon test every eight dimensions, then k_scan_u's best-two update
+    auto complete_row = [&](auto UC, int rowg, bool is_p) {
+        constexpr int u = decltype(UC)::value;
+        const double* __restrict__ rc = g_cen + (size_t)rowg * DP;  // wave-uniform addresses: scalar loads
+        const double* __restrict__ rs = g_scl + (size_t)rowg * DP;
+        const double* __restrict__ px = s_pts + u * 64 + lane;
+        double acc = 0.0;
+        bool gone = false;
+        cc_static_for<(DP + 7) / 8>([&](auto CC) {
+            constexpr int lo = 8 * decltype(CC)::value, hi = (lo + 8) < DP ? (lo + 8) : DP;
+            if (gone) return;
+            double c[hi - lo], sc[hi - lo], pv[hi - lo];
+#pragma unroll
+            for (int i = 0; i < hi - lo; ++i) {
+                c[i] = rc[lo + i];
+                sc[i] = rs[lo + i];
+                pv[i] = px[(lo + i) * 128];
+            }
+#pragma unroll
+            for (int i = 0; i < hi - lo; ++i) {
+                double x = pv[i] - c[i];               // mc_functions.py:37
+                x = x * x;                             // :38
+                x = x * sc[i];                         // :39 (the divisor is a power of two)
+                acc = (lo + i == 0) ? x : acc + x;     // :41
+            }
+            if constexpr (hi < DP) {
+                const double t = thx(u, is_p ? 0 : 1);
+                if (__builtin_amdgcn_ballot_w64(acc <= t) == 0ull) {
+                    if (is_p) lb[u][0] = cc_vmin(lb[u][0], acc);
+                    else lb[u][1] = cc_vmin(lb[u][1], acc);
+                    gone = true;
+                }
+            }
+        });
+        if (gone) return;
+        ++n_full;
+        auto update = [&](auto KC) {
+            constexpr int K = decltype(KC)::value;
+            const double a = acc;
+            double& d0 = bd[u][K][0];
+            double& d1 = bd[u][K][1];
+            int& s0 = bs[u][K][0];
+            int& s1 = bs[u][K][1];
+            bool ins = a < d1;
+            bool first = a < d0;
+            // exact ties: list order decides (hddstream.py:326/373, strict `<`)
+            const unsigned long long e1 = __builtin_amdgcn_ballot_w64(a == d1);
+            const unsigned long long e0 = __builtin_amdgcn_ballot_w64(a == d0);
+            if ((e1 | e0) != 0ull) {
+                if (a == d1 || a == d0) {
+                    const int key = g_key[rowg];
+                    if (a == d1) ins = key < (s1 >= 0 ? g_key[s1] : CC_IDX_INF);
+                    if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
+                }
+            }
+            d1 = cc_vmin(d1, cc_vmax(d0, a));
+            d0 = cc_vmin(d0, a);
+            s1 = first ? s0 : (ins ? rowg : s1);
+            s0 = first ? rowg : s0;
+        };
+        if (is_p) update(std::integral_constant<int, 0>{});
+        else update(std::integral_constant<int, 1>{});
+    };
+
+    double tc[2];
+    int kdl = CC_KIND_DEAD;
+    if (r0 < r1) cc_load_prefix<DP>(g_cen, g_kind, r0, min(CC_SCAN_TM, r1 - r0), lane, tc, kdl);
+    for (int rt = r0; rt < r1; rt += CC_SCAN_TM) {
+        const int tm = __builtin_amdgcn_readfirstlane(min(CC_SCAN_TM, r1 - rt));
+        CC_WAVE_SYNC();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float v = (float)(tc[q] - org[lane & 7]);
+            tile[lane + q * 64] = v;
+            float hsum = v * v;
+            hsum += __shfl_xor(hsum, 1);
+            hsum += __shfl_xor(hsum, 2);
+            hsum += __shfl_xor(hsum, 4);
+            // a prefix beyond single precision's range: never abandoned (t' < -inf is false)
+            if ((lane & 7) == 0) thh[(lane >> 3) + q * 8] = (hsum < 0x1p120f) ? 0.5f * hsum : -__builtin_inff();
+        }
+        const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
+        const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
+        CC_WAVE_SYNC();
+        if (rt + CC_SCAN_TM < r1) cc_load_prefix<DP>(g_cen, g_kind, rt + CC_SCAN_TM, min(CC_SCAN_TM, r1 - rt - CC_SCAN_TM), lane, tc, kdl);
+        n_rows += 2 * tm;
+        const cc_f4* t4 = reinterpret_cast<const cc_f4*>(__builtin_assume_aligned(tile, 16));
+        const unsigned full = (1u << tm) - 1u;
+        unsigned surv[2] = {0u, 0u};
+        // ---- phase A (k_scan_a's): t' = p^.c^ - tau < h^ abandons the row for the half ----
+        auto rows_of = [&](auto KSELC) {
+            constexpr int KSEL = decltype(KSELC)::value;
+            auto two = [&](int m0, int n) {
+                cc_f4 c01[2], c23[2];
+                float h[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int m = (v < n) ? m0 + v : m0;
+                    c01[v] = t4[m * 2]; c23[v] = t4[m * 2 + 1]; h[v] = thh[m];
+                }
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    if (v >= n) break;
+                    const int m = m0 + v;
+                    int K;
+                    if constexpr (KSEL == 0) K = 0;
+                    else if constexpr (KSEL == 1) K = 1;
+                    else K = ((pmask >> m) & 1u) ? 0 : 1;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        cc_f2 acc = __builtin_elementwise_fma(p2[u][0], cc_f2{c01[v].x, c01[v].y}, K == 0 ? ninit[u][0] : ninit[u][1]);
+                        acc = __builtin_elementwise_fma(p2[u][1], cc_f2{c01[v].z, c01[v].w}, acc);
+                        acc = __builtin_elementwise_fma(p2[u][2], cc_f2{c23[v].x, c23[v].y}, acc);
+                        acc = __builtin_elementwise_fma(p2[u][3], cc_f2{c23[v].z, c23[v].w}, acc);
+                        float t;
+                        asm("v_add_f32 %0, %1, %2" : "=v"(t) : "v"(acc.x), "v"(acc.y));
+                        // kept unless t' < h^ (a NaN - an overflow the guards did not see - keeps the row)
+                        surv[u] |= (__builtin_amdgcn_ballot_w64(!(t < h[v])) != 0ull) ? (1u << m) : 0u;
+                    }
+                }
+            };
+            int m = 0;
+            for (; m + 2 <= tm; m += 2) two(m, 2);
+            if (m < tm) two(m, 1);
+        };
+        if (pmask == full) rows_of(std::integral_constant<int, 0>{});
+        else if (omask == full) rows_of(std::integral_constant<int, 1>{});
+        else rows_of(std::integral_constant<int, -1>{});
+        // rows of neither list (dead) are never completed: dropped from the masks, not counted as abandoned
+        const unsigned listed = (pmask | omask) & full;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            surv[u] &= listed;
+            if ((~surv[u] & pmask & full) != 0u) dflag |= 1u << (2 * u);
+            if ((~surv[u] & omask & full) != 0u) dflag |= 2u << (2 * u);
+        }
+        // ---- phase B: the rows that stayed, half by half ----
+        cc_static_for<2>([&](auto UC) {
+            constexpr int u = decltype(UC)::value;
+            unsigned sv = surv[u];
+            while (sv != 0u) {
+                const int m = __builtin_ctz(sv);
+                sv &= sv - 1u;
+                complete_row(UC, rt + m, ((pmask >> m) & 1u) != 0u);
+            }
+        });
+    }
+    // rows abandoned in phase A: their exact partial sums exceed every lane's T, which is all that is recorded of them
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if ((dflag >> (2 * u)) & 1u) lb[u][0] = cc_vmin(lb[u][0], thx(u, 0));
+        if ((dflag >> (2 * u)) & 2u) lb[u][1] = cc_vmin(lb[u][1], thx(u, 1));
+    }
+    if (guessed && found != nullptr) {
+        // the points for which this wave evaluated a pcore MC within the guessed threshold: their pcore list's best is exact
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(valid[u] && bs[u][0][0] >= 0 && bd[u][0][0] <= thx(u, 0));
+            if (lane == 0 && fm != 0ull) atomicOr(found + (size_t)win.q * (CC_MAX_WINDOW / 64) + (size_t)blockIdx.x * 2 + u, fm);
+        }
+    }
+    // statistics for the host's policy: a sample - the waves of the window's first point tile (see k_scan_p)
+    if (lane == 0 && blockIdx.x == 0 && n_rows > 0) {
+        atomicAdd(pstat + win.q * 2, (unsigned long long)n_rows);
+        atomicAdd(pstat + win.q * 2 + 1, (unsigned long long)n_full);
+    }
+    // the survivors' list-order keys; every kind's pair takes in the bound of what the wave abandoned; the waves' pairs are
+    // merged through LDS (the bytes of the staged points: every wave is done with them)
+    Cand cnd[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int sl = bs[u][K][r];
+                cnd[u][K * 2 + r] = Cand{bd[u][K][r], sl >= 0 ? g_key[sl] : CC_IDX_INF, sl};
+            }
+            cc_top2_push(cnd[u][K * 2], cnd[u][K * 2 + 1], Cand{lb[u][K], -1, (valid[u] && lb[u][K] < CC_INF) ? CC_SLOT_BOUND : -1});
+        }
+    }
+    Cand* s_m = reinterpret_cast<Cand*>(smem);
+    auto s_m_at = [&](int w, int c) -> Cand& { return s_m[(w * 8 + c) * 64 + lane]; };
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_m_at(wv - 1, u * 4 + c) = cnd[u][c];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (!valid[u]) continue;
+#pragma unroll
+        for (int w = 0; w < NW - 1; ++w) {
+            cc_top2_push(cnd[u][0], cnd[u][1], s_m_at(w, u * 4 + 0));
+            cc_top2_push(cnd[u][0], cnd[u][1], s_m_at(w, u * 4 + 1));
+            cc_top2_push(cnd[u][2], cnd[u][3], s_m_at(w, u * 4 + 2));
+            cc_top2_push(cnd[u][2], cnd[u][3], s_m_at(w, u * 4 + 3));
+        }
+        Cand* o = part + ((size_t)(j0 + u * 64 + lane) * S + blockIdx.y) * 4;
+        o[0] = cnd[u][0]; o[1] = cnd[u][1]; o[2] = cnd[u][2]; o[3] = cnd[u][3];
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // k_missed: after a snapshot scan with guessed thresholds - the window points no wave found a pcore MC for (their own MC
 // lies beyond the guess, or they have none), in point order, for the seeded chain that follows (k_seed / k_seed_merge /
 // k_scan_p over `list`).  One workgroup; the marks are cleared for the window's next use of them.  A list that would

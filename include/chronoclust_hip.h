@@ -139,6 +139,14 @@ typedef struct cc_stats {
     int64_t seq_g_points;          /* of seq_points: taken by k_seq_g (table in HBM: beyond the sequential kernel's LDS image) */
     int64_t link_launches;         /* windows whose round 0 linked the points that decided "create" among themselves
                                     * (k_link_scan + k_link_apply: while microclusters are being created)                  */
+    int64_t scan_p2_launches;      /* of scan_p_launches: the window's pruned scan as k_scan_p2 (two points per lane in phase A,
+                                    * phase B from the same residency) rather than k_scan_p                                */
+    /* the split of the snapshot scans over the ranks of a group (cc_comm_calibrate): what was measured when the group
+     * was formed and the thresholds in force - (table rows x d) from which a plain scan / a pruned chain is split */
+    double  calib_allgather_us;    /* all-gather of one full window's records (64 B per point and rank); 0: not measured   */
+    double  calib_scan_ns_per_row_dim;  /* plain snapshot scan of a full window: ns per (table row, dimension)             */
+    int64_t split_threshold_row_dims;
+    int64_t split_threshold_row_dims_pruned;
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -266,6 +274,21 @@ int cc_assoc_argmin(cc_handle* h, const double* cur_cen, const double* cur_pref,
 int cc_comm_unique_id(void* out_id);
 int cc_comm_init_rccl(cc_handle* h, const void* id_bytes, int rank, int world);
 int cc_comm_init_local(cc_handle** handles, int world);
+/* Collective (every rank of the group, after joining it; cc_comm_init_rccl calls it itself unless
+ * CHRONOCLUST_HIP_CALIBRATE=0; the members of an in-process group call it from their own threads): MEASURES what the split of
+ * the snapshot scans over the ranks costs and what it saves, and derives the split thresholds from the measurement instead of
+ * a constant -
+ *   - three all-gathers of one full window's candidate records (64 B per point and rank) on the handle's stream: the exchange
+ *     a split window pays, `calib_allgather_us` (minimum of the three);
+ *   - three plain snapshot scans (k_scan_u) of a full window over 4 096 synthetic rows x 20 dimensions on scratch buffers:
+ *     what a row costs, `calib_scan_ns_per_row_dim`;
+ *   - both figures are exchanged and every rank takes the group's MAXIMUM, so that all ranks derive the same thresholds (they
+ *     decide the sequence of collectives): a plain scan is split from rows x d >= allgather x world / (world - 1) / scan per
+ *     (row, dim) on - where the time saved, scan x (1 - 1 / world), equals the exchange -, a pruned chain from 3.3 times
+ *     that (it spends 0.3 of a plain scan's time on the same rows: 92 against 306 us per full window at 5 000 x 20).
+ * A group of ONE rank measures and reports but keeps its thresholds (there is nothing to save; one-rank groups exist to
+ * exercise the transport).  cc_set_shard_thresholds afterwards overrides both thresholds.  cc_get_stats reports all four. */
+int cc_comm_calibrate(cc_handle* h);
 int cc_comm_destroy(cc_handle* h);
 int cc_comm_info(cc_handle* h, int32_t* rank, int32_t* world, int32_t* transport);
 /* RELAXED multi-GPU mode - not the reference's semantics.  The events of a timepoint are sharded over the ranks in
@@ -345,6 +368,7 @@ typedef struct cc_policy_config {
                                 * stretch of points that doubles with every failed try                               */
     int64_t shard_min_row_dims;
     int64_t n_end;             /* end of the range of points the call clusters                                     */
+    int64_t shard_min_row_dims_pruned;  /* the split threshold while the scans are pruned chains (0: shard_min_row_dims)   */
 } cc_policy_config;
 typedef struct cc_policy_carry {
     int32_t adapt_win, clean_batches, since_shrink, pad;

@@ -82,6 +82,17 @@ def test_c5_full_size_does_not_depend_on_window_or_lookahead(c5):
     P.same_results(P.run_pipeline([X], cfg, tuning=dict(window=12288, segments=256, lookahead=2)), res)
 
 
+def test_c5_full_size_pruned_scans_equal_plain_scans(c5):
+    """50 M x 40, 50 000 microclusters: every window's snapshot scan the plain k_scan_u (CHRONOCLUST_HIP_PRUNE=0) against the
+    default run, 97 % of whose windows are pruned two-kernel chains on the full table - bit for bit."""
+    X, cfg, res = c5
+    with P.knobs(CHRONOCLUST_HIP_PRUNE=0):
+        plain = P.run_pipeline([X], cfg)
+    assert plain[0]["stats"]["scan_p_launches"] == 0 and res[0]["stats"]["scan_p_launches"] > 1000
+    P.same_results(plain, res)
+    print("C5 full size with plain scans: online %.1f ms" % plain[0]["stats"]["run_ms"])
+
+
 def test_c5_full_size_prefix_matches_oracle(c5):
     X, cfg, res = c5
     _oracle_prefix(cfg, X, 20_000, res[0]["labels_uid"])  # (the 40 000-point prefix of this shape: test_full_size_shapes.py)

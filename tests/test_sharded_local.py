@@ -16,7 +16,7 @@ import scenarios
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0, env=None):
+def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0, env=None, calibrate=False):
     """The pipeline of app.run on `world` replicas of one stream, one thread per rank.  Returns the per-timepoint
     results of every rank.  env: knobs the library reads when a handle is created (CHRONOCLUST_HIP_PRUNE ...)."""
     import os
@@ -40,6 +40,8 @@ def run_group(world, Xs, cfg, tuning=None, min_row_dims=0, offline_min_rows=0, e
 
     def work(rank):
         try:
+            if calibrate:  # (collective: every member from its own thread; overrides the thresholds set above)
+                streams[rank]._h.comm_calibrate()
             results[rank] = P.run_pipeline(Xs, cfg, stream=streams[rank])
         except BaseException as e:  # noqa: BLE001 - reported after the join
             errors[rank] = e
@@ -309,3 +311,41 @@ def test_skewed_stream_in_a_group():
         P.same_results(r, single)
         assert sum(x["stats"]["heavy_launches"] for x in r) > 0 and all(x["stats"]["sharded_windows"] > 0 for x in r)
     assert [x["stats"]["heavy_launches"] for x in res[0]] == [x["stats"]["heavy_launches"] for x in res[1]]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_thresholds_come_from_a_measurement_and_agree_on_all_ranks(world):
+    """cc_comm_calibrate: the all-gather of a window's records and a plain scan are TIMED when the group is formed, every rank
+    takes the group's maxima and derives the same thresholds (plain scans from exchange x world / (world - 1) / scan per
+    (row, dim) on, pruned chains from 3.3 times that); a stream clustered with those thresholds equals one GPU's."""
+    n, d, g = 120_000, 20, 6000
+    X = scenarios.make_blobs(11, n, d, g)
+    cfg = scenarios.params_to_config(scenarios.blob_params(n))
+    single = P.run_pipeline([X], cfg)
+    res = run_group(world, [X], cfg, min_row_dims=-1, offline_min_rows=-1, calibrate=True)
+    stats = [r[0]["stats"] for r in res]
+    keys = ("calib_allgather_us", "calib_scan_ns_per_row_dim", "split_threshold_row_dims", "split_threshold_row_dims_pruned")
+    assert all(tuple(s[k] for k in keys) == tuple(stats[0][k] for k in keys) for s in stats)  # the same on every rank
+    s0 = stats[0]
+    assert s0["calib_allgather_us"] > 1.0 and 0.3 < s0["calib_scan_ns_per_row_dim"] < 30.0
+    want = s0["calib_allgather_us"] * 1e3 * world / (world - 1) / s0["calib_scan_ns_per_row_dim"]
+    assert abs(s0["split_threshold_row_dims"] - want) <= 1.0
+    assert abs(s0["split_threshold_row_dims_pruned"] - 3.3 * want) <= 4.0
+    for r in res:
+        P.same_results(r, single)
+    print("world %d: all-gather %.1f us, scan %.2f ns per (row, dim): split from %d / %d row-dims on; %d of %d windows split" % (
+        world, s0["calib_allgather_us"], s0["calib_scan_ns_per_row_dim"], s0["split_threshold_row_dims"],
+        s0["split_threshold_row_dims_pruned"], s0["sharded_windows"], s0["windows"]))
+
+
+def test_a_group_of_one_measures_but_keeps_its_thresholds():
+    from chronoclust_amd import _lib
+    h = _lib.Handle(0)
+    h.comm_init_rccl(_lib.comm_unique_id(), 0, 1)  # (calibrates by itself)
+    s = h.stats()
+    assert s["calib_allgather_us"] > 0.0 and s["calib_scan_ns_per_row_dim"] > 0.0
+    assert s["split_threshold_row_dims"] == 400_000 and s["split_threshold_row_dims_pruned"] == 400_000
+    h.set_shard_thresholds(1234, -1)
+    s = h.stats()
+    assert s["split_threshold_row_dims"] == 1234 and s["split_threshold_row_dims_pruned"] == 1234
+    h.close()
