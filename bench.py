@@ -57,6 +57,7 @@ FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39
 PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")
 PMC_BENCH_STEP_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench_step.json")  # tools/pmc_bench_step.py: counted on bench.py itself
 PMC_VALU_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
+PRUNED_CHAIN = ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p", "k_scan_p2")  # kernels of a pruned snapshot scan as the PMC summaries name them
 SCAN_SOURCES = ("cc_scan.h", "cc_common.h", "cc_div.h")  # what defines the snapshot-scan kernels the PMC files describe
 REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
 EXIT_LEG_FAILED = 3
@@ -488,8 +489,8 @@ def load_pmc_valu(d):
             full = float(pm["rows_evaluated_in_full_frac"])
         for kname, k in pm["kernels"].items():
             out[kname] = dict(k, source=name)
-    need = ("k_scan_u", "k_scan_p")
-    if all(n in out for n in need):
+    # (the window's pruned scan is k_scan_p2 since round 6; k_scan_p where that is switched off or does not apply)
+    if "k_scan_u" in out and ("k_scan_p" in out or "k_scan_p2" in out):
         return out, files, full
     return None, why or "incomplete PMC files for d = %d" % d, None
 
@@ -528,7 +529,7 @@ def scan_roofline(acc, d, kernel):
         parts["plain"] = {"kernel": "k_scan_u (start-up: every row evaluated in full)", "launches": n_u,
                           "avg_launch_us": 1e3 * ms_u / n_u, "effective_frac": 3.0 * (pd_all - pd_p) / (ms_u * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
     if n_p:
-        parts["pruned"] = {"kernel": "k_seed + k_seed_merge + k_scan_p (steady state: rows abandoned on a prefix)", "launches": n_p,
+        parts["pruned"] = {"kernel": "k_scan_p2 (k_seed + k_seed_merge before it while thresholds are seeded; steady state: rows abandoned on a prefix)", "launches": n_p,
                            "avg_launch_us": 1e3 * ms_p / n_p, "effective_frac": 3.0 * pd_p / (ms_p * 1e-3) / 1e12 / FP64_VALU_PEAK_TOPS}
     out["parts"] = parts
     pm, why, full_pmc = load_pmc_valu(d)
@@ -547,7 +548,7 @@ def scan_roofline(acc, d, kernel):
     if full_pmc is None:  # (a file that does not record the share of rows its own launches completed: no extra charge)
         full_pmc = full
     extra = max(0.0, full - full_pmc) * pm["k_scan_u"]["valu_instructions_per_wave_row"]
-    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p") if k in pm) + extra
+    per_row_p = sum(pm[k]["valu_instructions_per_wave_row"] for k in PRUNED_CHAIN if k in pm) + extra
     lanes_u = pairs_u * pm["k_scan_u"]["valu_instructions_per_wave_row"]
     lanes_p = pairs_p * per_row_p
     executed = (lanes_u + lanes_p) / secs / 1e12
@@ -560,7 +561,7 @@ def scan_roofline(acc, d, kernel):
     keys = ("valu_instructions_per_wave_row", "salu_instructions_per_wave_row", "lds_instructions_per_wave_row",
             "valu_busy_fraction", "lds_busy_fraction", "lds_array_busy_fraction", "wave_time_parked_on_waitcnt",
             "co_limiter", "avg_us_under_pmc", "source")
-    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u", "k_seed", "k_seed_merge", "k_scan_a", "k_scan_p") if n in pm},
+    out["executed"] = {"kernels": {n: {k: pm[n][k] for k in keys if k in pm[n]} for n in ("k_scan_u",) + PRUNED_CHAIN if n in pm},
                        "instruction_lanes_per_launch": (lanes_u + lanes_p) / acc["scan_launches"],
                        "note": "counters of full windows running alone (tools/steady.py under rocprofv3 --pmc, three passes); "
                                "busy fractions are of the kernel's own run time, `frac` above is over this run's launches "
@@ -614,6 +615,8 @@ def counted_on_bench(rf, cfg, scan_ms_per_step, ms_per_step):
 
 def scan_kernel_name(s, d):
     if s.get("scan_p_launches", 0) > 0:
+        if s.get("scan_p2_launches", 0) > 0:
+            return "k_scan_p2<%d, 4> (pruned; + k_seed, k_seed_merge while seeded) / k_scan_u<%d, 4> (plain)" % (d, d)
         return "k_seed<%d, 4> + k_seed_merge + k_scan_p<%d, 4> (pruned) / k_scan_u<%d, 4>" % (d, d, d)
     return ("k_scan_u<%d, 4>" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<%d, DIRTY=false>" % d
 

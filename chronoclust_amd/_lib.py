@@ -46,7 +46,8 @@ class CcStats(C.Structure):
                 ("seq_g_points", C.c_int64), ("link_launches", C.c_int64),
                 ("scan_p2_launches", C.c_int64),
                 ("calib_allgather_us", C.c_double), ("calib_scan_ns_per_row_dim", C.c_double),
-                ("split_threshold_row_dims", C.c_int64), ("split_threshold_row_dims_pruned", C.c_int64)]
+                ("split_threshold_row_dims", C.c_int64), ("split_threshold_row_dims_pruned", C.c_int64),
+                ("missed_plain_launches", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8

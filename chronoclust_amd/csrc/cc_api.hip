@@ -204,6 +204,7 @@ struct cc_handle {
     bool allow_claims = true;   // CHRONOCLUST_HIP_CLAIMS=0: k_decide's atomics whatever the table size
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
+    bool allow_missed_plain = true;  // CHRONOCLUST_HIP_MISSED_PLAIN=0: the points a guessed threshold missed go through the seeded chain, not k_scan_u
     bool allow_scan_p2 = true;  // CHRONOCLUST_HIP_SCANP2=0: the pruned scan of a window as k_scan_p (one point per lane) instead of k_scan_p2
     bool allow_link = true;     // CHRONOCLUST_HIP_LINK=0: round 0 does not link the points that decide "create" among themselves (cc_link.h)
     DevBuf<int> link_near;      // [window] k_link_scan: per window point that decided "create", the earliest such point before it that would absorb it
@@ -690,13 +691,24 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                            part_stride, shard_rank, shard_world, h->pstat_p(), plist, 0.0,
                                            (unsigned long long*)nullptr, (const unsigned*)nullptr, (size_t)0, 0, 1);
                 };
+                // the points a guessed threshold missed: the plain scan over their list (k_scan_u's header says why); the seeded
+                // chain on request (CHRONOCLUST_HIP_MISSED_PLAIN=0)
+                auto missed_scan = [&](const int* list) {
+                    if (!h->allow_missed_plain) {
+                        seeded_chain(CC_MISSED_CAP, list, part, h->part_stride, S);
+                        return;
+                    }
+                    ++h->stats.missed_plain_launches;
+                    hipLaunchKernelGGL((k_scan_u<DP, NW>), dim3((CC_MISSED_CAP + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                       rows.scl, rows.kind, rows.key, part, round, mode, h->part_stride, shard_rank, shard_world, list);
+                };
                 if (phase == 1) {
                     // guessed thresholds on the exact multi-GPU path, after the ranks' records were gathered: the points
                     // whose merged pcore list starts with a bound (k_missed_g: the same list on every rank) go through the
                     // seeded chain - seeds over all rows on every rank, phases A / B over the rank's rows
                     hipLaunchKernelGGL(k_missed_g, dim3(1), dim3(1024), 0, st, h->ctl.p, (const Cand*)h->gpart.p, h->gpart_stride,
                                        (size_t)win * 4 + 4, shard_world, h->missed.p, CC_MISSED_CAP, round, mode, h->found.p);
-                    seeded_chain(CC_MISSED_CAP, h->missed.p, part, h->part_stride, S);
+                    missed_scan(h->missed.p);
                     return;
                 }
                 if (h->prune_now) {
@@ -720,7 +732,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                             return;
                         }
                         hipLaunchKernelGGL(k_missed, dim3(1), dim3(1024), 0, st, h->ctl.p, h->found.p, list, CC_MISSED_CAP, round, mode);
-                        seeded_chain(CC_MISSED_CAP, list, part, h->part_stride, S);
+                        missed_scan(list);
                         return;
                     }
                     seeded_chain(win, nullptr, part, h->part_stride, S);
@@ -985,6 +997,8 @@ int cc_create(int device, cc_handle** out)
         if (sa) h->split_a_mode = std::max(0, std::min(2, atoi(sa)));
         const char* ln = getenv("CHRONOCLUST_HIP_LEAN");
         h->allow_lean = !(ln && ln[0] == '0');
+        const char* mpl = getenv("CHRONOCLUST_HIP_MISSED_PLAIN");
+        if (mpl && atoi(mpl) == 0) h->allow_missed_plain = false;
         const char* p2 = getenv("CHRONOCLUST_HIP_SCANP2");
         h->allow_scan_p2 = !(p2 && p2[0] == '0');
         const char* lk = getenv("CHRONOCLUST_HIP_LINK");

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
                                                                  const int* __restrict__ g_kind,
                                                                  const int* __restrict__ g_key, Cand* __restrict__ part,
                                                                  int round, int mode, size_t part_stride, int shard_rank,
-                                                                 int shard_world)
+                                                                 int shard_world, const int* __restrict__ plist = nullptr)
 {
     static_assert(DP % 2 == 0 && DP >= 4 && DP <= 64, "padded dimensionalities are even");
     // a row is read in NC chunks of whole pairs of dimensions (at most ten dimensions: 20 SGPRs), alternately into two
@@ -643,24 +643,30 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
     constexpr int NP = DP / 2;
     constexpr int NC = 2 * ((NP + 9) / 10);
     constexpr int CH_MAX = 2 * ((NP + NC - 1) / NC);
-    int B, m_rows_scan;
+    int B, m_rows_scan, q;
     long long cursor;
     if (mode == 1) {
-        const int q = round & 1;
+        q = round & 1;
         B = ctl->la_b[q];
         m_rows_scan = ctl->la_rows[q];
         cursor = ctl->la_cursor[q];
-        part += (size_t)q * part_stride;
     } else {
         B = ctl->win_b;
         m_rows_scan = ctl->m_rows;
         cursor = ctl->cursor;
         if (ctl->mode != 0) return;  // this window's snapshot scan ran ahead
-        part += (size_t)(ctl->window_seq & 1ull) * part_stride;
+        q = (int)(ctl->window_seq & 1ull);
     }
+    part += (size_t)q * part_stride;
     if (B == 0) return;
+    // plist (round 6): not the window's tiles but the points a guessed-threshold scan missed (k_missed's / k_missed_g's list of
+    // the window's parity).  Such a point has no microcluster within the guess: a seeded threshold of its own is as wide as
+    // its nearest microcluster is far, the pruned chain completes most rows for it - one by one, each a chain of dependent
+    // round trips (187 us per launch for ten points of the C2 stream) -, and the plain scan is the faster kernel by ten.
+    if (plist) plist += (size_t)q * CC_MISSED_CAP;
+    const int n_here = plist ? ctl->n_missed[q] : B;
     const int j0 = (int)blockIdx.x * 64;
-    if (j0 >= B) return;
+    if (j0 >= n_here) return;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int S = gridDim.y;
@@ -675,8 +681,8 @@ __global__ __launch_bounds__(64 * NW, ScanUShape<DP>::WGS) void k_scan_u(const C
     const size_t n_pts = (size_t)ctl->xt_stride;
     const double k = ctl->k;
     const double inv_k = ctl->inv_k;
-    const int jj = j0 + lane;
-    const bool valid = jj < B;
+    const bool valid = j0 + lane < n_here;
+    const int jj = plist ? (valid ? plist[j0 + lane] : 0) : j0 + lane;
 
     double p[DP];
     {

@@ -147,6 +147,7 @@ typedef struct cc_stats {
     double  calib_scan_ns_per_row_dim;  /* plain snapshot scan of a full window: ns per (table row, dimension)             */
     int64_t split_threshold_row_dims;
     int64_t split_threshold_row_dims_pruned;
+    int64_t missed_plain_launches; /* plain scans (k_scan_u over a point list) for the points a guessed-threshold scan missed */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
