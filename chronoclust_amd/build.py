@@ -81,5 +81,29 @@ def build_div_test(force=False):
     return DIV_TEST_PROGRAM
 
 
+P16_TEST_SOURCE = os.path.join(os.path.dirname(_HERE), "tests", "hip", "prefix16_check.hip")
+P16_TEST_PROGRAM = os.path.join(os.path.dirname(_HERE), "tests", "hip", "_build", "prefix16_check")
+
+
+def build_prefix16_test(force=False):
+    """The device check of csrc/cc_scan16.h (tests/hip/prefix16_check.hip: MFMA operand layout, accumulation error, and the
+    statement "abandoned implies beyond the threshold"; tests/test_prefix16.py runs it on the GPU box).  Keyed to the content
+    of the kernel sources it includes."""
+    hsh = hashlib.sha256(open(P16_TEST_SOURCE, "rb").read())
+    for path in SOURCES[1:] + [HEADER]:
+        hsh.update(open(path, "rb").read())
+    digest = hsh.hexdigest()
+    stamp = P16_TEST_PROGRAM + ".sha256"
+    if not force and os.path.exists(P16_TEST_PROGRAM) and os.path.exists(stamp) and open(stamp).read().strip() == digest:
+        return P16_TEST_PROGRAM
+    os.makedirs(os.path.dirname(P16_TEST_PROGRAM), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-w",
+                           P16_TEST_SOURCE, "-o", P16_TEST_PROGRAM])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    return P16_TEST_PROGRAM
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

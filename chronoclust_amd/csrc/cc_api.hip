@@ -189,6 +189,9 @@ struct cc_handle {
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
+    DevBuf<cc_h8> a16;        // [2][(table capacity + 64) x 2]  k_prefix16: the table rows as half-precision operands of the MFMA prefix test (two window parities)
+    DevBuf<Prefix16Hdr> hdr16;  // [2]              ... origin and scale they were converted with
+    size_t a16_stride = 0;
     DevBuf<unsigned> masks;   // [2][tiles of 128 points, sub-ranges, words per sub-range]  k_scan_a's survivor masks (two window parities)
     size_t mask_stride = 0;
     // CHRONOCLUST_HIP_SCANA: 0 phase A inside k_scan_p (one point per lane, the round-3 form), 2 always as a kernel of its own
@@ -205,6 +208,8 @@ struct cc_handle {
     bool allow_long = true;     // CHRONOCLUST_HIP_LONGCHAINS=0: every chain replayed by k_chain
     bool allow_quiet = true;    // CHRONOCLUST_HIP_QUIET=0: k_decide re-derives every decision of a validation round even when k_dseed has shown that all of them repeat their claims
     bool allow_missed_plain = true;  // CHRONOCLUST_HIP_MISSED_PLAIN=0: the points a guessed threshold missed go through the seeded chain, not k_scan_u
+    int p3_listed_rows = 10000;  // CHRONOCLUST_HIP_P3_LISTED=<rows>: k_scan_p3 lists the rows phase A keeps from this many table rows on
+    bool allow_scan_p3 = true;   // CHRONOCLUST_HIP_SCANP3=0: the prefix test of the window's pruned scan on the VALU (k_scan_p2), not the matrix cores
     bool allow_scan_p2 = true;  // CHRONOCLUST_HIP_SCANP2=0: the pruned scan of a window as k_scan_p (one point per lane) instead of k_scan_p2
     bool allow_link = true;     // CHRONOCLUST_HIP_LINK=0: round 0 does not link the points that decide "create" among themselves (cc_link.h)
     DevBuf<int> link_near;      // [window] k_link_scan: per window point that decided "create", the earliest such point before it that would absorb it
@@ -628,8 +633,37 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 // k_scan_p for the window's points: phase A as a kernel of its own (two points per lane, survivor masks), phase
                 // B behind it; lists of points (the ones a guessed threshold missed, probes) keep the one-kernel form
                 auto scan_p_window = [&](int srank, int sworld, double gF, unsigned long long* found_) {
-                    if (h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000)) {
+                    const bool one_kernel = h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000);
+                    if (one_kernel || (h->allow_scan_p3 && h->split_a_mode == 1 && DP <= 40)) {
                         if constexpr (DP <= 40) {
+                            // one kernel, phase A on the matrix cores (cc_scan16.h): the rows as half-precision operands first
+                            // (at any table size: CHRONOCLUST_HIP_SCANA=2 keeps the two-kernel form of large tables)
+                            if (h->allow_scan_p3) {
+                                const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
+                                if (h->a16_stride < a16_rows * 2) {
+                                    // (grown between batches only: a scan in flight on the other stream may be reading it)
+                                    sync_stream(h, h->stream);
+                                    sync_stream(h, h->stream2);
+                                    h->a16.ensure(2 * a16_rows * 2);
+                                    h->a16_stride = a16_rows * 2;
+                                    h->hdr16.ensure(2);
+                                }
+                                hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
+                                                   rows.cen, rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
+                                // (unused dynamic LDS caps the workgroups a CU holds: CHRONOCLUST_HIP_SCAN_LDS_KB, an experiment knob)
+                                static const unsigned p3_lds = []() { const char* e = getenv("CHRONOCLUST_HIP_SCAN_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
+                                // (kept rows listed per wave and walked with their operands prefetched - LISTED - from p3_listed_rows table rows on)
+                                if (h->hc.m_rows >= h->p3_listed_rows)
+                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, true>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                                       rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
+                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                                else
+                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, false>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                                       rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
+                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                                ++h->stats.scan_p2_launches;
+                                return;
+                            }
                             // one kernel, two points per lane in phase A, phase B from the same residency (k_scan_p2)
                             if (h->allow_scan_p2) {
                                 hipLaunchKernelGGL((k_scan_p2<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
@@ -999,6 +1033,10 @@ int cc_create(int device, cc_handle** out)
         h->allow_lean = !(ln && ln[0] == '0');
         const char* mpl = getenv("CHRONOCLUST_HIP_MISSED_PLAIN");
         if (mpl && atoi(mpl) == 0) h->allow_missed_plain = false;
+        const char* p3l = getenv("CHRONOCLUST_HIP_P3_LISTED");
+        if (p3l) h->p3_listed_rows = atoi(p3l);
+        const char* p3 = getenv("CHRONOCLUST_HIP_SCANP3");
+        if (p3 && atoi(p3) == 0) h->allow_scan_p3 = false;
         const char* p2 = getenv("CHRONOCLUST_HIP_SCANP2");
         h->allow_scan_p2 = !(p2 && p2[0] == '0');
         const char* lk = getenv("CHRONOCLUST_HIP_LINK");
@@ -1870,7 +1908,11 @@ struct OnlineRun {
         const int scan_cus = h->n_cus;
         // (measured, `profiles/r03_tool_prune_split.txt`: four rounds of the resident workgroups at d <= 20 - k_scan_p is
         // compiled for four per CU there -, eight of the three per CU beyond)
-        const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? 16 : 24);
+        // (round 6, k_scan_p3: the prefix test costs next to nothing on the matrix cores, what is left of a workgroup's time is its
+        // prologue - the points staged, their constants - and the rows it completes: two rounds of the resident workgroups at
+        // d <= 20, 54 against 63 us per C2 window running alone, half the partials per point)
+        const bool p3 = h->allow_scan_p3 && h->d <= 40 && h->split_a_mode != 2;
+        const int prune_wgs = h->prune_rounds4 > 0 ? h->prune_rounds4 : (h->d <= 20 ? (p3 ? 8 : 16) : 24);
         const int S = h->prune_now ? std::max(1, std::min(S_cfg, (scan_cus * prune_wgs) / std::max(1, (gw + 63) / 64)))
                                    : scan_partials_for((gw + 63) / 64, S_cfg, scan_resident_wgs(h, scan_cus));
         // capacity of the round's list for the sparse dirty scans: a sixteenth of the window (the policy's bound on

@@ -223,6 +223,7 @@ __device__ __forceinline__ double cc_sel_scale(unsigned mask, double scaled, dou
 
 // The kernels of the online phase, by stage (all of them see the helpers above):
 #include "cc_scan.h"      // snapshot scans and dirty scans
+#include "cc_scan16.h"    // the pruned scan's prefix test on the matrix cores (k_prefix16, k_scan_p3)
 #include "cc_validate.h"  // k_dseed, k_decide, k_claims, k_chain, k_chain_long, k_commit_a / b
 #include "cc_link.h"      // round 0 that knows the window's own creators (k_link_scan, k_link_apply)
 #include "cc_seq.h"       // the sequential kernel (table in LDS)

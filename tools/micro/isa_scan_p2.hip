@@ -6,7 +6,12 @@
 #include "../../include/chronoclust_hip.h"
 #include "../../chronoclust_amd/csrc/cc_common.h"
 #include "../../chronoclust_amd/csrc/cc_online.h"
+#ifndef ISA_LISTED
+#define ISA_LISTED false
+#endif
 #ifndef ISA_DP
 #define ISA_DP 20
 #endif
 template __global__ void k_scan_p2<ISA_DP, 4>(Ctl*, const double*, const double*, const double*, const int*, const int*, const double*, size_t, Cand*, int, int, size_t, int, int, unsigned long long*, double, unsigned long long*);
+template __global__ void k_scan_p3<ISA_DP, 4, ISA_LISTED>(Ctl*, const double*, const double*, const double*, const int*, const int*, const double*, size_t, Cand*, int, int, size_t, int, int, unsigned long long*, double, unsigned long long*, const cc_h8*, const Prefix16Hdr*, size_t);
+template __global__ void k_prefix16<ISA_DP>(const Ctl*, const double*, const int*, cc_h8*, Prefix16Hdr*, size_t, int, int);

@@ -39,5 +39,6 @@ if len(eps) >= 2:
         prev = r["End_Timestamp"]
 PY
 python3 tools/kernel_avgs.py $OUT/trace > $OUT/kernel_avgs.txt
+python3 tools/window_detail.py $OUT/trace ${WDETAIL:-45} 2 > $OUT/window_detail.txt
 find $OUT -name "*kernel_trace.csv" -delete
 cut -c1-300 $OUT/bench.txt | tail -2; cat $OUT/tail.txt | head -120
