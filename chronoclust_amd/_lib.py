@@ -57,7 +57,8 @@ class CcPolicyConfig(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("window", "rounds_max", "windows_per_sync", "early_window", "lookahead",
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
                                          "allow_sparse", "allow_guess", "allow_probe")] + \
-               [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64), ("shard_min_row_dims_pruned", C.c_int64)]
+               [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64), ("shard_min_row_dims_pruned", C.c_int64),
+                ("lookahead_pruned", C.c_int32), ("pad", C.c_int32)]
 
 
 class CcPolicyCarry(C.Structure):

@@ -180,6 +180,7 @@ struct cc_handle {
     DevBuf<Cand> probe_part;  // ... into these scratch partials
     bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
     bool allow_lean = true;   // CHRONOCLUST_HIP_LEAN=0: guessed scans always list and rescan the points they missed
+    bool la_pruned = false;   // CHRONOCLUST_HIP_LA_PRUNED=1: lookahead scans also while the scans are pruned chains on one GPU
     bool allow_probe = true;  // CHRONOCLUST_HIP_PROBE=0: pruned scans are retried blindly after a stretch of points
     DevBuf<unsigned long long> found;  // [2][CC_MAX_WINDOW / 64] per point tile: the points a guessed-threshold scan found a pcore MC for
     DevBuf<int> missed;                // [2][CC_MISSED_CAP] the others, listed by k_missed (two window parities)
@@ -189,7 +190,7 @@ struct cc_handle {
     DevBuf<double> thr;       // [2][window, 2]     abandon thresholds per point and kind
     DevBuf<float> thr32;      // [2][window, 2]     ... and what phase A's single-precision prefix sums are compared with
     DevBuf<unsigned long long> cmax;  // [2]        largest |centroid coordinate| of the scanned prefixes (bits of a double)
-    DevBuf<cc_h8> a16;        // [2][(table capacity + 64) x 2]  k_prefix16: the table rows as half-precision operands of the MFMA prefix test (two window parities)
+    DevBuf<cc_h8> a16;        // [2][(table capacity + 64) x 4]  k_prefix16: the table rows as half-precision operands of the MFMA prefix test (two window parities)
     DevBuf<Prefix16Hdr> hdr16;  // [2]              ... origin and scale they were converted with
     size_t a16_stride = 0;
     DevBuf<unsigned> masks;   // [2][tiles of 128 points, sub-ranges, words per sub-range]  k_scan_a's survivor masks (two window parities)
@@ -352,9 +353,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld, \"shard_min_row_dims_pruned\": %lld}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld, \"shard_min_row_dims_pruned\": %lld, \"lookahead_pruned\": %d}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end, (long long)c.shard_min_row_dims_pruned,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end, (long long)c.shard_min_row_dims_pruned, c.lookahead_pruned,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -640,12 +641,12 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                             // (at any table size: CHRONOCLUST_HIP_SCANA=2 keeps the two-kernel form of large tables)
                             if (h->allow_scan_p3) {
                                 const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
-                                if (h->a16_stride < a16_rows * 2) {
+                                if (h->a16_stride < a16_rows * 4) {
                                     // (grown between batches only: a scan in flight on the other stream may be reading it)
                                     sync_stream(h, h->stream);
                                     sync_stream(h, h->stream2);
-                                    h->a16.ensure(2 * a16_rows * 2);
-                                    h->a16_stride = a16_rows * 2;
+                                    h->a16.ensure(2 * a16_rows * 4);
+                                    h->a16_stride = a16_rows * 4;
                                     h->hdr16.ensure(2);
                                 }
                                 hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
@@ -1033,6 +1034,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_lean = !(ln && ln[0] == '0');
         const char* mpl = getenv("CHRONOCLUST_HIP_MISSED_PLAIN");
         if (mpl && atoi(mpl) == 0) h->allow_missed_plain = false;
+        const char* lap = getenv("CHRONOCLUST_HIP_LA_PRUNED");
+        if (lap && atoi(lap) != 0) h->la_pruned = true;
         const char* p3l = getenv("CHRONOCLUST_HIP_P3_LISTED");
         if (p3l) h->p3_listed_rows = atoi(p3l);
         const char* p3 = getenv("CHRONOCLUST_HIP_SCANP3");
@@ -1708,6 +1711,8 @@ struct OnlineRun {
         pcfg.allow_sparse = h->allow_sparse;
         pcfg.allow_guess = h->allow_guess ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
         pcfg.allow_probe = h->allow_probe ? 1 : 0;
+        pcfg.lookahead_pruned = h->la_pruned ? 1 : 0;
+        pcfg.pad = 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.shard_min_row_dims_pruned = h->shard_min_row_dims_pruned;
         pcfg.n_end = N;

@@ -216,7 +216,6 @@ public:
         // costs a truncated window and two more batches at the start-up window size, ~0.9 ms of a C2 step,
         // profiles/r05_tool_startup_lookahead.txt -; once on it stays on until a window is cut short)
         const bool calm = tiles > 0 && (dtiles * 8 <= tiles || few_flagged);
-        const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned && (la_on_ || calm));
         // While plain scans run, the batch's first window also runs the pruned chain on 128 of its points (a probe: its
         // results are not used, its sample is): pruned scans come back as soon as the probe says they would pay, instead
         // of being tried on whole batches that cost twice the plain scan when they fail.
@@ -237,6 +236,14 @@ public:
         const bool shard_next = policy_want_shard(c_, o.m_rows, prune_on_);
         const bool shard_flip = shard_next != shard_on_;
         shard_on_ = shard_next;
+        // (round 6) ... and while the scan is long enough to be worth a stream of its own.  A PRUNED scan no longer is: with its
+        // prefix test on the matrix cores (k_scan_p3) a full window's chain takes 55 us of the window's 180, the two streams share one
+        // machine - what runs beside the scan runs that much slower (profiles/r06_tool_window_detail.txt) -, and the scan copies,
+        // the carry set and its dirty scan are work the in-place scan does not have: C2 14.2 -> 14.0 ms, the C4 shape 148 -> 154 M
+        // points/s with lookahead off.  Split over the ranks of a group the scan's chain ends in an all-gather, which the second
+        // stream does hide: lookahead as before.
+        const bool short_scan = c_.lookahead != 3 && prune_on_ && !shard_on_ && c_.lookahead_pruned == 0;
+        const bool want_la = c_.lookahead == 3 || (c_.lookahead != 2 && trunc_batch == 0 && !unpruned && (la_on_ || calm) && !short_scan);
         probe_gate_ = grew == 0 && !unpruned && want >= std::min(8192, c_.window);
         // Guessed thresholds (k_scan_p with Ctl::tg instead of k_seed + k_seed_merge, which cost as much as the scan they
         // serve): while a mean join distance exists and few points are missed - more than one in sixteen: back to seeds

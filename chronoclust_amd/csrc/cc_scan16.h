@@ -72,13 +72,15 @@ __device__ __forceinline__ _Float16 cc_rn16(double x)
 // A = sqrt(8) (u (pm' + 1) + 2 a) (pm' = pm (1 + 2^-9) + a bounds the unrounded |p'_i|).  U^ = s - 2 p^.c^ + 2 H, H = |c^|^2 / 2.
 // The accumulator holds D = p^.c^ - h^ - tau^ + delta: the products are exact in single precision (11 x 11 bits), the sum of
 // the <= 14 terms is taken to be off by at most g (8 pm + H + |tau^|), g = 2^-18 (sixteen additions at two units in the last
-// place each, the alignment shifts of a fused adder tree included - tests/hip/prefix16_check.hip measures it: < 2^-22);
+// place each, the alignment shifts of a fused adder tree included - tests/hip/prefix16_check.hip measures it: < 2^-21);
 // |h^ - H| <= eh = 2^-19 (two pieces: 2^-22 H + a flushed remainder, H <= 4); tau^ <= tau (both pieces rounded down).
+// With a prefix of np > 8 dimensions (a second MFMA over dimensions 8 .. np - 1 accumulates into the first one's result):
+// sqrt(np) for sqrt(8), np pm for 8 pm, H <= np / 2, up to 30 terms: g = 2^-17, eh = 2^-18 - the constants the code uses for any np.
 // D < 0 then implies U^ > s - 2 tau - 2 g (..) - 2 eh >= L = (sqrt(Ts (1 + 2^-40) / smin) + A)^2 for
 //     tau <= (s - L) / 2 - g (|tau0| + 8 pm + 4) (1 + 2^-10) - eh,
 // hence U > Ts / smin and P > T.  A tau below -60000 is clamped there: the accumulator is then positive whatever the row
 // (|p^.c^ - h^| <= 12), i.e. nothing is abandoned, as for T = inf.  Returns the two pieces (tau1, tau2 2^10).
-__device__ __forceinline__ void cc_tau16(double Ts, double s, double pm, double inv_k, bool ok, _Float16& t1, _Float16& t2)
+__device__ __forceinline__ void cc_tau16(double Ts, double s, double pm, double inv_k, bool ok, _Float16& t1, _Float16& t2, int np = 8)
 {
     t1 = (_Float16)(-CC_P16_BIG);  // never abandon
     t2 = (_Float16)0.0f;
@@ -86,11 +88,11 @@ __device__ __forceinline__ void cc_tau16(double Ts, double s, double pm, double 
     const double smin = inv_k < 1.0 ? inv_k : 1.0;
     const double u = 0x1p-11 * (1.0 + 0x1p-9), a = 0x1p-14;
     const double pmr = pm * (1.0 + 0x1p-9) + a;
-    const double A = 2.8284271247461903 * (1.0 + 0x1p-20) * (u * (pmr + 1.0) + 2.0 * a);
+    const double A = sqrt((double)np) * (1.0 + 0x1p-20) * (u * (pmr + 1.0) + 2.0 * a);
     const double r = sqrt(Ts * (1.0 + 0x1p-40) / smin) * (1.0 + 0x1p-50) + A;
     const double L = r * r * (1.0 + 0x1p-20);
     const double tau0 = 0.5 * (s - L) - 0x1p-48 * s;
-    const double tau = tau0 - 0x1p-18 * (1.0 + 0x1p-10) * (__builtin_fabs(tau0) + 8.0 * pm + 4.0) - 0x1p-19 - 0x1p-100;
+    const double tau = tau0 - 0x1p-17 * (1.0 + 0x1p-10) * (__builtin_fabs(tau0) + (double)np * pm + 0.5 * (double)np) - 0x1p-18 - 0x1p-100;
     if (!(tau > -(double)CC_P16_BIG)) return;  // (NaN included)
     t1 = cc_rd16(tau);
     const double rest = tau - (double)t1;  // >= 0, exact
@@ -104,11 +106,17 @@ __device__ __forceinline__ void cc_tau16(double Ts, double s, double pm, double 
 // and scale to the scan (the scan converts its points with the same values).  A row with a coordinate beyond the scale
 // (|c^_i| > 1: the bound it was derived from is read without synchronisation with the other stream's commits) is never abandoned.
 // ---------------------------------------------------------------------------------
+// dimensions of the prefix test at dimensionality DP: all of them up to 24 (eight in the first MFMA, the rest in the second)
+template <int DP>
+struct Prefix16 {
+    static constexpr int NP = DP < 24 ? DP : 24;
+};
 template <int DP>
 __global__ __launch_bounds__(256) void k_prefix16(const Ctl* __restrict__ ctl, const double* __restrict__ g_cen,
                                                   const int* __restrict__ g_kind, cc_h8* __restrict__ a16,
                                                   Prefix16Hdr* __restrict__ hdr, size_t a16_stride, int round, int mode)
 {
+    constexpr int NP = Prefix16<DP>::NP;
     const ScanWin win = cc_scan_window(ctl, round, mode);
     if (win.B == 0) return;
     a16 += (size_t)win.q * a16_stride;
@@ -130,9 +138,9 @@ __global__ __launch_bounds__(256) void k_prefix16(const Ctl* __restrict__ ctl, c
     // (the scan reads whole tiles of 32 rows: the rows behind the last one are written as rows of neither list)
     const int rows_pad = ((win.rows + CC_P16_TM - 1) / CC_P16_TM) * CC_P16_TM + CC_P16_TM;  // (a rank's share need not start on a tile)
     if (row >= rows_pad) return;
-    cc_h8 lo, hi;
+    cc_h8 lo, hi, x1, x2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { lo[i] = (_Float16)0.0f; hi[i] = (_Float16)0.0f; }
+    for (int i = 0; i < 8; ++i) { lo[i] = (_Float16)0.0f; hi[i] = (_Float16)0.0f; x1[i] = (_Float16)0.0f; x2[i] = (_Float16)0.0f; }
     if (row < win.rows) {
         const double* c = g_cen + (size_t)row * DP;
         double H = 0.0;
@@ -143,6 +151,16 @@ __global__ __launch_bounds__(256) void k_prefix16(const Ctl* __restrict__ ctl, c
             wild = wild || !(__builtin_fabs(x) <= 1.0);
             const _Float16 xh = cc_rn16(x);
             lo[i] = xh;
+            H += (double)xh * (double)xh;
+        }
+        // dimensions 8 .. NP - 1: the second MFMA's operand (centred on the same row 0)
+#pragma unroll
+        for (int i = 8; i < NP; ++i) {
+            const double x = (c[i] - g_cen[i]) * sc;
+            wild = wild || !(__builtin_fabs(x) <= 1.0);
+            const _Float16 xh = cc_rn16(x);
+            if (i < 16) x1[i - 8] = xh;
+            else x2[i - 16] = xh;
             H += (double)xh * (double)xh;
         }
         H *= 0.5;
@@ -157,11 +175,13 @@ __global__ __launch_bounds__(256) void k_prefix16(const Ctl* __restrict__ ctl, c
         hi[5] = (kd == CC_KIND_OUTLIER) ? (_Float16)0x1p-10f : (_Float16)0.0f;
         if (wild) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) lo[i] = (_Float16)0.0f;
+            for (int i = 0; i < 8; ++i) { lo[i] = (_Float16)0.0f; x1[i] = (_Float16)0.0f; x2[i] = (_Float16)0.0f; }
         }
     }
-    a16[(size_t)row * 2] = lo;
-    a16[(size_t)row * 2 + 1] = hi;
+    a16[(size_t)row * 4] = lo;
+    a16[(size_t)row * 4 + 1] = hi;
+    a16[(size_t)row * 4 + 2] = x1;
+    a16[(size_t)row * 4 + 3] = x2;
 }
 
 // ---------------------------------------------------------------------------------
@@ -210,7 +230,8 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
     constexpr int MERGE_BYTES = (NW > 1 ? NW - 1 : 1) * 8 * 64 * (int)sizeof(Cand);
     constexpr int PTS_BYTES = PTS_DOUBLES * 8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[PTS_BYTES > MERGE_BYTES ? PTS_BYTES : MERGE_BYTES];
-    __shared__ __attribute__((aligned(16))) _Float16 s_p16[128 * 8];  // the points' scaled prefixes: [point][8]
+    constexpr int NP = Prefix16<DP>::NP;  // dimensions of the prefix test
+    __shared__ __attribute__((aligned(16))) _Float16 s_p16[128 * 24];  // the points' scaled prefixes: [point][24] (zeros beyond NP)
     __shared__ __attribute__((aligned(8))) _Float16 s_tau[128 * 4];   // [point][tauP1, tauP2 2^10, tauO1, tauO2 2^10], negated
     __shared__ double s_T[2 * 128];
     // phase B is deferred: the (row, half) pairs phase A keeps are LISTED per wave and walked afterwards with the next rows'
@@ -242,11 +263,20 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
     // the points' prefixes in half precision (four values per thread), then per (point, kind) the constant of the test
     static_assert(NW == 4, "the prologue's work split assumes 256 threads");
     {
-        const int x = (int)threadIdx.x & 127, i0 = 4 * ((int)threadIdx.x >> 7);
-        cc_h4 v;
+        // (thread = (point, half of the 24 slots): twelve values each)
+        const int x = (int)threadIdx.x & 127, i0 = 12 * ((int)threadIdx.x >> 7);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = cc_rn16((s_pts[(i0 + i) * 128 + x] - hdr->org[i0 + i]) * sc);
-        *reinterpret_cast<cc_h4*>(s_p16 + x * 8 + i0) = v;
+        for (int q = 0; q < 3; ++q) {
+            cc_h4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dim = i0 + 4 * q + i;
+                // (centred on table row 0 - hdr->org holds its first eight coordinates, the others are read from the table)
+                v[i] = (dim < NP) ? cc_rn16((s_pts[(dim < DP ? dim : 0) * 128 + x] - (dim < 8 ? hdr->org[dim < 8 ? dim : 0] : g_cen[dim < DP ? dim : 0])) * sc)
+                                  : (_Float16)0.0f;
+            }
+            *reinterpret_cast<cc_h4*>(s_p16 + x * 24 + i0 + 4 * q) = v;
+        }
     }
     __syncthreads();
     {
@@ -254,10 +284,10 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
         double s2 = 0.0, pm = 0.0;
         bool fin = true;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const double raw = (s_pts[i * 128 + x] - hdr->org[i]) * sc;
+        for (int i = 0; i < NP; ++i) {
+            const double raw = (s_pts[i * 128 + x] - (i < 8 ? hdr->org[i < 8 ? i : 0] : g_cen[i])) * sc;
             fin = fin && (__builtin_fabs(raw) <= 1.0);
-            const double v = (double)s_p16[x * 8 + i];
+            const double v = (double)s_p16[x * 24 + i];
             s2 += v * v;
             pm = __builtin_fmax(pm, __builtin_fabs(v));
         }
@@ -266,23 +296,25 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
         if (T == -CC_INF) {  // a lane without a point keeps no row alive
             t1 = (_Float16)CC_P16_BIG;
             t2 = (_Float16)0.0f;
-        } else cc_tau16(T * sc * sc, s2, pm, inv_k, fin && sc > 0.0, t1, t2);
+        } else cc_tau16(T * sc * sc, s2, pm, inv_k, fin && sc > 0.0, t1, t2, NP);
         s_tau[x * 4 + K * 2] = -t1;
         s_tau[x * 4 + K * 2 + 1] = -t2;
         if (K == 0 && !(fin && sc > 0.0)) {  // (a point beyond the scale: its prefix must not reach the matrix cores as inf)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s_p16[x * 8 + i] = (_Float16)0.0f;
+            for (int i = 0; i < 24; ++i) s_p16[x * 24 + i] = (_Float16)0.0f;
         }
     }
     __syncthreads();
     // the four A operands: points 32 b + (lane & 31); lane half 0 the prefix, half 1 the constants (read again from LDS at the
     // start of every pass over tiles: they need not stay in registers while a list is walked)
-    auto load_a = [&](cc_h8 (&afr)[4]) {
+    auto load_a = [&](cc_h8 (&afr)[4], cc_h8 (&afx)[4]) {
         const int r = lane & 31;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int x = 32 * b + r;
-            if (lane < 32) afr[b] = *reinterpret_cast<const cc_h8*>(s_p16 + x * 8);
+            // (the second MFMA: dimensions 8 .. 15 on lane half 0, 16 .. 23 on half 1)
+            if constexpr (NP > 8) afx[b] = *reinterpret_cast<const cc_h8*>(s_p16 + x * 24 + 8 + 8 * (lane >> 5));
+            if (lane < 32) afr[b] = *reinterpret_cast<const cc_h8*>(s_p16 + x * 24);
             else {
                 const cc_h4 t = *reinterpret_cast<const cc_h4*>(s_tau + x * 4);
                 afr[b] = cc_h8{(_Float16)1.0f, (_Float16)0x1p-10f, t[0], t[1], t[2], t[3], (_Float16)0.0f, (_Float16)0.0f};
@@ -340,7 +372,9 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
                     acc = (qlo + i == 0) ? x : acc + x;    // :41
                 }
             });
-            if constexpr (hi < DP) {
+            // (no exact test inside the dimensions phase A has already tested in half precision: a row that passed there passes
+            // here but for rounding, and without the test the row's operands are one round trip instead of one per eight dimensions)
+            if constexpr (hi < DP && hi >= NP) {
                 const double t = thx(u, is_p ? 0 : 1);
                 if (__builtin_amdgcn_ballot_w64(acc <= t) == 0ull) {
                     if (is_p) lb[u][0] = cc_vmin(lb[u][0], acc);
@@ -423,22 +457,25 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
         CC_WAVE_SYNC();  // (the list may be rewritten)
     };
     const bool test_on = sc > 0.0;  // (no usable scale: every row goes to phase B)
-    auto load_b = [&](int rt) -> cc_h8 { return a16[(size_t)(rt + (lane & 31)) * 2 + (lane >> 5)]; };
+    auto load_b = [&](int rt) -> cc_h8 { return a16[(size_t)(rt + (lane & 31)) * 4 + (lane >> 5)]; };
+    auto load_bx = [&](int rt) -> cc_h8 { return a16[(size_t)(rt + (lane & 31)) * 4 + 2 + (lane >> 5)]; };
     // passes: tiles until the list could overflow (two halves x 32 rows per tile), then the walk; one pass unless most rows stay
     int rt = r0;
     while (rt < r1) {
-    cc_h8 afr[4];
-    load_a(afr);
-    cc_h8 bfr = load_b(rt);
+    cc_h8 afr[4], afx[4];
+    load_a(afr, afx);
+    cc_h8 bfr = load_b(rt), bfx;
+    if constexpr (NP > 8) bfx = load_bx(rt);
     int kdl = (lane < min(CC_P16_TM, r1 - rt)) ? g_kind[rt + lane] : CC_KIND_DEAD;
     int n_list = 0;
     for (; rt < r1 && (!LISTED || n_list + 2 * CC_P16_TM <= LCAP); rt += CC_P16_TM) {
         const int tm = __builtin_amdgcn_readfirstlane(min(CC_P16_TM, r1 - rt));
-        const cc_h8 bcur = bfr;
+        const cc_h8 bcur = bfr, bxcur = bfx;
         const unsigned pmask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_PCORE);
         const unsigned omask = (unsigned)__builtin_amdgcn_ballot_w64(kdl == CC_KIND_OUTLIER);
         if (rt + CC_P16_TM < r1) {
             bfr = load_b(rt + CC_P16_TM);
+            if constexpr (NP > 8) bfx = load_bx(rt + CC_P16_TM);
             kdl = (lane < min(CC_P16_TM, r1 - rt - CC_P16_TM)) ? g_kind[rt + CC_P16_TM + lane] : CC_KIND_DEAD;
         }
         n_rows += 2 * tm;
@@ -452,8 +489,12 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
                 cc_f16acc z;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-                const cc_f16acc d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[2 * u], bcur, z, 0, 0, 0);
-                const cc_f16acc d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[2 * u + 1], bcur, z, 0, 0, 0);
+                cc_f16acc d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[2 * u], bcur, z, 0, 0, 0);
+                cc_f16acc d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afr[2 * u + 1], bcur, z, 0, 0, 0);
+                if constexpr (NP > 8) {
+                    d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afx[2 * u], bxcur, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(afx[2 * u + 1], bxcur, d1, 0, 0, 0);
+                }
                 // "some D >= 0" on the bit patterns: a float with its sign bit clear is a non-negative int (v_max3_i32 needs no
                 // canonicalisation of its inputs; -0 cannot arise from a +0 accumulator, and cc_tau16's slack covers D = 0)
                 typedef int cc_i16v __attribute__((ext_vector_type(16)));

@@ -370,6 +370,9 @@ typedef struct cc_policy_config {
     int64_t shard_min_row_dims;
     int64_t n_end;             /* end of the range of points the call clusters                                     */
     int64_t shard_min_row_dims_pruned;  /* the split threshold while the scans are pruned chains (0: shard_min_row_dims)   */
+    int32_t lookahead_pruned;  /* 1: lookahead scans also while the scans are pruned chains on one GPU (CHRONOCLUST_HIP_LA_PRUNED=1;
+                                * round 6: off - such a scan is too short to be worth a stream of its own, cc_policy.h)        */
+    int32_t pad;
 } cc_policy_config;
 typedef struct cc_policy_carry {
     int32_t adapt_win, clean_batches, since_shrink, pad;

@@ -58,15 +58,17 @@ def test_recorded_decisions_are_a_function_of_the_counters(path):
 
 def test_the_traces_cover_the_regimes():
     by_name = {os.path.basename(p)[:-6]: calls_of(p) for p in TRACES}
-    # C2: small windows on the empty table, growth, the start-up window, then the full window with lookahead, the
-    # dirty scans left out and pruned snapshot scans
+    # C2: small windows on the empty table, growth, the start-up window, then the full window, the dirty scans left out and
+    # pruned snapshot scans - in place since round 6: a pruned scan on one GPU is too short for a stream of its own
+    # (cc_policy.h, `short_scan`); while the scans are still plain and the stream is calm, lookahead scans run
     c2 = by_name["c2_startup_and_steady"][0]
     sizes = [c2[3]["win_cfg"]] + [d["win_cfg"] for _, d in c2[4]]
     assert sizes[0] == 256 and 4096 in sizes and sizes[-1] == 32768 and max(sizes[:4]) <= 4096
     last = c2[4][-1][1]
     # (prune 2: pruned scans with guessed thresholds - a mean join distance exists by then, few points are missed;
     #  prune 3: the same without the list of missed points, after a batch in which none was missed)
-    assert last["lookahead"] == 1 and last["nodirty"] == 1 and last["prune"] in (2, 3)
+    assert last["lookahead"] == 0 and last["nodirty"] == 1 and last["prune"] in (2, 3)
+    assert all(d["lookahead"] == 0 for _, d in c2[4] if d["prune"] != 0)
     assert any(d["prune"] == 3 for _, d in c2[4]) and any(d["prune"] == 2 for _, d in c2[4])
     assert any(d["prune"] == 0 for _, d in c2[4])  # start-up: most rows evaluated in full - the plain scan takes over
     assert any(o["stat_missed"] > 0 for o, _ in c2[4]) and all(o["tg_ok"] in (0, 1) for o, _ in c2[4])
