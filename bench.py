@@ -142,7 +142,7 @@ def compact_line(full, detail_file=None):
     cfg = full.get("config") or {}
     line["config"] = {k: cfg.get(k) for k in ("workload", "points", "dim", "microclusters", "clusters", "streams") if k in cfg}
     line["config"]["workload"] = str(cfg.get("workload", ""))[:160]
-    for k in ("online_only_points_per_s", "value_with_transfers"):
+    for k in ("online_only_points_per_s", "value_with_transfers", "filter_on_points_per_s"):
         if full.get(k) is not None:
             line[k] = full[k]
     rf = full.get("roofline")
@@ -458,6 +458,31 @@ def with_transfers(h, X, steps, step):
             "waiting_for_upload_ms_per_step": 1e3 * wait_s / steps, "labels_download_ms_per_step": 1e3 * lab_s / steps,
             "note": "host array in (pageable, 8 d bytes per point) through cc_points_prefetch one step ahead, labels out "
                     "(uid int64 + path int8 per point); everything else as the headline step"}
+
+
+def general_regimes(h, cfg, n, d, step, steps):
+    """The headline step (reset + online + offline phases, inputs resident) with the parameters moved out of the common case:
+    pi = d - 2 (the tentative-add pdim filter decides which pcore microclusters a point may join) and k = 3 (every distance
+    term an IEEE division).  The handle's parameters are put back afterwards."""
+    out = {}
+    for name, over in (("filter_pi_d_minus_2", {"pi": d - 2}), ("k_3", {"k": 3.0}), ("filter_and_k_3", {"pi": d - 2, "k": 3.0})):
+        c = dict(cfg, **over)
+        set_params(h, c, n, d)
+        step()
+        h.sync()
+        t0 = time.perf_counter()
+        acc = {"scan_p_launches": 0, "scan_launches": 0, "truncated": 0, "windows": 0}
+        for _ in range(steps):
+            s, n_clusters = step()
+            for k in acc:
+                acc[k] += s[k]
+        h.sync()
+        el = time.perf_counter() - t0
+        out[name] = {"value": n * steps / el, "unit": "points/s", "ms_per_step": 1e3 * el / steps, "steps": steps, "parameters": over,
+                     "clusters": n_clusters, "windows_per_step": acc["windows"] / steps, "truncated_windows_per_step": acc["truncated"] / steps,
+                     "snapshot_scans_per_step": acc["scan_launches"] / steps, "pruned_scans_per_step": acc["scan_p_launches"] / steps}
+    set_params(h, cfg, n, d)
+    return out
 
 
 def digest_of(h):
@@ -860,6 +885,7 @@ def main():
     ap.add_argument("--early-window", type=int, default=0, help="window while the table grows / is being promoted (0: 4096)")
     ap.add_argument("--windows-per-sync", type=int, default=0, help="windows enqueued between host read-backs (0: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-general-regimes", action="store_true", help="skip the step with the pdim filter on / k not a power of two")
     ap.add_argument("--no-transfers", action="store_true", help="skip the transfer-inclusive measurement (upload + labels inside the timed region)")
     ap.add_argument("--cpu-sample", type=int, default=100_000)
     ap.add_argument("--cpu-cores", type=int, default=16, help="threads of the all-cores CPU column (at most the usable cores)")
@@ -1031,6 +1057,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, X, args.cpu_sample, max(1, min(usable, args.cpu_cores)), uid,
                                                gpu_tables=(h.export(_L.PCORE), h.export(_L.OUTLIER)))
             out["cpu_baseline"]["host_cpu_count"] = os.cpu_count()
+        if world == 1 and not args.no_transfers and not args.no_general_regimes and not args.only_leg:
+            # the same step outside the friendliest regime (pi = d, k = 4): the pdim filter of hddstream.py:317-321 on, k not a
+            # power of two - pruned scans there since round 6 (k_scan_p3<GENERAL> behind seeded thresholds)
+            out["general_regimes"] = general_regimes(h, cfg, n, d, step, max(2, min(args.steps, 6)))
+            out["filter_on_points_per_s"] = out["general_regimes"]["filter_pi_d_minus_2"]["value"]
     h.close()
     del X
     if rank == 0:

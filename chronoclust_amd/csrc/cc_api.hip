@@ -180,6 +180,7 @@ struct cc_handle {
     DevBuf<Cand> probe_part;  // ... into these scratch partials
     bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
     bool allow_lean = true;   // CHRONOCLUST_HIP_LEAN=0: guessed scans always list and rescan the points they missed
+    bool allow_prune_general = true;  // CHRONOCLUST_HIP_PRUNE_GENERAL=0: no pruned scans where the pdim filter is on or k is not a power of two
     bool la_pruned = false;   // CHRONOCLUST_HIP_LA_PRUNED=1: lookahead scans also while the scans are pruned chains on one GPU
     bool allow_probe = true;  // CHRONOCLUST_HIP_PROBE=0: pruned scans are retried blindly after a stretch of points
     DevBuf<unsigned long long> found;  // [2][CC_MAX_WINDOW / 64] per point tile: the points a guessed-threshold scan found a pcore MC for
@@ -609,6 +610,26 @@ Versions versions_view(cc_handle* h)
 // does the snapshot scan of this handle's stream run as k_scan_u? (decided per launch by the same test)
 bool scan_u_applies(const cc_handle* h, int DP) { return h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 && h->d == DP; }
 
+// the table rows as half-precision operands of the MFMA prefix test (k_prefix16): two window parities, whole tiles of 32 rows
+// (grown between batches only: a scan in flight on the other stream may be reading it)
+void ensure_prefix16(cc_handle* h)
+{
+    const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
+    if (h->a16_stride >= a16_rows * 4) return;
+    sync_stream(h, h->stream);
+    sync_stream(h, h->stream2);
+    h->a16.ensure(2 * a16_rows * 4);
+    h->a16_stride = a16_rows * 4;
+    h->hdr16.ensure(2);
+}
+
+// does a PRUNED snapshot scan of this handle run as k_scan_p3<GENERAL> - the pdim filter on and / or k not a power of two?
+// (the plain scans of these cases stay with k_scan<FILTER, POW2>)
+bool scan_p3_general_applies(const cc_handle* h, int DP)
+{
+    return h->allow_scan_p3 && h->allow_prune_general && h->d == DP && DP > 8 && DP <= 40 && (h->hc.filter != 0 || !h->hc.pow2);
+}
+
 template <int DP, bool DIRTY>
 void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand* clean, Cand* part, int S, int round,
                     int mode, int shard_rank, int shard_world, int phase)
@@ -640,28 +661,23 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                             // one kernel, phase A on the matrix cores (cc_scan16.h): the rows as half-precision operands first
                             // (at any table size: CHRONOCLUST_HIP_SCANA=2 keeps the two-kernel form of large tables)
                             if (h->allow_scan_p3) {
+                                ensure_prefix16(h);
                                 const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
-                                if (h->a16_stride < a16_rows * 4) {
-                                    // (grown between batches only: a scan in flight on the other stream may be reading it)
-                                    sync_stream(h, h->stream);
-                                    sync_stream(h, h->stream2);
-                                    h->a16.ensure(2 * a16_rows * 4);
-                                    h->a16_stride = a16_rows * 4;
-                                    h->hdr16.ensure(2);
-                                }
                                 hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
                                                    rows.cen, rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
                                 // (unused dynamic LDS caps the workgroups a CU holds: CHRONOCLUST_HIP_SCAN_LDS_KB, an experiment knob)
                                 static const unsigned p3_lds = []() { const char* e = getenv("CHRONOCLUST_HIP_SCAN_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
                                 // (kept rows listed per wave and walked with their operands prefetched - LISTED - from p3_listed_rows table rows on)
                                 if (h->hc.m_rows >= h->p3_listed_rows)
-                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, true>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, true, false>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                                        rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
-                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride,
+                                                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
                                 else
-                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, false>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
+                                    hipLaunchKernelGGL((k_scan_p3<DP, NW, false, false>), dim3((win + 127) / 128, S), block, p3_lds, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl,
                                                        rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, srank, sworld,
-                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                                                       h->pstat_p(), gF, found_, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride,
+                                                       (const double*)nullptr, (const double*)nullptr, (const double*)nullptr, (const double*)nullptr);
                                 ++h->stats.scan_p2_launches;
                                 return;
                             }
@@ -792,6 +808,35 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
             }
             hipLaunchKernelGGL((k_scan_u<DP, NW>), grid, block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.scl, rows.kind,
                                rows.key, part, round, mode, h->part_stride, shard_rank, shard_world);
+            return;
+        }
+    }
+    if constexpr (!DIRTY && DP > 8 && DP <= 40) {
+        // the pruned chain where the pdim filter is on or k is not a power of two (round 6): seeds and thresholds as ever (any
+        // threshold is a valid one), then k_scan_p3<GENERAL>.  Seeded thresholds only: the points a guessed threshold misses
+        // would need a plain scan over a point list, which exists for the common case alone (k_scan_u).
+        if (h->prune_now && scan_p3_general_applies(h, DP) && phase == 0) {
+            ++h->stats.scan_p_launches;
+            ++h->stats.scan_p2_launches;
+            hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
+                               h->spart.p, round, mode, h->spart_stride, h->cmax.p, (const int*)nullptr);
+            hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen, rows.scl,
+                               h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride, h->prune_F, round, mode, h->cmax.p,
+                               h->pstat_p(), (const int*)nullptr);
+            ensure_prefix16(h);
+            const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
+            hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p, rows.cen,
+                               rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
+            if (h->hc.m_rows >= h->p3_listed_rows)
+                hipLaunchKernelGGL((k_scan_p3<DP, NW, true, true>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                   rows.scl, rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, shard_rank,
+                                   shard_world, h->pstat_p(), 0.0, (unsigned long long*)nullptr, (const cc_h8*)h->a16.p,
+                                   (const Prefix16Hdr*)h->hdr16.p, h->a16_stride, (const double*)h->X.p, rows.cf1, rows.cf2, rows.w);
+            else
+                hipLaunchKernelGGL((k_scan_p3<DP, NW, false, true>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                   rows.scl, rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, shard_rank,
+                                   shard_world, h->pstat_p(), 0.0, (unsigned long long*)nullptr, (const cc_h8*)h->a16.p,
+                                   (const Prefix16Hdr*)h->hdr16.p, h->a16_stride, (const double*)h->X.p, rows.cf1, rows.cf2, rows.w);
             return;
         }
     }
@@ -1034,6 +1079,8 @@ int cc_create(int device, cc_handle** out)
         h->allow_lean = !(ln && ln[0] == '0');
         const char* mpl = getenv("CHRONOCLUST_HIP_MISSED_PLAIN");
         if (mpl && atoi(mpl) == 0) h->allow_missed_plain = false;
+        const char* pg = getenv("CHRONOCLUST_HIP_PRUNE_GENERAL");
+        if (pg && atoi(pg) == 0) h->allow_prune_general = false;
         const char* lap = getenv("CHRONOCLUST_HIP_LA_PRUNED");
         if (lap && atoi(lap) != 0) h->la_pruned = true;
         const char* p3l = getenv("CHRONOCLUST_HIP_P3_LISTED");
@@ -1703,14 +1750,16 @@ struct OnlineRun {
         pcfg.lookahead = h->tun.lookahead;
         pcfg.allow_nodirty = h->allow_nodirty ? 1 : 0;
         pcfg.prune_mode = h->prune_mode;
-        pcfg.prune_applicable = (h->d > 8 && h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 != 0 &&
-                                 (h->d == 14 || h->d == 16 || h->d == 20 || h->d == 32 || h->d == 40 || h->d == 64)) ? 1 : 0;
+        const bool width_ok = h->d == 14 || h->d == 16 || h->d == 20 || h->d == 32 || h->d == 40;
+        // (the pdim filter on and / or k not a power of two: k_scan_p3<GENERAL> behind seeded thresholds - no guesses, no probes)
+        const bool prune_general = width_ok && scan_p3_general_applies(h, h->d);
+        pcfg.prune_applicable = ((h->d > 8 && h->allow_scan_u && h->hc.filter == 0 && h->hc.pow2 != 0 && (width_ok || h->d == 64)) || prune_general) ? 1 : 0;
         pcfg.can_shard = (grouped && !h->shard_suspended) ? 1 : 0;
         pcfg.d = h->d;
         pcfg.resume = resume ? 1 : 0;
         pcfg.allow_sparse = h->allow_sparse;
-        pcfg.allow_guess = h->allow_guess ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
-        pcfg.allow_probe = h->allow_probe ? 1 : 0;
+        pcfg.allow_guess = (h->allow_guess && !prune_general) ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
+        pcfg.allow_probe = (h->allow_probe && !prune_general) ? 1 : 0;
         pcfg.lookahead_pruned = h->la_pruned ? 1 : 0;
         pcfg.pad = 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;

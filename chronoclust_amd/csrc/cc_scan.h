@@ -1184,6 +1184,7 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
         if (t < 2) pstat[win.q * 2 + t] = 0ull;
     }
     constexpr int d = DP;  // (the pruned scan runs for d == DP only: every loop below unrolls, its loads go out together)
+    const bool pow2 = ctl->pow2 != 0;
     spart += (size_t)win.q * spart_stride;
     thr += (size_t)win.q * thr_stride;
     thr32 += (size_t)win.q * thr_stride;
@@ -1217,7 +1218,9 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
                 if (i0 + u < d) {
                     double x0 = pv[u] - c0[u], x1 = pv[u] - c1[u], x2 = pv[u] - c2[u];
                     x0 = x0 * x0; x1 = x1 * x1; x2 = x2 * x2;
-                    x0 = x0 * s0[u]; x1 = x1 * s1[u]; x2 = x2 * s2[u];
+                    // (k not a power of two - round 6, k_scan_p3<GENERAL> -: the operand column holds the preference entries)
+                    if (pow2) { x0 = x0 * s0[u]; x1 = x1 * s1[u]; x2 = x2 * s2[u]; }
+                    else { x0 = x0 / s0[u]; x1 = x1 / s1[u]; x2 = x2 / s2[u]; }
                     a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2;
                 }
             }

@@ -195,15 +195,26 @@ __global__ __launch_bounds__(256) void k_prefix16(const Ctl* __restrict__ ctl, c
 #ifndef CC_SCANP3_WGS
 #define CC_SCANP3_WGS 4  // workgroups per CU the kernel is compiled for
 #endif
-template <int DP, int NW, bool LISTED>
+// GENERAL (round 6): the cases the plain scan served with k_scan<FILTER, POW2> - the pdim filter of hddstream.py:317-321 on
+// (pi < d) and / or k not a power of two.  Phase A does not depend on either (its bound takes min(1, 1/k) for every operand);
+// phase B divides by the preference entry where k is not a power of two (the table's operand column then holds the entries
+// themselves), and a pcore row enters a point's list only if the microcluster with the point added keeps pdim <= pi - evaluated
+// lazily, for the rows that would enter (cc_tentative_radius: the row's CF1, CF2, W, the point's coordinates from the row-major
+// copy).  A row the filter rejects for a point may still be abandoned for it by phase A and leave its bound: sound (a bound
+// claims only that nothing closer was overlooked).
+template <int DP, int NW, bool LISTED, bool GENERAL>
 __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
     Ctl* __restrict__ ctl, const double* __restrict__ Xt, const double* __restrict__ g_cen, const double* __restrict__ g_scl,
     const int* __restrict__ g_kind, const int* __restrict__ g_key, const double* __restrict__ thr, size_t thr_stride,
     Cand* __restrict__ part, int round, int mode, size_t part_stride, int shard_rank, int shard_world,
     unsigned long long* __restrict__ pstat, double guess_F, unsigned long long* __restrict__ found,
-    const cc_h8* __restrict__ a16, const Prefix16Hdr* __restrict__ hdr, size_t a16_stride)
+    const cc_h8* __restrict__ a16, const Prefix16Hdr* __restrict__ hdr, size_t a16_stride,
+    const double* __restrict__ X, const double* __restrict__ g_cf1, const double* __restrict__ g_cf2, const double* __restrict__ g_w)
 {
     static_assert(DP % 2 == 0 && DP > 8 && DP <= 64, "k_scan_p3 shapes");
+    const Par par = cc_load_par(ctl);
+    const bool gen_pow2 = !GENERAL || par.pow2 != 0;
+    const bool gen_filter = GENERAL && par.filter != 0;
     const ScanWin win = cc_scan_window(ctl, round, mode);
     const int B = win.B;
     if (B == 0) return;
@@ -258,7 +269,9 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
         s_T[e] = (j0 + x < B) ? T : -CC_INF;
     }
     const double sc = hdr->sc;
-    const double inv_k = ctl->inv_k;
+    // (the control block carries 1 / k only where the kernels multiply by it; cc_tau16 needs min(1, 1 / k) - its 2^-40 covers
+    // the rounding of the quotient)
+    const double inv_k = gen_pow2 ? ctl->inv_k : 1.0 / par.k;
     __syncthreads();  // the points and thresholds are staged
     // the points' prefixes in half precision (four values per thread), then per (point, kind) the constant of the test
     static_assert(NW == 4, "the prologue's work split assumes 256 threads");
@@ -368,7 +381,8 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
                 for (int i = 0; i < qhi - qlo; ++i) {
                     double x = pv[i] - c[i];               // mc_functions.py:37
                     x = x * x;                             // :38
-                    x = x * scl[i];                        // :39 (the divisor is a power of two)
+                    if constexpr (GENERAL) x = gen_pow2 ? x * scl[i] : x / scl[i];  // :39
+                    else x = x * scl[i];                   // :39 (the divisor is a power of two)
                     acc = (qlo + i == 0) ? x : acc + x;    // :41
                 }
             });
@@ -404,8 +418,21 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
                     if (a == d0) first = key < (s0 >= 0 ? g_key[s0] : CC_IDX_INF);
                 }
             }
-            d1 = cc_vmin(d1, cc_vmax(d0, a));
-            d0 = cc_vmin(d0, a);
+            if (GENERAL && K == 0 && gen_filter) {
+                if (ins) {
+                    // hddstream.py:317-321: pdim of the MC *with the point added* must be <= pi
+                    int ne1 = 0;
+                    cc_tentative_radius(g_cf1 + (size_t)rowg * DP, g_cf2 + (size_t)rowg * DP, g_w[rowg],
+                                        X + (size_t)(win.cursor + j0 + u * 64 + lane) * DP, DP, par, nullptr, &ne1);
+                    if (ne1 > par.pi) ins = false;
+                }
+                first = first && ins;
+                d1 = first ? d0 : (ins ? a : d1);
+                d0 = first ? a : d0;
+            } else {
+                d1 = cc_vmin(d1, cc_vmax(d0, a));
+                d0 = cc_vmin(d0, a);
+            }
             s1 = first ? s0 : (ins ? rowg : s1);
             s0 = first ? rowg : s0;
         };

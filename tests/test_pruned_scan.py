@@ -203,6 +203,43 @@ def _fuzz_case(seed):
     return cfg, window, lookahead, F, Xs
 
 
+def _general_case(seed):
+    """The same random streams OUTSIDE the common case (round 6, k_scan_p3<GENERAL>): k not a power of two and / or the pdim
+    filter of hddstream.py:317-321 on (pi < d), at the widths that kernel is compiled for."""
+    cfg, window, lookahead, F, Xs = _fuzz_case(seed)
+    rng = np.random.default_rng(9100 + seed)
+    d = Xs[0].shape[1]
+    if d == 64:
+        d = int(rng.choice([14, 20, 40]))
+        Xs = [np.ascontiguousarray(X[:, :d]) for X in Xs]
+    which = seed % 3  # 0: any k, 1: the filter, 2: both
+    if which != 1:
+        cfg["k"] = float(rng.choice([3.0, 1.5, 10.0, 0.3, 7.25]))
+    if which != 0:
+        cfg["pi"] = int(rng.choice([1, 3, d // 2, d - 1]))
+    return cfg, window, lookahead, F, Xs
+
+
+@pytest.mark.parametrize("seed", range(72))
+def test_forced_pruning_fuzz_with_the_pdim_filter_and_any_k(seed):
+    from oracle import oracle as O
+    cfg, window, lookahead, F, Xs = _general_case(seed)
+    h = _hdd(cfg, 2, F=F, window=window, lookahead=lookahead)
+    o = O.OracleHDDStream(cfg)
+    pruned = plain_u = windows = 0
+    for t, X in enumerate(Xs):
+        h.online_microcluster_maintenance(X, t)
+        o.online_microcluster_maintenance(X, t)
+        _against_oracle(h, o)
+        s = h.stats()
+        pruned, plain_u, windows = pruned + s["scan_p_launches"], plain_u + s["scan_u_launches"], windows + s["windows"]
+    # the pruned chain ran wherever windows were scanned at all (small tables go to the sequential kernels), and none of the
+    # common case's kernels did
+    assert plain_u == 0 and (pruned > 0 or windows == 0), (pruned, plain_u, windows)
+    if seed == 0:
+        assert pruned > 0
+
+
 @pytest.mark.parametrize("seed", range(96))
 def test_forced_pruning_fuzz(seed):
     from oracle import oracle as O
