@@ -47,7 +47,7 @@ class CcStats(C.Structure):
                 ("scan_p2_launches", C.c_int64),
                 ("calib_allgather_us", C.c_double), ("calib_scan_ns_per_row_dim", C.c_double),
                 ("split_threshold_row_dims", C.c_int64), ("split_threshold_row_dims_pruned", C.c_int64),
-                ("missed_plain_launches", C.c_int64)]
+                ("missed_plain_launches", C.c_int64), ("seed16_launches", C.c_int64)]
 
 
 POLICY_MAX_ROUNDS = 8
@@ -58,7 +58,7 @@ class CcPolicyConfig(C.Structure):
                                          "allow_nodirty", "prune_mode", "prune_applicable", "can_shard", "d", "resume",
                                          "allow_sparse", "allow_guess", "allow_probe")] + \
                [("shard_min_row_dims", C.c_int64), ("n_end", C.c_int64), ("shard_min_row_dims_pruned", C.c_int64),
-                ("lookahead_pruned", C.c_int32), ("pad", C.c_int32)]
+                ("lookahead_pruned", C.c_int32), ("force_prune_rows", C.c_int32)]
 
 
 class CcPolicyCarry(C.Structure):

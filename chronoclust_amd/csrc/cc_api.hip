@@ -180,6 +180,8 @@ struct cc_handle {
     DevBuf<Cand> probe_part;  // ... into these scratch partials
     bool allow_guess = true;  // CHRONOCLUST_HIP_GUESS=0: seeded thresholds only
     bool allow_lean = true;   // CHRONOCLUST_HIP_LEAN=0: guessed scans always list and rescan the points they missed
+    int force_prune_rows = 0;  // CHRONOCLUST_HIP_FORCE_PRUNE_ROWS: pruned scans whatever the phase from this many table rows on (0, the default: never forced - measured: it pays nowhere yet)
+    bool allow_seed16 = false;  // CHRONOCLUST_HIP_SEED16=1: the seeds of a seeded pruned chain from the matrix cores (k_seed16) with the tight threshold, not from k_seed (eight-dimension prefix scores, F x the nearest) - measured a wash at C2's shapes, DESIGN section 9
     bool allow_prune_general = true;  // CHRONOCLUST_HIP_PRUNE_GENERAL=0: no pruned scans where the pdim filter is on or k is not a power of two
     bool la_pruned = false;   // CHRONOCLUST_HIP_LA_PRUNED=1: lookahead scans also while the scans are pruned chains on one GPU
     bool allow_probe = true;  // CHRONOCLUST_HIP_PROBE=0: pruned scans are retried blindly after a stretch of points
@@ -354,9 +356,9 @@ struct PolicyTrace {
         if (!f) return;
         fprintf(f, "{\"call\": {\"config\": {\"window\": %d, \"rounds_max\": %d, \"windows_per_sync\": %d, \"early_window\": %d, "
                    "\"lookahead\": %d, \"allow_nodirty\": %d, \"prune_mode\": %d, \"prune_applicable\": %d, \"can_shard\": %d, \"d\": %d, "
-                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld, \"shard_min_row_dims_pruned\": %lld, \"lookahead_pruned\": %d}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
+                   "\"resume\": %d, \"allow_sparse\": %d, \"allow_guess\": %d, \"allow_probe\": %d, \"shard_min_row_dims\": %lld, \"n_end\": %lld, \"shard_min_row_dims_pruned\": %lld, \"lookahead_pruned\": %d, \"force_prune_rows\": %d}, \"carry\": [%d, %d, %d], \"start\": [%lld, %d], \"dec\": ",
                 c.window, c.rounds_max, c.windows_per_sync, c.early_window, c.lookahead, c.allow_nodirty, c.prune_mode,
-                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end, (long long)c.shard_min_row_dims_pruned, c.lookahead_pruned,
+                c.prune_applicable, c.can_shard, c.d, c.resume, c.allow_sparse, c.allow_guess, c.allow_probe, (long long)c.shard_min_row_dims, (long long)c.n_end, (long long)c.shard_min_row_dims_pruned, c.lookahead_pruned, c.force_prune_rows,
                 k.adapt_win, k.clean_batches, k.since_shrink, cursor, rows);
         dec_json(f, d0);
         fprintf(f, "}}\n");
@@ -654,7 +656,7 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                 // window's points (plist == nullptr) or for the ones a guessed threshold missed
                 // k_scan_p for the window's points: phase A as a kernel of its own (two points per lane, survivor masks), phase
                 // B behind it; lists of points (the ones a guessed threshold missed, probes) keep the one-kernel form
-                auto scan_p_window = [&](int srank, int sworld, double gF, unsigned long long* found_) {
+                auto scan_p_window = [&](int srank, int sworld, double gF, unsigned long long* found_, bool have_prefix16 = false) {
                     const bool one_kernel = h->split_a_mode == 0 || (h->split_a_mode == 1 && h->hc.m_rows < 10000);
                     if (one_kernel || (h->allow_scan_p3 && h->split_a_mode == 1 && DP <= 40)) {
                         if constexpr (DP <= 40) {
@@ -663,8 +665,9 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                             if (h->allow_scan_p3) {
                                 ensure_prefix16(h);
                                 const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
-                                hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
-                                                   rows.cen, rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
+                                if (!have_prefix16)
+                                    hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
+                                                       rows.cen, rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
                                 // (unused dynamic LDS caps the workgroups a CU holds: CHRONOCLUST_HIP_SCAN_LDS_KB, an experiment knob)
                                 static const unsigned p3_lds = []() { const char* e = getenv("CHRONOCLUST_HIP_SCAN_LDS_KB"); return e ? (unsigned)atoi(e) * 1024u : 0u; }();
                                 // (kept rows listed per wave and walked with their operands prefetched - LISTED - from p3_listed_rows table rows on)
@@ -725,16 +728,34 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
                                        h->mask_stride, tps, q);
                 };
                 auto seeded_chain = [&](int n_pts, const int* plist, Cand* part, size_t part_stride, int S) {
-                        // (k_seed holds two points per lane: point tiles of 128)
-                        hipLaunchKernelGGL((k_seed<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
-                                           rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p, plist);
+                        const bool whole_window = plist == nullptr && n_pts == win && part_stride == h->part_stride && S == (int)grid.y;
+                        // seeds from the matrix cores and the tight threshold they allow (k_seed16; round 6) where the window's scan is
+                        // k_scan_p3: the rows' half-precision records first, they serve both kernels
+                        bool s16 = false;
+                        if constexpr (DP <= 40) s16 = whole_window && h->allow_seed16 && h->allow_scan_p3 && h->split_a_mode != 2;
+                        if (s16) {
+                            if constexpr (DP <= 40) {
+                                ensure_prefix16(h);
+                                const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
+                                hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p,
+                                                   rows.cen, rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
+                                hipLaunchKernelGGL((k_seed16<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, (const Ctl*)h->ctl.p, (const double*)h->Xt.p,
+                                                   rows.cen, h->spart.p, round, mode, h->spart_stride, (const cc_h8*)h->a16.p,
+                                                   (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                                ++h->stats.seed16_launches;
+                            }
+                        } else {
+                            // (k_seed holds two points per lane: point tiles of 128)
+                            hipLaunchKernelGGL((k_seed<DP, NW>), dim3((n_pts + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
+                                               rows.kind, h->spart.p, round, mode, h->spart_stride, h->cmax.p, plist);
+                        }
                         hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * n_pts + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen,
                                            rows.scl, h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride,
-                                           h->prune_F, round, mode, h->cmax.p, h->pstat_p(), plist);
+                                           s16 ? 0.0 : h->prune_F, round, mode, h->cmax.p, h->pstat_p(), plist);
                         // (split over the ranks of a group: seeds and thresholds over ALL rows on every rank - replicated, so
                         // that every rank abandons against the same T -, phases A / B over the rank's own rows)
-                        if (plist == nullptr && n_pts == win && part_stride == h->part_stride && S == (int)grid.y) {
-                            scan_p_window(shard_rank, shard_world, 0.0, (unsigned long long*)nullptr);
+                        if (whole_window) {
+                            scan_p_window(shard_rank, shard_world, 0.0, (unsigned long long*)nullptr, s16);
                             return;
                         }
                         hipLaunchKernelGGL((k_scan_p<DP, NW, false>), dim3((n_pts + 63) / 64, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
@@ -818,15 +839,20 @@ void launch_scan_dp(cc_handle* h, hipStream_t st, int win, Rows rows, const Cand
         if (h->prune_now && scan_p3_general_applies(h, DP) && phase == 0) {
             ++h->stats.scan_p_launches;
             ++h->stats.scan_p2_launches;
-            hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
-                               h->spart.p, round, mode, h->spart_stride, h->cmax.p, (const int*)nullptr);
-            hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen, rows.scl,
-                               h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride, h->prune_F, round, mode, h->cmax.p,
-                               h->pstat_p(), (const int*)nullptr);
             ensure_prefix16(h);
             const size_t a16_rows = h->tab.cap + 2 * CC_P16_TM;
             hipLaunchKernelGGL((k_prefix16<DP>), dim3((unsigned)((a16_rows + 255) / 256)), dim3(256), 0, st, (const Ctl*)h->ctl.p, rows.cen,
                                rows.kind, h->a16.p, h->hdr16.p, h->a16_stride, round, mode);
+            if (h->allow_seed16) {
+                hipLaunchKernelGGL((k_seed16<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, (const Ctl*)h->ctl.p, (const double*)h->Xt.p, rows.cen,
+                                   h->spart.p, round, mode, h->spart_stride, (const cc_h8*)h->a16.p, (const Prefix16Hdr*)h->hdr16.p, h->a16_stride);
+                ++h->stats.seed16_launches;
+            } else
+                hipLaunchKernelGGL((k_seed<DP, NW>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen, rows.kind,
+                                   h->spart.p, round, mode, h->spart_stride, h->cmax.p, (const int*)nullptr);
+            hipLaunchKernelGGL((k_seed_merge<DP>), dim3((2 * win + 63) / 64), dim3(64), 0, st, h->ctl.p, h->X.p, rows.cen, rows.scl,
+                               h->spart.p, h->spart_stride, S, h->thr.p, h->thr32.p, h->thr_stride, h->allow_seed16 ? 0.0 : h->prune_F, round,
+                               mode, h->cmax.p, h->pstat_p(), (const int*)nullptr);
             if (h->hc.m_rows >= h->p3_listed_rows)
                 hipLaunchKernelGGL((k_scan_p3<DP, NW, true, true>), dim3((win + 127) / 128, S), block, 0, st, h->ctl.p, h->Xt.p, rows.cen,
                                    rows.scl, rows.kind, rows.key, h->thr.p, h->thr_stride, part, round, mode, h->part_stride, shard_rank,
@@ -1079,6 +1105,10 @@ int cc_create(int device, cc_handle** out)
         h->allow_lean = !(ln && ln[0] == '0');
         const char* mpl = getenv("CHRONOCLUST_HIP_MISSED_PLAIN");
         if (mpl && atoi(mpl) == 0) h->allow_missed_plain = false;
+        const char* fpr = getenv("CHRONOCLUST_HIP_FORCE_PRUNE_ROWS");
+        if (fpr) h->force_prune_rows = atoi(fpr);
+        const char* s16 = getenv("CHRONOCLUST_HIP_SEED16");
+        if (s16) h->allow_seed16 = atoi(s16) != 0;
         const char* pg = getenv("CHRONOCLUST_HIP_PRUNE_GENERAL");
         if (pg && atoi(pg) == 0) h->allow_prune_general = false;
         const char* lap = getenv("CHRONOCLUST_HIP_LA_PRUNED");
@@ -1761,7 +1791,8 @@ struct OnlineRun {
         pcfg.allow_guess = (h->allow_guess && !prune_general) ? (h->allow_lean ? 1 : 2) : 0;  // (2: guessed thresholds, never lean)
         pcfg.allow_probe = (h->allow_probe && !prune_general) ? 1 : 0;
         pcfg.lookahead_pruned = h->la_pruned ? 1 : 0;
-        pcfg.pad = 0;
+        // (pruned scans from this many rows on whatever the phase: where the seeded chain runs behind k_seed16)
+        pcfg.force_prune_rows = (pcfg.prune_applicable && h->allow_seed16 && h->allow_scan_p3 && h->d <= 40 && h->split_a_mode != 2) ? h->force_prune_rows : 0;
         pcfg.shard_min_row_dims = h->shard_min_row_dims;
         pcfg.shard_min_row_dims_pruned = h->shard_min_row_dims_pruned;
         pcfg.n_end = N;

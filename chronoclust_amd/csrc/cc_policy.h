@@ -222,7 +222,7 @@ public:
         if (!prune_on_ && pr > 0) probe_ok_ = pfu * 12 <= pr;
         const bool probing = c_.prune_applicable != 0 && c_.prune_mode == 1 && !prune_on_ && prev_probe_;
         const bool blind = c_.allow_probe == 0 && o.cursor >= prune_resume_at_;  // (the round-3 rule: try again after a stretch)
-        const bool prune_next = c_.prune_applicable != 0 && c_.prune_mode != 0 &&
+        const bool prune_next0 = c_.prune_applicable != 0 && c_.prune_mode != 0 &&
                                 ((c_.prune_mode == 2 && prune_resume_at_ != std::numeric_limits<long long>::max()) ||
                                  // on: stays on until a batch completes too many rows (prune_resume_at_ moves ahead of the
                                  // cursor); off: comes back on a probe's word - no blind tries on whole batches
@@ -230,6 +230,13 @@ public:
                                  // a settled stream (no tile needed its dirty scan: nothing created, promoted or moved far)
                                  // is where pruned scans pay: tried at once, whatever the earlier tries said
                                  (nodirty_ && prune_resume_at_ != std::numeric_limits<long long>::max()));
+        // (round 6) a table of force_prune_rows rows or more: pruned scans whatever the samples said - behind seeds from the matrix
+        // cores and the tight threshold (k_seed16, k_seed_merge with F <= 0) the chain returns exactly what the plain scan returns
+        // and costs a fraction of it at that size, in the start-up windows too; below that size the chain's five launches cost
+        // what the plain scan costs (75 us per 4 096-point window at C2's 5 000 rows) and the rules above decide as before
+        const bool forced = c_.prune_applicable != 0 && c_.prune_mode == 1 && c_.force_prune_rows > 0 && o.m_rows >= c_.force_prune_rows &&
+                            prune_resume_at_ != std::numeric_limits<long long>::max();
+        const bool prune_next = prune_next0 || forced;
         const bool prune_flip = prune_next != prune_on_;
         prune_on_ = prune_next;
         // (a pending lookahead scan was made for the old split of the table rows / the old kind of scan: restart on a change)

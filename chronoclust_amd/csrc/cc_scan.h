@@ -1229,6 +1229,17 @@ __global__ __launch_bounds__(64) void k_seed_merge(const Ctl* __restrict__ ctl, 
         dmin = a1 < dmin ? a1 : dmin;
         dmin = a2 < dmin ? a2 : dmin;
         out = F * dmin;
+        if (F <= 0.0) {
+            // TIGHT (round 6, behind k_seed16's seeds): the SECOND smallest of the exact distances - at least two rows of the kind
+            // lie within it, so the scan that abandons what lies beyond returns the exact two best, which is all a plain scan
+            // returns.  One seed only (one sub-range, or one row of the kind): its distance; the second place is then a bound.
+            const double lo = a0 < a1 ? a0 : a1, hi = a0 < a1 ? a1 : a0;
+            const double mid = a2 < hi ? a2 : hi;  // min(hi, a2)
+            out = !h1 ? a0 : (!h2 ? hi : (lo < mid ? mid : lo));
+            // (strictly above it: the bound the scan leaves for what it abandoned - T - must not tie with the exact second
+            // candidate, a bound sorts first on a tie)
+            out = out * (1.0 + 0x1p-20) + 0x1p-1000;
+        }
     }
     thr[(size_t)j * 2 + K] = out;
     double pm = 0.0;

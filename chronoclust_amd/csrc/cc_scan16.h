@@ -618,3 +618,153 @@ __global__ __launch_bounds__(64 * NW, CC_SCANP3_WGS) void k_scan_p3(
         o[0] = cnd[u][0]; o[1] = cnd[u][1]; o[2] = cnd[u][2]; o[3] = cnd[u][3];
     }
 }
+
+// ---------------------------------------------------------------------------------
+// k_seed16 (round 6): the seeds of a pruned scan from the matrix cores - per window point and kind the table row with the
+// smallest APPROXIMATE squared distance over the prefix test's dimensions (all of them up to 24), in the format k_seed leaves
+// (one SeedCand per point, workgroup sub-range and kind; k_seed_merge evaluates the best three exactly).  k_seed scores eight
+// dimensions: enough to find a point's own microcluster, not to rank rows that are all far from it - the pcore list of a point
+// whose own microcluster is still an outlier microcluster, every list while the table fills.  With seeds that ARE the nearest
+// rows the threshold can be the exact distance of the second nearest (k_seed_merge, F <= 0): the pruned chain then returns the
+// exact two best per kind, which is all the plain scan returns, at a fraction of its arithmetic - in the start-up windows too.
+// Roles swapped against k_scan_p3: A = 32 table rows (k_prefix16's records as they are), B = 32 points, D[row][point]: a lane
+// holds ONE point's scores against 16 rows per MFMA and keeps a running maximum with its row; the slots that carry tau in the
+// scan carry + 128 for the rows of the wanted kind here (|p^.c^ - h^| <= 36: the others never win), one pass per kind on top of
+// the shared product over dimensions 8 .. 23.
+// ---------------------------------------------------------------------------------
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW, 4) void k_seed16(const Ctl* __restrict__ ctl, const double* __restrict__ Xt,
+                                                     const double* __restrict__ g_cen, SeedCand* __restrict__ spart, int round, int mode,
+                                                     size_t spart_stride, const cc_h8* __restrict__ a16,
+                                                     const Prefix16Hdr* __restrict__ hdr, size_t a16_stride)
+{
+    static_assert(NW == 4 && DP % 2 == 0 && DP > 8 && DP <= 64, "k_seed16 shapes");
+    constexpr int NP = Prefix16<DP>::NP;
+    const ScanWin win = cc_scan_window(ctl, round, mode);
+    const int B = win.B;
+    if (B == 0) return;
+    const int j0 = (int)blockIdx.x * 128;
+    if (j0 >= B) return;
+    spart += (size_t)win.q * spart_stride;
+    a16 += (size_t)win.q * a16_stride;
+    hdr += win.q;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int S = gridDim.y;
+    const int nsub = S * NW;
+    const int sub = blockIdx.y * NW + wv;
+    const int per = (((win.rows + nsub - 1) / nsub + CC_P16_TM - 1) / CC_P16_TM) * CC_P16_TM;
+    const int r0 = sub * per;
+    const int r1 = min(win.rows, r0 + per);
+    const size_t n_pts = (size_t)ctl->xt_stride;
+    const double sc = hdr->sc;
+    __shared__ __attribute__((aligned(16))) _Float16 s_p16[128 * 24];
+    {
+        const int x = (int)threadIdx.x & 127, i0 = 12 * ((int)threadIdx.x >> 7);
+        const bool pv = j0 + x < B;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            cc_h4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int dim = i0 + 4 * q + i;
+                double raw = 0.0;
+                if (dim < NP && pv) raw = (Xt[win.cursor + j0 + x + (size_t)dim * n_pts] - (dim < 8 ? hdr->org[dim < 8 ? dim : 0] : g_cen[dim < DP ? dim : 0])) * sc;
+                v[i] = (__builtin_fabs(raw) <= 1.0) ? cc_rn16(raw) : (_Float16)0.0f;  // (a heuristic: a point beyond the scale scores as the origin)
+            }
+            *reinterpret_cast<cc_h4*>(s_p16 + x * 24 + i0 + 4 * q) = v;
+        }
+    }
+    __syncthreads();
+    const int r = lane & 31, hh = lane >> 5;
+    cc_h8 bb[4], bx[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int x = 32 * b + r;
+        bx[b] = *reinterpret_cast<const cc_h8*>(s_p16 + x * 24 + 8 + 8 * hh);
+        if (hh == 0) bb[b] = *reinterpret_cast<const cc_h8*>(s_p16 + x * 24);
+        else bb[b] = cc_h8{(_Float16)1.0f, (_Float16)0x1p-10f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    }
+    float best[4][2];
+    int idx[4][2];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) { best[b][K] = 64.0f; idx[b][K] = -1; }  // (a row of the wanted kind scores above 128 - 36)
+    auto load_a = [&](int rt, int part) -> cc_h8 { return a16[(size_t)(rt + r) * 4 + part + hh]; };
+    cc_h8 an, axn;
+    if (r0 < r1 && sc > 0.0) { an = load_a(r0, 0); axn = load_a(r0, 2); }
+    for (int rt = r0; rt < r1 && sc > 0.0; rt += CC_P16_TM) {
+        const cc_h8 ac = an, axc = axn;
+        if (rt + CC_P16_TM < r1) { an = load_a(rt + CC_P16_TM, 0); axn = load_a(rt + CC_P16_TM, 2); }
+        const int tm = min(CC_P16_TM, r1 - rt);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            cc_f16acc z;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+            cc_f16acc xacc = z;
+            if constexpr (NP > 8) xacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(axc, bx[b], z, 0, 0, 0);
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                cc_h8 bk = bb[b];
+                // (slot 10 pairs with the row's is-pcore flag, slot 12 with its is-outlier flag)
+                if (hh == 1) bk[K == 0 ? 2 : 4] = (_Float16)128.0f;
+                const cc_f16acc d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ac, bk, xacc, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int m = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const bool gt = d[i] > best[b][K] && m < tm;  // strict: the first row in scan order keeps a tie (deterministic)
+                    best[b][K] = gt ? d[i] : best[b][K];
+                    idx[b][K] = gt ? rt + m : idx[b][K];
+                }
+            }
+        }
+    }
+    // the two lane halves hold disjoint rows of the same points: the better one (ties: the lower row, as a scan in row order would)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int K = 0; K < 2; ++K) {
+            const float ob = __shfl_xor(best[b][K], 32);
+            const int oi = __shfl_xor(idx[b][K], 32);
+            const bool take = oi >= 0 && (idx[b][K] < 0 || ob > best[b][K] || (ob == best[b][K] && oi < idx[b][K]));
+            best[b][K] = take ? ob : best[b][K];
+            idx[b][K] = take ? oi : idx[b][K];
+        }
+    // the waves' winners through LDS; wave 0 writes: lanes 0 .. 31 blocks 0, 1 (b = 0: point r, b = 1: point 32 + r), lanes 32 .. 63 blocks 2, 3
+    __shared__ float s_b[3 * 8 * 64];
+    __shared__ int s_i[3 * 8 * 64];
+    if (wv > 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int K = 0; K < 2; ++K) {
+                s_b[((wv - 1) * 8 + b * 2 + K) * 64 + lane] = best[b][K];
+                s_i[((wv - 1) * 8 + b * 2 + K) * 64 + lane] = idx[b][K];
+            }
+    }
+    __syncthreads();
+    if (wv != 0) return;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int K = 0; K < 2; ++K)
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) {
+                const float ob = s_b[(w * 8 + b * 2 + K) * 64 + lane];
+                const int oi = s_i[(w * 8 + b * 2 + K) * 64 + lane];
+                const bool take = oi >= 0 && (idx[b][K] < 0 || ob > best[b][K] || (ob == best[b][K] && oi < idx[b][K]));
+                best[b][K] = take ? ob : best[b][K];
+                idx[b][K] = take ? oi : idx[b][K];
+            }
+        // (both lane halves hold block b's 32 points: half 0 writes blocks 0 and 1, half 1 blocks 2 and 3)
+        if ((b >> 1) != hh) continue;
+        const int x = j0 + 32 * b + r;
+        if (x >= B) continue;
+        SeedCand* o = spart + ((size_t)x * S + blockIdx.y) * 2;
+        // (k_seed_merge ranks by `part`, smaller is nearer: the score's negative)
+        o[0] = SeedCand{idx[b][0] >= 0 ? 128.0f - best[b][0] : __builtin_inff(), idx[b][0]};
+        o[1] = SeedCand{idx[b][1] >= 0 ? 128.0f - best[b][1] : __builtin_inff(), idx[b][1]};
+    }
+}

@@ -148,6 +148,7 @@ typedef struct cc_stats {
     int64_t split_threshold_row_dims;
     int64_t split_threshold_row_dims_pruned;
     int64_t missed_plain_launches; /* plain scans (k_scan_u over a point list) for the points a guessed-threshold scan missed */
+    int64_t seed16_launches;       /* seeded pruned chains whose seeds came from the matrix cores (k_seed16) with the tight threshold */
 } cc_stats;
 
 /* HDDStream.__init__ (hddstream.py:30-67): one state object on GPU `device`. */
@@ -372,7 +373,9 @@ typedef struct cc_policy_config {
     int64_t shard_min_row_dims_pruned;  /* the split threshold while the scans are pruned chains (0: shard_min_row_dims)   */
     int32_t lookahead_pruned;  /* 1: lookahead scans also while the scans are pruned chains on one GPU (CHRONOCLUST_HIP_LA_PRUNED=1;
                                 * round 6: off - such a scan is too short to be worth a stream of its own, cc_policy.h)        */
-    int32_t pad;
+    int32_t force_prune_rows;  /* > 0: pruned scans whenever the table has at least this many rows, whatever the samples said (round
+                                * 6: behind k_seed16's seeds and the tight threshold a pruned chain returns what the plain scan returns,
+                                * and from a few thousand rows on at a fraction of its time - also while the table still fills)  */
 } cc_policy_config;
 typedef struct cc_policy_carry {
     int32_t adapt_win, clean_batches, since_shrink, pad;

@@ -39,6 +39,14 @@ KNOBS = {
     # 10 000 rows on), with pruning forced so that the small tables of these suites run it at all
     "split pruned scan forced": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANA=2),
     "split pruned scan off": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANA=0),
+    # round 6: the prefix test on the matrix cores (k_scan_p3) is the default; the packed-FP32 forms behind it
+    "prefix test on the VALU": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANP3=0),                            # k_scan_p2
+    "prefix test one point per lane": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_SCANP3=0, CHRONOCLUST_HIP_SCANP2=0),  # k_scan_p
+    "kept rows listed": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_P3_LISTED=0),  # k_scan_p3<LISTED> whatever the table size
+    "missed points through the seeded chain": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_MISSED_PLAIN=0),
+    # seeds of the seeded chain from the matrix cores + the tight threshold (k_seed16, k_seed_merge with F <= 0)
+    "seeds from the matrix cores": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_GUESS=0, CHRONOCLUST_HIP_SEED16=1),
+    "no pruning outside the common case": dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_PRUNE_GENERAL=0),  # pdim filter / k != 2^e: k_scan only
 }
 
 
@@ -90,12 +98,15 @@ def test_seeded_cases_under_knob(knob, case):
     filter_on = 0 < float(cfg["pi"]) < d
     applies_u = pow2 and not filter_on and d in (4, 8, 14, 16, 20, 32, 40, 64)
     env = KNOBS[knob]
+    # (round 6) outside the common case - the pdim filter on, k not a power of two - the pruned chain is k_scan_p3<GENERAL>
+    applies_g = (not pow2 or filter_on) and d in (14, 16, 20, 32, 40) and env.get("CHRONOCLUST_HIP_SCANP3", 1) != 0 and \
+        env.get("CHRONOCLUST_HIP_PRUNE_GENERAL", 1) != 0
     if tot["windows"] > 0:
         expect_u = applies_u and env.get("CHRONOCLUST_HIP_SCANU", 1) != 0
         assert (tot["scan_u_launches"] > 0) == expect_u
-        if env.get("CHRONOCLUST_HIP_PRUNE") == 0 or not expect_u or d <= 8:
+        if env.get("CHRONOCLUST_HIP_PRUNE") == 0 or not (expect_u or applies_g) or d <= 8:
             assert tot["scan_p_launches"] == 0
-        if env.get("CHRONOCLUST_HIP_PRUNE") == 2 and expect_u and d > 8:
+        if env.get("CHRONOCLUST_HIP_PRUNE") == 2 and (expect_u or applies_g) and d > 8:
             assert tot["scan_p_launches"] > 0
         if env.get("CHRONOCLUST_HIP_GUESS") == 0:
             assert tot["scan_g_launches"] == 0
