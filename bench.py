@@ -57,10 +57,22 @@ FP64_VALU_PEAK_TOPS = 39.3     # 78.6 TFLOP/s FP64 vector counts an FMA as 2: 39
 PMC_TRAFFIC_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")
 PMC_BENCH_STEP_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_bench_step.json")  # tools/pmc_bench_step.py: counted on bench.py itself
 PMC_VALU_GLOB = os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_valu_d%d%s.json")  # (% (d, "" | "_plain")), tools/pmc_valu_summary.py
-PRUNED_CHAIN = ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p", "k_scan_p2")  # kernels of a pruned snapshot scan as the PMC summaries name them
+PRUNED_CHAIN = ("k_seed", "k_seed_merge", "k_scan_a", "k_scan_p", "k_scan_p2", "k_prefix16", "k_scan_p3")  # kernels of a pruned snapshot scan as the PMC summaries name them
 SCAN_SOURCES = ("cc_scan.h", "cc_common.h", "cc_div.h")  # what defines the snapshot-scan kernels the PMC files describe
 REFERENCE_RATE_FILE = os.path.join(ROOT, "profiles", "reference_py_rate.json")
 EXIT_LEG_FAILED = 3
+
+
+def kernel_short(name):
+    """rocprofv3 leaves some template instances mangled (_Z9k_scan_p3ILi20ELi4ELb0ELb0EEv...): the function's own name, marked as
+    a template instance, so that prefix matches written for demangled names ("k_scan_p3<") keep working."""
+    import re
+    name = re.sub(r"^void ", "", str(name))
+    m = re.match(r"_Z(\d+)", name)
+    if m:
+        n = int(m.group(1))
+        return name[m.end():m.end() + n] + "<mangled>"
+    return re.sub(r"\(.*", "", name)
 
 
 def csrc_digest(names=None):
@@ -148,7 +160,7 @@ def compact_line(full, detail_file=None):
     rf = full.get("roofline")
     if rf:
         ex = (rf.get("executed") or {}).get("kernels") or {}
-        dom = ex.get("k_scan_p") or ex.get("k_scan_u") or {}
+        dom = ex.get("k_scan_u") or ex.get("k_scan_p3") or ex.get("k_scan_p") or {}  # (by time the plain scan of the start-up windows dominates since round 6)
         hbm = rf.get("hbm") or {}
         line["roofline"] = {
             "bound": rf.get("bound"), "kernel": str(rf.get("kernel", ""))[:120], "achieved": rf.get("achieved"),
@@ -515,7 +527,7 @@ def load_pmc_valu(d):
         for kname, k in pm["kernels"].items():
             out[kname] = dict(k, source=name)
     # (the window's pruned scan is k_scan_p2 since round 6; k_scan_p where that is switched off or does not apply)
-    if "k_scan_u" in out and ("k_scan_p" in out or "k_scan_p2" in out):
+    if "k_scan_u" in out and ("k_scan_p" in out or "k_scan_p2" in out or "k_scan_p3" in out):
         return out, files, full
     return None, why or "incomplete PMC files for d = %d" % d, None
 
@@ -641,7 +653,7 @@ def counted_on_bench(rf, cfg, scan_ms_per_step, ms_per_step):
 def scan_kernel_name(s, d):
     if s.get("scan_p_launches", 0) > 0:
         if s.get("scan_p2_launches", 0) > 0:
-            return "k_scan_p2<%d, 4> (pruned; + k_seed, k_seed_merge while seeded) / k_scan_u<%d, 4> (plain)" % (d, d)
+            return "k_scan_u<%d,4> (plain: start-up) / k_prefix16 + k_scan_p3<%d,4> (pruned, MFMA prefix test: steady state)" % (d, d)
         return "k_seed<%d, 4> + k_seed_merge + k_scan_p<%d, 4> (pruned) / k_scan_u<%d, 4>" % (d, d, d)
     return ("k_scan_u<%d, 4>" % d) if s.get("scan_u_launches", 0) > 0 else "k_scan<%d, DIRTY=false>" % d
 
@@ -1026,7 +1038,7 @@ def main():
             n_pts = n * args.steps
             alg_bytes = n_pts * (8 * d + 4) + table_rows * (16 * d + 8)
             hbm = alg_bytes / (scan_ms * 1e-3) / 1e9
-            out["roofline"] = scan_roofline(pacc, d, scan_kernel_name(s, d) + " (snapshot scan)")
+            out["roofline"] = scan_roofline(pacc, d, scan_kernel_name(s, d))
             out["roofline"].update({
                 "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": alg_bytes / scan_launches,

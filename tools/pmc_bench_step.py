@@ -20,7 +20,7 @@ import bench  # noqa: E402
 d, detail_path, n_steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
 df = pd.read_csv(f)
-df["name"] = df["Kernel_Name"].str.replace(r"^void ", "", regex=True).str.replace(r"\(.*", "", regex=True)
+df["name"] = df["Kernel_Name"].map(bench.kernel_short)
 g = df.groupby(["name", "Dispatch_Id", "Counter_Name"])["Counter_Value"].sum().unstack().reset_index()
 t = df.groupby(["name", "Dispatch_Id"]).agg(s=("Start_Timestamp", "first"), e=("End_Timestamp", "first")).reset_index()
 g = g.merge(t, on=["name", "Dispatch_Id"])
@@ -41,7 +41,7 @@ for name, sub in g.groupby("name"):
 
 
 def is_scan(name):
-    return name.startswith(("k_scan_u<", "k_scan_p<", "k_scan_p2<", "k_scan_a<", "k_seed<", "k_seed_merge<", "k_missed")) or \
+    return name.startswith(("k_scan_u<", "k_scan_p<", "k_scan_p2<", "k_scan_p3<", "k_prefix16<", "k_seed16<", "k_scan_a<", "k_seed<", "k_seed_merge<", "k_missed")) or \
         (name.startswith("k_scan<") and ", false, " in name)  # (k_scan<DP, FILTER, POW2, DIRTY=false, NW>: the LDS-staged snapshot scan)
 
 
@@ -56,7 +56,7 @@ out = {
     "ms_per_step_under_pmc": detail["ms_per_step"],
     "snapshot_scan": {
         "kernels": sorted(scan),
-        "launches_per_step": sum(v["launches_per_step"] for k, v in scan.items() if k.startswith(("k_scan_u<", "k_scan_p<", "k_scan_p2<", "k_scan<"))),
+        "launches_per_step": sum(v["launches_per_step"] for k, v in scan.items() if k.startswith(("k_scan_u<", "k_scan_p<", "k_scan_p2<", "k_scan_p3<", "k_scan<"))),
         "instruction_lanes_per_step": sum(v["instruction_lanes_per_step"] for v in scan.values()),
         "us_per_step_under_pmc": sum(v["us_per_step_under_pmc"] for v in scan.values()),
     },

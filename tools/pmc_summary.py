@@ -13,7 +13,8 @@ import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 
-CHAIN = ("k_seed<", "k_seed_merge", "k_scan_p<", "k_missed", "k_scan_u<")
+# (k_scan_p3 / k_prefix16: rocprofv3 leaves these template instances mangled - matched without the "<")
+CHAIN = ("k_seed<", "k_seed_merge", "k_scan_p<", "k_scan_p2<", "k_prefix16", "k_scan_p3", "k_missed", "k_scan_u<")
 HEADS = ("k_scan_u<",)
 
 

@@ -54,7 +54,8 @@ if len(sys.argv) > 7 and os.path.exists(sys.argv[7]):
 
 out = {"shape": "%d points x %d microclusters x %d dims per launch, running alone (tools/steady.py, LA=2)" % (WINDOW, ROWS, D),
        "csrc_sha256": bench.csrc_digest(), "scan_sha256": bench.scan_digest(), "rows_evaluated_in_full_frac": FULL, "dim": D, "rows": ROWS, "window": WINDOW, "kernels": {}}
-for pat in ("k_seed<", "k_seed_merge", "k_scan_a<", "k_scan_p<", "k_scan_p2<", "k_scan_u<"):
+# (k_scan_p3 / k_prefix16: rocprofv3 leaves these instances mangled - matched without the "<")
+for pat in ("k_seed<", "k_seed_merge", "k_scan_a<", "k_scan_p<", "k_scan_p2<", "k_prefix16", "k_scan_p3", "k_scan_u<"):
     a, na = full_launches(sys.argv[1], pat)
     b, nb = full_launches(sys.argv[2], pat)
     c, nc = full_launches(sys.argv[3], pat)
@@ -91,7 +92,7 @@ for pat in ("k_seed<", "k_seed_merge", "k_scan_a<", "k_scan_p<", "k_scan_p2<", "
     else:
         k["co_limiter"] = "scalar-load waits and wave-launch overheads"
     out["kernels"][pat.rstrip("<")] = k
-if ("k_scan_p" in out["kernels"] or "k_scan_p2" in out["kernels"]) and "k_scan_u" in out["kernels"]:
+if ("k_scan_p" in out["kernels"] or "k_scan_p2" in out["kernels"] or "k_scan_p3" in out["kernels"]) and "k_scan_u" in out["kernels"]:
     # (with the pruned scan on, k_scan_u only ran on the short windows of the build-up run: its per-row figures would
     # be scaled by the wrong window; the plain scan's own are in the *_plain.json file, measured with CHRONOCLUST_HIP_PRUNE=0)
     del out["kernels"]["k_scan_u"]

@@ -18,7 +18,8 @@ df = pd.read_csv(f)
 df["dur"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
 name = df["Kernel_Name"]
 parts = {"k_seed": name.str.contains("k_seed<"), "k_seed_merge": name.str.contains("k_seed_merge"),
-         "k_scan_p": name.str.contains("k_scan_p<"), "k_missed": name.str.contains("k_missed"), "k_scan_u": name.str.contains("k_scan_u<"),
+         "k_scan_p": name.str.contains("k_scan_p<"), "k_scan_p2": name.str.contains("k_scan_p2<"), "k_scan_p3": name.str.contains("k_scan_p3", regex=False),
+         "k_prefix16": name.str.contains("k_prefix16", regex=False), "k_missed": name.str.contains("k_missed"), "k_scan_u": name.str.contains("k_scan_u<"),
          "k_scan (LDS-staged, clean)": name.str.contains(r"k_scan<\d+, (?:true|false), (?:true|false), false", regex=True)}
 out = {"kernels": {}}
 total = 0.0
@@ -37,7 +38,14 @@ out["probes"] = probes
 # Every pruned launch has exactly one window-level k_scan_p; a k_missed is followed by one more (over the list of missed
 # points, same launch), a probe has one of its own (inside a plain launch); lean guessed scans are a k_scan_p and nothing else.
 calls = {k: out["kernels"].get(k, {}).get("calls", 0) for k in parts}
-chains = calls["k_scan_p"] - calls["k_missed"] - probes + calls["k_scan_u"] + calls["k_scan (LDS-staged, clean)"]
+# (round 6: the window's pruned scan is k_scan_p3 - k_scan_p2 / k_scan_p behind knobs -, and the points a guessed threshold
+# missed go through k_scan_u over their list: one small k_scan_u per k_missed; k_scan_p then only runs in probes)
+missed_plain = calls["k_scan_p3"] + calls["k_scan_p2"] > 0
+if missed_plain:
+    chains = calls["k_scan_p3"] + calls["k_scan_p2"] + max(0, calls["k_scan_p"] - probes) + calls["k_scan_u"] - calls["k_missed"] + \
+        calls["k_scan (LDS-staged, clean)"]
+else:
+    chains = calls["k_scan_p"] - calls["k_missed"] - probes + calls["k_scan_u"] + calls["k_scan (LDS-staged, clean)"]
 out["scan_chains"] = chains
 out["rocprof_avg_chain_us"] = total / chains if chains else None
 line = json.load(open(sys.argv[2]))

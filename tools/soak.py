@@ -37,6 +37,8 @@ def main():
         cases = [("fuzz la=3", lambda s: F.test_fuzz_case(s, 3)),
                  ("fuzz la=2", lambda s: F.test_fuzz_case(s, 2)),
                  ("forced pruning", lambda s: P.test_forced_pruning_fuzz(s)),
+                 # (round 6: the pruned chain outside the common case - pdim filter on, k not a power of two; the suite holds seeds 0-71)
+                 ("forced pruning, filter / any k", lambda s: P.test_forced_pruning_fuzz_with_the_pdim_filter_and_any_k(s)),
                  ("register sequential kernel", lambda s: S.test_register_resident_sequential_kernel_fuzz(s)),
                  # (the general fuzz cases with the sequential kernels forced: k_seq, and k_seq_g beyond its image)
                  ("fuzz sequential", lambda s: S.test_fuzz_case_sequential(s))]
