@@ -1054,7 +1054,10 @@ int cc_create(int device, cc_handle** out)
         if (hipHostMalloc((void**)&h->hc_pin, 2 * sizeof(Ctl), hipHostMallocDefault) != hipSuccess) h->hc_pin = nullptr;
         h->badflag.ensure(4);
         memset(&h->hc, 0, sizeof(Ctl));
-        h->tun.window = 32768;
+        // (round 6: the largest window - with the scans in place, what a window costs whatever its size (launches, prologues, the
+        // validation kernels' chains of round trips: ~100 us) is a larger share of a shorter one: C2 13.98 -> 13.32 ms, the C5 shape
+        // 75 -> 85 M points/s; the policy holds it at 32 768 while the table is small - cc_policy.h, `win`)
+        h->tun.window = CC_MAX_WINDOW;
         h->tun.rounds = 3;
         h->tun.segments = 64;
         h->tun.windows_per_sync = 16;

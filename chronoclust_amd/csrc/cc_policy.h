@@ -98,7 +98,11 @@ public:
     // a batch of windows has run; `o` = the cumulative counters now
     cc_policy_decision after_batch(const cc_policy_obs& o)
     {
-        const int Rmax = c_.rounds_max, win = c_.window;
+        // (the configured window while a microcluster takes at most a dozen of a window's points on average; with fewer
+        // microclusters - the C4 shape: 2 000 - a window of 49 152 points makes chains of more claimants than the member lists hold
+        // the rule rather than the exception: 32 768 there, as before round 6)
+        const int Rmax = c_.rounds_max;
+        const int win = (c_.window > 32768 && (long long)o.m_rows * 12 < (long long)c_.window) ? 32768 : c_.window;
         const int early_win = c_.early_window > 0 ? c_.early_window : 4096;
         const long long done_before = prev_.cursor, done = o.cursor;
         // ---- pruned scans: on while the rows they still evaluate in full stay a minority ----

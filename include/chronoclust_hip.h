@@ -78,7 +78,7 @@ typedef struct cc_params {
 
 /* Tuning knobs of the exact windowed online path (0 = library default). */
 typedef struct cc_tuning {
-    int32_t window;          /* points speculated per window (<= 49152, default 32768) */
+    int32_t window;          /* points speculated per window (<= 49152 = the default since round 6) */
     int32_t rounds;          /* max validation rounds per window                 */
     int32_t segments;        /* microcluster-range segments per point tile       */
     int32_t windows_per_sync;/* windows enqueued between host read-backs         */

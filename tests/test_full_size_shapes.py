@@ -200,7 +200,7 @@ def test_c5_shape_pruned_equals_plain_on_the_settled_table():
             for key in ("id", "uid", "w", "cf1", "cf2", "cen", "pref"):
                 assert np.array_equal(a[key], b[key]), (name, kind, key)
         assert [c.members_in_merge_order for c in h.final_clusters] == [c.members_in_merge_order for c in base.final_clusters]
-    assert runs["plain"][0] == 0 and runs["plain"][1] >= m // 32768
+    assert runs["plain"][0] == 0 and runs["plain"][1] >= m // 49152  # (49 152: the largest window, the default since round 6)
     assert runs["one kernel"][0] == runs["one kernel"][1] > 0 and runs["split"][0] == runs["split"][1] > 0
     assert st0["scan_p_launches"] > 0 and st0["rows"] == g
 

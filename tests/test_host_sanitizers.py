@@ -73,7 +73,7 @@ for i in range(3000):
     o["after_sequential"] = 1 if rng.random() < 0.02 else 0
     obs.append(o)
 decs, carry = _lib.policy_replay(cfg, (0, 0, 1000), (0, 0), obs)
-assert len(decs) == len(obs) + 1 and all(64 <= d["win_cfg"] <= 32768 or d["win_cfg"] == 32768 for d in decs[1:])
+assert len(decs) == len(obs) + 1 and all(64 <= d["win_cfg"] <= 49152 for d in decs[1:])
 
 # the formatter's corpus (tests/test_host_logic.py's, enlarged to 65 000 values) on a pool of threads
 specials = [0.0, -0.0, 1.0, -1.0, 0.1, 1e-4, 9.999e-5, 1e-5, 1.5e-5, 123456789.0, 1e15, 1e16, 9999999999999998.0,

@@ -63,7 +63,7 @@ def test_the_traces_cover_the_regimes():
     # (cc_policy.h, `short_scan`); while the scans are still plain and the stream is calm, lookahead scans run
     c2 = by_name["c2_startup_and_steady"][0]
     sizes = [c2[3]["win_cfg"]] + [d["win_cfg"] for _, d in c2[4]]
-    assert sizes[0] == 256 and 4096 in sizes and sizes[-1] == 32768 and max(sizes[:4]) <= 4096
+    assert sizes[0] == 256 and 4096 in sizes and sizes[-1] == 49152 and max(sizes[:4]) <= 4096  # (49 152: the default since round 6)
     last = c2[4][-1][1]
     # (prune 2: pruned scans with guessed thresholds - a mean join distance exists by then, few points are missed;
     #  prune 3: the same without the list of missed points, after a batch in which none was missed)

@@ -65,7 +65,9 @@ for SH in "${SHAPES[@]}"; do
     D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PA --output-format csv -d $OUT/pmc_valu_a_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_a_d$1$SUF.txt 2>&1 || exit 1
     D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PB --output-format csv -d $OUT/pmc_valu_b_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_b_d$1$SUF.txt 2>&1 || exit 1
     D=$1 G=$2 N=$3 LA=2 REPS=1 rocprofv3 --pmc $PC --output-format csv -d $OUT/pmc_valu_c_d$1$SUF -o r -- python tools/steady.py > $OUT/pmc_valu_c_d$1$SUF.txt 2>&1 || exit 1
-    python tools/pmc_valu_summary.py $OUT/pmc_valu_a_d$1$SUF $OUT/pmc_valu_b_d$1$SUF $OUT/pmc_valu_c_d$1$SUF $1 $2 32768 $OUT/pmc_valu_a_d$1$SUF.txt > $OUT/pmc_valu_d$1$SUF.json
+    # (the window the policy settles on: the library's default, 49 152, or 32 768 while the table has fewer than a twelfth as many rows)
+    W=49152; [ $(( $2 * 12 )) -lt 49152 ] && W=32768
+    python tools/pmc_valu_summary.py $OUT/pmc_valu_a_d$1$SUF $OUT/pmc_valu_b_d$1$SUF $OUT/pmc_valu_c_d$1$SUF $1 $2 $W $OUT/pmc_valu_a_d$1$SUF.txt > $OUT/pmc_valu_d$1$SUF.json
   done
 done
 unset CHRONOCLUST_HIP_PRUNE
