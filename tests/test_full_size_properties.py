@@ -70,14 +70,14 @@ def test_c2_labels_do_not_depend_on_window_or_segments(c2):
                                  dict(CHRONOCLUST_HIP_PRUNE=2, CHRONOCLUST_HIP_GUESS=0), dict(CHRONOCLUST_HIP_LINK=0, CHRONOCLUST_HIP_NODIRTY=0)],
                          ids=["plain_scans", "pruned_forced_split", "seeded_thresholds_only", "no_links_dirty_scans_always"])
 def test_c2_pruned_steady_state_equals_plain_scans_at_full_size(c2, env):
-    """The pruned chain at C2's own size - 5 000 rows, 32 768-point windows, guessed / lean thresholds, lookahead: the 800 000
+    """The pruned chain at C2's own size - 5 000 rows, full windows, guessed / lean thresholds: the 800 000
     points behind the start-up phase - against the PLAIN scan of every window (CHRONOCLUST_HIP_PRUNE=0), against the pruned
     chain forced from the first window on in its two-kernel form, and against seeded thresholds only: bit for bit.  (The
     tunings of the test above all prune; a threshold bug that only shows at full size would be invariant under them.
     tools/full_oracle.py runs the whole stream through the oracle - minutes of CPU, recorded under profiles/.)"""
     from chronoclust_amd.clustering.hddstream import HDDStream
     X, cfg, h = c2
-    assert h.stats()["scan_p_launches"] > 20  # (the default run's steady state is pruned)
+    assert h.stats()["scan_p_launches"] >= 15  # (the default run's steady state is pruned: ~800 000 points in windows of 49 152)
     with P.knobs(**env):
         g = HDDStream(cfg)
     g.online_microcluster_maintenance(X, 0)
